@@ -1,0 +1,217 @@
+"""bench.py -- images/sec of the YOLOStereo3D forward path (BASELINE.json configs[1]: Stereo3D ResNet-34,
+384x1280 stereo pairs, bf16, batch 8 per MI355X), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = one test_forward_batched-equivalent pass over one batch of synthetic pairs already resident in HBM:
+stem -> ResNet-34 (L and R stacked) -> cost volumes -> ghost pyramid -> head towers -> device-side decode/NMS ->
+(N > 1: RCCL all_gather of the padded detections, the only collective) -> one host sync for the counts.
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GFLOP_PER_PAIR = 473.82          # conv/GEMM 2*MAC per 384x1280 pair (Stereo3D R34)
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=8, help='stereo pairs per GPU per step')
+    ap.add_argument('--height', type=int, default=384)
+    ap.add_argument('--width', type=int, default=1280)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying a hipGraph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3D
+    from visualdet3d_amd.utils import synthetic as syn
+    tmp = tempfile.mkdtemp()
+    cfg = syn.stereo3d_cfg(tmp, depth=34, score_thr=0.75, nms_iou_thr=0.4)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    model = Stereo3D(cfg)
+    sd = syn.seeded_state_dict(model.state_dict(), seed=1, head_std=0.00042)
+    model.load_state_dict(sd)
+    model = model.to(device).eval()
+    model.compute_dtype = torch.bfloat16 if args.dtype == 'bf16' else torch.float32
+    return model, cfg, sd
+
+
+def profile_convs(model, inputs, reps=3):
+    """Per-launch HIP-event timing of the dominant kernel family (conv_igemm) on the launch stream.
+    Returns (total_flops_per_step, total_seconds_per_step, n_launches)."""
+    from visualdet3d_amd import hip_ops as ops
+    records = []
+    orig = ops.conv2d
+
+    def timed(x, pc, out=None, residual=None, relu=False, out_f32=False):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        o = orig(x, pc, out=out, residual=residual, relu=relu, out_f32=out_f32)
+        e.record()
+        B, Ho, Wo, Co = o.shape
+        records.append((2.0 * B * Ho * Wo * Co * pc.kh * pc.kw * pc.Cin, s, e))
+        return o
+
+    ops.conv2d = timed
+    try:
+        with torch.no_grad():
+            for _ in range(reps):
+                model.forward_device(*inputs)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d = orig
+    flops = sum(r[0] for r in records) / reps
+    secs = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3 / reps
+    return flops, secs, len(records) // reps
+
+
+def cpu_baseline(cfg, sd, args):
+    """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) on a bounded sample."""
+    from oracle import detector_oracle as orc
+    from visualdet3d_amd.utils import synthetic as syn
+    torch.set_num_threads(os.cpu_count() or 1)
+    L, R = syn.stereo_pair(1, args.height, args.width, seed=0)
+    P2, _ = syn.kitti_calib(args.width, batch=1)
+    sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        orc.stereo3d_forward(sd_cpu, cfg, L, R, P2)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            orc.stereo3d_forward(sd_cpu, cfg, L, R, P2)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > args.cpu_seconds or n >= 20:
+                break
+    return dict(value=n / el, unit='img/s', cores=torch.get_num_threads(), kind='port',
+                sample='%d fp32 batch-1 %dx%d stereo pairs through oracle/detector_oracle.py in %.1f s' % (n, args.height, args.width, el))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = world > 1
+    if dist:
+        import torch.distributed as td
+        td.init_process_group(backend='nccl', init_method='env://')
+    assert torch.cuda.is_available(), 'bench.py measures the MI355X HIP path; no GPU visible'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+
+    from visualdet3d_amd.utils import synthetic as syn
+    model, cfg, sd = build_model(args, device)
+    B = args.batch
+    L, R = syn.stereo_pair(B, args.height, args.width, seed=100 + rank)
+    P2, P3 = syn.kitti_calib(args.width, batch=B)
+    L, R, P2 = L.to(device), R.to(device), P2.to(device)   # inputs resident in HBM before the timed region
+    inputs = (L, R, P2)
+
+    graph = None
+    static_out = None
+    with torch.no_grad():
+        for _ in range(2):                       # packs weights, builds anchor tables, warms the allocator
+            static_out = model.forward_device(*inputs)
+        torch.cuda.synchronize()
+        if not args.no_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model.forward_device(*inputs)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = model.forward_device(*inputs)
+
+    gather_buf = None
+    if dist:
+        import torch.distributed as td
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            out = static_out
+        else:
+            with torch.no_grad():
+                out = model.forward_device(*inputs)
+        scores, boxes, labels, aidx, count = out
+        if dist:
+            # the trivial batch gather: fixed-size padded detections over RCCL/xGMI (latency bound, ~100 KB)
+            k = min(scores.shape[1], 128)
+            pack = torch.cat([scores[:, :k, None], boxes[:, :k], labels[:, :k, None].float()], dim=2).contiguous()
+            outs = [torch.empty_like(pack) for _ in range(world)]
+            cnts = [torch.empty_like(count) for _ in range(world)]
+            td.all_gather(outs, pack)
+            td.all_gather(cnts, count)
+            count = torch.stack(cnts)
+        return count.cpu()                       # the one host sync: detection counts
+
+    for _ in range(args.warmup):
+        step()
+    if dist:
+        td.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    torch.cuda.synchronize()
+    if dist:
+        td.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert int(counts.min()) >= 0, 'candidate overflow in the head post-processing'
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        flops, secs, nl = profile_convs(model, inputs)
+        peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
+        ach = flops / secs / 1e12
+        line = {
+            'metric': 'images/sec at 384x1280 stereo (YOLOStereo3D ResNet-34 forward incl. decode+NMS)',
+            'value': round(value, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'Stereo3D_example (YOLOStereo3D, ResNet-34) %dx%d stereo pairs, batch=%d per GPU'
+                                   % (args.height, args.width, B),
+                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (all %d launches per step)' % nl,
+                         'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                         'traffic': None,
+                         'whole_path_frac': round(value / world * GFLOP_PER_PAIR * (args.height * args.width) / (384 * 1280) / 1e3 / peak, 4)},
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg, sd, args)
+        print(json.dumps(line))
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,189 @@
+/*
+ * vd3d.h -- C-ABI of libvd3d_hip.so: the MI355X (gfx950) native operator set behind the visualDet3D
+ * detector forward path (YOLOStereo3D / GroundAware-Mono3D / KM3D).
+ *
+ * Boundary rules:
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless the name says host;
+ *   - activations are NHWC ("channels-last"), element type selected by `dtype` (VD3D_BF16 / VD3D_F32);
+ *   - every entry point takes the hipStream_t to launch on (as void*) and returns 0 or a negative
+ *     VD3D_E* code -- never exit()/printf like the reference's extensions do
+ *     (lib/ops/iou3d/src/iou3d.cpp:13-21, lib/ops/dcn/src/cuda/deform_conv_cuda_kernel.cu:272-276);
+ *   - nothing here allocates: callers own every buffer (the reference allocates temporaries inside the
+ *     extension: deform_conv_cuda.cpp:527,533; iou3d.cpp:87,98).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the reference root,
+ * visualDet3D/networks/...).
+ */
+#ifndef VD3D_H
+#define VD3D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VD3D_BF16 0
+#define VD3D_F32 1
+
+#define VD3D_OK 0
+#define VD3D_EINVAL (-1)   /* bad argument (shape / alignment / dtype) */
+#define VD3D_ELAUNCH (-2)  /* HIP launch error (hipGetLastError) */
+#define VD3D_ERANGE (-3)   /* tensor too large for 32-bit element offsets */
+
+/* ABI version, bumped on any signature change. */
+int vd3d_abi_version(void);
+/* Human-readable text of the last HIP error seen by this thread (host pointer, never NULL). */
+const char* vd3d_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused implicit-GEMM convolution:  out = act( conv(in, W) * scale + shift (+ residual) )
+ * Replaces nn.Conv2d + BatchNorm2d(eval) + ReLU (+ residual add) chains:
+ *   backbones/resnet.py:23-52,55-91 (BasicBlock / Bottleneck), lib/blocks.py:24-43 (ConvBnReLU),
+ *   lib/ghost_module.py:27-32 (primary conv), heads/detection_3d_head.py:54-79,508-530 (head towers),
+ *   lib/PSM_cost_volume.py:29-33 (1x1 down-sample).
+ * GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = kh*kw*Cin (tap-major, channel-minor).
+ * MFMA: v_mfma_f32_32x32x16_bf16 (VD3D_BF16) or v_mfma_f32_32x32x2_f32 (VD3D_F32), fp32 accumulate.
+ */
+typedef struct vd3d_conv_params {
+    const void* in;        /* [B][H][W][>=Cin] activations; Cin contiguous elements per (pixel, tap)   */
+    const void* weight;    /* packed [CoutPad][Kpad], K index = (ky*kw + kx)*Cin + c, zero padded      */
+    const float* scale;    /* [Cout] or NULL (== 1)                                                    */
+    const float* shift;    /* [Cout] or NULL (== 0)                                                    */
+    const void* residual;  /* [M][>=Cout] same dtype as `in`, or NULL                                  */
+    void* out;             /* [M][>=Cout]                                                              */
+    int32_t B, H, W, Cin;  /* input geometry (H, W = bounds for the zero padding test)                */
+    int32_t in_pix_stride; /* elements between horizontally adjacent input pixels                      */
+    int32_t in_row_stride; /* elements between input rows                                              */
+    int64_t in_batch_stride;
+    int64_t in_bytes;      /* size in bytes of the allocation `in` points into, from `in` (bounds)    */
+    int32_t Ho, Wo, Cout;
+    int32_t out_pix_stride; /* elements between consecutive output pixels (dense [M] pixel order)      */
+    int32_t res_pix_stride;
+    int32_t kh, kw, stride, pad, dil;
+    int32_t Kpad;          /* padded K of the packed weight (multiple of 128 bytes / element size)    */
+    int32_t CoutPad;       /* rows of the packed weight (multiple of 128)                              */
+    int32_t relu;          /* 1: ReLU epilogue                                                         */
+    int32_t dtype;         /* VD3D_BF16 | VD3D_F32: element type of in / weight / residual             */
+    int32_t out_f32;       /* 1: write `out` as fp32 even when dtype is bf16 (final head convs)        */
+} vd3d_conv_params;
+
+int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream);
+
+/* Stem input packing: NCHW fp32 image -> zero-bordered NHWC4 (3 channels + 1 zero) so that one kernel row of
+ * the 7x7/s2 stem (backbones/resnet.py:118, conv1) is 8 px * 4 ch = 32 contiguous elements.
+ * out: [B][H+2*pad_y][W+pad_l+pad_r][4] of `dtype`; borders are written as zeros. */
+int vd3d_pack_image_nhwc4(const float* in_nchw, void* out, int B, int H, int W,
+                          int pad_y, int pad_l, int pad_r, int dtype, void* stream);
+
+/* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (backbones/resnet.py:121,193). */
+int vd3d_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C,
+                      int in_pix_stride, int out_pix_stride, int dtype, void* stream);
+/* nn.AvgPool2d(2) on NHWC (detectors/yolostereo3d_core.py:25,35). */
+int vd3d_avgpool2x2(const void* in, void* out, int B, int H, int W, int C,
+                    int in_pix_stride, int out_pix_stride, int dtype, void* stream);
+/* Depth-wise 3x3 (pad 1) + folded BN + ReLU on NHWC: lib/ghost_module.py:34-38 (cheap_operation).
+ * weight: [9][C] fp32 tap-major; scale/shift: [C] fp32. */
+int vd3d_dwconv3x3(const void* in, const float* weight, const float* scale, const float* shift, void* out,
+                   int B, int H, int W, int C, int in_pix_stride, int out_pix_stride, int relu,
+                   int dtype, void* stream);
+/* Strided NHWC channel-slice copy (torch.cat replacement when a producer cannot write in place). */
+int vd3d_copy_channels(const void* in, void* out, int64_t n_pix, int C, int in_pix_stride, int out_pix_stride,
+                       int dtype, void* stream);
+/* NHWC (dtype) -> NCHW fp32 and back: only at the module boundary (state taps, tests). */
+int vd3d_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int in_pix_stride,
+                          int dtype, void* stream);
+int vd3d_nchw_f32_to_nhwc(const float* in, void* out, int B, int H, int W, int C, int out_pix_stride,
+                          int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Stereo cost volumes.
+ * PSMCosineModule.forward (lib/PSM_cost_volume.py:81-96):
+ *   cost[b,y,x,d] = (1/C) * sum_c L[b,y,x,c] * R[b,y,x-d,c]   for x >= d, else 0;   d in [0, D)
+ * left/right: NHWC [B][H][W][C]; cost: NHWC [B][H][W][D] written with out_pix_stride (concat slice). */
+int vd3d_psm_cosine(const void* left, const void* right, void* cost, int B, int H, int W, int C, int D,
+                    int in_pix_stride, int out_pix_stride, int dtype, void* stream);
+/* CostVolume.forward concat-volume build (lib/PSM_cost_volume.py:49-64), channels-last:
+ *   vol[b,d,y,x,0:F]  = L[b,y,x,:] (x >= d else 0);  vol[b,d,y,x,F:2F] = R[b,y,x-d,:] (x >= d else 0). */
+int vd3d_costvol_build(const void* left, const void* right, void* vol, int B, int H, int W, int F, int D,
+                       int in_pix_stride, int dtype, void* stream);
+/* Conv3d(3x3x3, pad 1) + folded BN3d + ReLU, channels-last [B][D][H][W][Cin] (lib/PSM_cost_volume.py:34-41).
+ * weight: [27][Cin][Cout] fp32.  If out_fd_major != 0 the result is written as NHWC [B][H][W][Cout*D] with
+ * channel = f*D + d (the reshape at PSM_cost_volume.py:66-67) using out_pix_stride. */
+int vd3d_conv3d_3x3x3(const void* in, const float* weight, const float* scale, const float* shift, void* out,
+                      int B, int D, int H, int W, int Cin, int Cout, int relu, int out_fd_major,
+                      int out_pix_stride, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Anchor head post-processing (heads/detection_3d_head.py:341-400 get_bboxes, :218-263 _decode,
+ * networks/utils/utils.py:186-196 ClipBoxes, heads/anchors.py:99-111 ground filter, torchvision nms).
+ * One launch covers B samples; per-sample results are identical to the reference's batch-1 path.
+ *   cls   [B][N][n_cls+1] fp32 logits (last = alpha bin), reg [B][N][12] fp32
+ *   anchors [N][4] fp32; prior_mean_std [A][types][6][2] fp32 (A = anchors per cell, N = cells*A)
+ *   P2 [B][3][4] fp32
+ * Outputs (padded to max_det per sample, decreasing score == torchvision nms order):
+ *   out_scores [B][max_det], out_boxes [B][max_det][11], out_labels [B][max_det] int32,
+ *   out_anchor [B][max_det] int32 (flat anchor index), out_count [B] int32
+ * workspace: see vd3d_head_workspace_bytes.  If more than max_cand anchors pass the score threshold in a
+ * sample, out_count[b] = -1 (caller must raise). */
+typedef struct vd3d_head_params {
+    const float* cls;
+    const float* reg;
+    const float* anchors;
+    const float* prior_mean_std;
+    const float* P2;
+    int32_t B, N, A, n_cls, n_types;
+    int32_t img_h, img_w;
+    float score_thr, nms_iou_thr;
+    float filter_y_min, filter_y_max, filter_x_max;
+    int32_t use_filter;
+    int32_t max_cand, max_det;
+    void* workspace;
+    float* out_scores;
+    float* out_boxes;
+    int32_t* out_labels;
+    int32_t* out_anchor;
+    int32_t* out_count;
+} vd3d_head_params;
+int64_t vd3d_head_workspace_bytes(int B, int max_cand);
+int vd3d_head_postprocess(const vd3d_head_params* p, void* stream);
+
+/* torchvision.ops.nms replacement (call sites heads/detection_3d_head.py:386, heads/km3d_head.py:303):
+ * boxes [n][4] fp32, scores [n] fp32 -> keep [n] int32 (indices in decreasing-score order), count [1]. */
+int vd3d_nms(const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep, int32_t* count,
+             void* workspace, void* stream);
+int64_t vd3d_nms_workspace_bytes(int n);
+
+/* ------------------------------------------------------------------------------------------------
+ * iou3d (lib/ops/iou3d/src/iou3d.cpp:174-179 pybind surface; kernels iou3d_kernel.cu:223-348).
+ * boxes are BEV (x1,y1,x2,y2,ry) fp32.  nms variants take boxes pre-sorted by score and write the kept
+ * indices + count on the DEVICE (the reference copies the mask to the host and scans there). */
+int vd3d_boxes_overlap_bev(const float* boxes_a, int na, const float* boxes_b, int nb, float* out, void* stream);
+int vd3d_boxes_iou_bev(const float* boxes_a, int na, const float* boxes_b, int nb, float* out, void* stream);
+int vd3d_nms_bev(const float* boxes, int n, float thr, int normal, int32_t* keep, int32_t* count,
+                 void* workspace, void* stream);
+int64_t vd3d_nms_bev_workspace_bytes(int n);
+
+/* ------------------------------------------------------------------------------------------------
+ * Deformable convolution forward (lib/ops/dcn/src/deform_conv_ext.cpp:149-163; kernels
+ * deform_conv_cuda_kernel.cu:190-243 (v1), :570-633 (v2)).  NCHW fp32 in/out exactly like the reference
+ * extension; the bilinear-sampled columns are never materialised in HBM.
+ *   input [B][C][H][W], offset [B][dg*2*kh*kw][Ho][Wo] (y,x interleaved per tap), mask [B][dg*kh*kw][Ho][Wo]
+ *   (NULL => DCNv1), weight [O][C/g][kh][kw], bias [O] or NULL, output [B][O][Ho][Wo]. */
+int vd3d_deform_conv_forward(const float* input, const float* weight, const float* bias, const float* offset,
+                             const float* mask, float* output, int B, int C, int H, int W, int O,
+                             int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                             int dil_h, int dil_w, int groups, int deformable_groups, void* stream);
+
+/* LookGround sampling (lib/look_ground.py:44-69): builds [prior disparity; x] and bilinear-samples it
+ * (grid_sample, border padding, align_corners=True) at (x, y + y_shift).  NHWC.
+ *   x [B][H][W][C], disp [B][H][W] fp32 (= 0.1*tanh(conv)), P2 [B][3][4] (already /16 on rows 0..1)
+ *   out [B][H][W][C+1] with channel 0 = sampled prior disparity (cat order of look_ground.py:66). */
+int vd3d_look_ground_sample(const void* x, const float* disp, const float* P2s, void* out, int B, int H, int W,
+                            int C, int in_pix_stride, int out_pix_stride, float baseline, float elevation,
+                            int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VD3D_H */

@@ -1,0 +1,91 @@
+"""ORACLE tooling (build container only): run the REFERENCE ITSELF on CPU (through oracle/ref_shim.py) on
+seeded synthetic inputs and commit its outputs as golden fixtures under tests/golden/.
+
+    python -m oracle.make_golden            # regenerates every fixture (needs /root/reference)
+
+The fixtures pin (a) the restatement in oracle/detector_oracle.py and (b) -- on the GPU box, where the
+reference tree does not exist -- the HIP path, against the reference's own results.
+Weights/inputs are regenerated from seeds by visualdet3d_amd.utils.synthetic, so only outputs are stored.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _REPO not in sys.path:
+    sys.path.insert(0, _REPO)
+
+from oracle import ref_shim  # noqa: E402
+from visualdet3d_amd.utils import synthetic as syn  # noqa: E402
+
+GOLDEN_DIR = os.path.join(_REPO, 'tests', 'golden')
+
+# name -> (detector, depth, H, W, batch-of-frames (each run at B=1 through the reference), weight seed, input seed, score_thr)
+STEREO_CASES = {
+    'stereo3d_r34_96x320': dict(depth=34, H=96, W=320, frames=2, wseed=1, iseed=3, score_thr=0.5, head_std=0.0005),
+    'stereo3d_r34_384x1280': dict(depth=34, H=384, W=1280, frames=2, wseed=1, iseed=0, score_thr=0.75, head_std=0.00042),
+    'stereo3d_r34_384x1280_thr06': dict(depth=34, H=384, W=1280, frames=1, wseed=2, iseed=5, score_thr=0.6, head_std=0.009),
+}
+
+
+def build_reference_stereo(case, tmp):
+    DD = ref_shim.detector_dict()
+    cfg = syn.stereo3d_cfg(tmp, depth=case['depth'], score_thr=case['score_thr'])
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    model = DD['Stereo3D'](cfg).eval()
+    sd = syn.seeded_state_dict(model.state_dict(), seed=case['wseed'], head_std=case['head_std'])
+    model.load_state_dict(sd)
+    return model, cfg, sd
+
+
+def subsample(t, n=4096):
+    """Deterministic strided sample of a tensor (keeps fixtures small)."""
+    flat = t.reshape(-1)
+    step = max(1, flat.numel() // n)
+    return flat[::step][:n].clone()
+
+
+def run_stereo_case(name, case):
+    tmp = tempfile.mkdtemp()
+    model, cfg, sd = build_reference_stereo(case, tmp)
+    L, R = syn.stereo_pair(case['frames'], case['H'], case['W'], seed=case['iseed'])
+    P2, P3 = syn.kitti_calib(case['W'], batch=case['frames'])
+    out = {}
+    with torch.no_grad():
+        for f in range(case['frames']):
+            l, r, p2, p3 = L[f:f + 1], R[f:f + 1], P2[f:f + 1].clone(), P3[f:f + 1].clone()
+            # stage taps, straight from the reference modules
+            core = model.core(torch.cat([l, r], dim=1))
+            feats = core['features']
+            cls_preds, reg_preds = model.bbox_head(dict(features=feats, P2=p2, image=l))
+            model.bbox_head.anchors.P2 = None  # defeat the per-P2 cache so every frame recomputes its mask
+            scores, boxes, labels = model([l, r, p2, p3])
+            out['f%d_scores' % f] = scores.numpy()
+            out['f%d_boxes' % f] = boxes.numpy()
+            out['f%d_labels' % f] = labels.numpy()
+            out['f%d_features_sub' % f] = subsample(feats).numpy()
+            out['f%d_cls_sub' % f] = subsample(cls_preds).numpy()
+            out['f%d_reg_sub' % f] = subsample(reg_preds).numpy()
+            out['f%d_mask_sum' % f] = np.int64(model.bbox_head.anchors.useful_mask.sum().item())
+            print(name, 'frame', f, 'detections', len(scores), 'labels', np.bincount(labels.numpy(), minlength=2))
+    out['meta'] = np.array([case['depth'], case['H'], case['W'], case['frames'], case['wseed'], case['iseed']])
+    out['score_thr'] = np.float32(case['score_thr'])
+    out['head_std'] = np.float64(case['head_std'])
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + '.npz'), **out)
+    return model, cfg, sd, (L, R, P2, P3), out
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only = sys.argv[1:] or None
+    for name, case in STEREO_CASES.items():
+        if only and name not in only:
+            continue
+        run_stereo_case(name, case)
+
+
+if __name__ == '__main__':
+    main()

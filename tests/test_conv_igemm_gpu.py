@@ -1,0 +1,149 @@
+"""GPU: the fused implicit-GEMM conv kernel (vd3d_conv2d_igemm) against torch CPU fp32 convolution.
+fp32 mode (v_mfma_f32_32x32x2_f32, exact fp32 FMA chains): rtol 1e-5 of the output scale.
+bf16 mode: inputs/weights rounded to bf16 on both sides, fp32 accumulate, output rounded to bf16 -> 1 bf16 ulp."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(B, H, W, Cin, Cout, k, stride, pad, dil, residual, relu, dtype, bias=True, bn=True, in_extra=0, out_extra=0, out_f32=False, seed=0):
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1 if bias else None
+    bnp = None
+    if bn:
+        bnp = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1, torch.randn(Cout, generator=g) * 0.1,
+               torch.rand(Cout, generator=g) + 0.5, 1e-5)
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    # reference on CPU
+    y = F.conv2d(rnd(x), rnd(w), None, stride, pad, dil)
+    scale = torch.ones(Cout)
+    shift = b.clone() if bias else torch.zeros(Cout)
+    if bn:
+        s = bnp[0] / torch.sqrt(bnp[3] + bnp[4])
+        shift = shift * s + (bnp[1] - bnp[2] * s)
+        scale = s
+    y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    Ho, Wo = y.shape[2:]
+    res = None
+    if residual:
+        res = rnd(torch.randn(B, Cout, Ho, Wo, generator=g))
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    # HIP
+    dev = 'cuda'
+    xin = torch.zeros(B, H, W, Cin + in_extra, dtype=dtype, device=dev)
+    xin[..., in_extra:] = x.permute(0, 2, 3, 1).to(dev).to(dtype)
+    xv = xin[..., in_extra:]
+    pc = ops.pack_conv(w.to(dev), b.to(dev) if bias else None, tuple(t.to(dev) if torch.is_tensor(t) else t for t in bnp) if bn else None,
+                       dtype, stride, pad, dil)
+    odt = torch.float32 if out_f32 else dtype
+    obuf = torch.full((B, Ho, Wo, Cout + out_extra), 7.0, dtype=odt, device=dev)
+    ov = obuf[..., :Cout]
+    rv = res.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype) if residual else None
+    out = ops.conv2d(xv, pc, out=ov, residual=rv, relu=relu, out_f32=out_f32)
+    torch.cuda.synchronize()
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    if out_extra:
+        assert bool((obuf[..., Cout:] == 7.0).all()), 'kernel wrote outside its channel slice'
+    scale_ref = y.abs().max().item()
+    err = (got - y).abs().max().item() / scale_ref
+    return err
+
+
+SHAPES = [
+    # B, H, W, Cin, Cout, k, stride, pad, dil, residual, relu
+    (2, 24, 80, 64, 64, 3, 1, 1, 1, True, True),
+    (1, 24, 40, 128, 256, 3, 2, 1, 1, False, True),
+    (2, 12, 20, 256, 256, 3, 1, 1, 1, True, True),
+    (1, 13, 27, 64, 128, 1, 2, 0, 1, False, False),     # 1x1 stride-2 downsample, ragged M
+    (1, 24, 80, 24, 24, 3, 1, 1, 1, False, True),       # Cin < K slice (ghost primary conv)
+    (1, 12, 40, 72, 72, 3, 1, 1, 1, True, True),
+    (1, 6, 20, 288, 288, 3, 1, 1, 1, True, True),
+    (1, 6, 20, 384, 144, 3, 1, 1, 1, False, False),     # Cout not a tile multiple
+    (1, 9, 11, 64, 27, 3, 1, 1, 1, False, False),       # Cout % 4 != 0 -> scalar epilogue (DCN offset conv)
+    (1, 10, 18, 64, 64, 3, 1, 2, 2, False, True),       # dilation 2
+    (3, 6, 20, 256, 8, 1, 1, 0, 1, False, True),        # cost-volume down-sample
+]
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_conv_fp32(shape):
+    err = _case(*shape, dtype=torch.float32)
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize('shape', SHAPES)
+def test_conv_bf16(shape):
+    err = _case(*shape, dtype=torch.bfloat16)
+    assert err < 1e-2, err  # bf16 output rounding: 2^-8 relative
+
+
+def test_conv_channel_slices_and_fp32_out():
+    # reads a channel slice, writes a channel slice of a wider buffer, fp32 output from bf16 compute
+    err = _case(2, 12, 20, 96, 96, 3, 1, 1, 1, False, True, torch.bfloat16, in_extra=24, out_extra=96)
+    assert err < 1e-2
+    err = _case(1, 6, 20, 256, 144, 3, 1, 1, 1, False, False, torch.bfloat16, bn=False, out_f32=True)
+    assert err < 2e-3  # only inputs are rounded; fp32 epilogue
+    err = _case(2, 12, 20, 96, 96, 3, 1, 1, 1, True, True, torch.float32, in_extra=24, out_extra=96)
+    assert err < 2e-5
+
+
+def test_conv_big_k():
+    # the 1408-channel head conv shape at reduced spatial size: K = 12672, 3 N tiles
+    err = _case(1, 6, 20, 1408, 320, 3, 1, 1, 1, True, True, torch.float32)
+    assert err < 5e-5
+    err = _case(1, 6, 20, 1408, 320, 3, 1, 1, 1, True, True, torch.bfloat16)
+    assert err < 1e-2
+
+
+def test_stem_and_pools():
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 64, 96, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    bn = (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5, 1e-5)
+    s = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    t = bn[1] - bn[2] * s
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1e-2)):
+        rnd = (lambda v: v.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda v: v)
+        y = F.relu(F.conv2d(rnd(x), rnd(w), None, 2, 3) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1))
+        pc = ops.pack_stem_conv(w.cuda(), tuple(v.cuda() if torch.is_tensor(v) else v for v in bn), dtype)
+        out = ops.stem_conv(x.cuda(), pc, dtype)
+        got = out.float().cpu().permute(0, 3, 1, 2)
+        assert got.shape == y.shape
+        assert ((got - y).abs().max() / y.abs().max()).item() < tol
+        yr = rnd(y)
+        mp = ops.maxpool3x3s2(out).float().cpu().permute(0, 3, 1, 2)
+        assert torch.equal(mp, F.max_pool2d(out.float().cpu().permute(0, 3, 1, 2), 3, 2, 1))
+        ap = ops.avgpool2x2(out).float().cpu().permute(0, 3, 1, 2)
+        ref = rnd(F.avg_pool2d(out.float().cpu().permute(0, 3, 1, 2), 2))
+        assert ((ap - ref).abs().max() / ref.abs().max()).item() < (1e-6 if dtype == torch.float32 else 1e-2)
+
+
+def test_dwconv_and_copy():
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(4)
+    C = 96
+    x = torch.randn(2, C, 12, 20, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    bn = (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5, 1e-5)
+    s = bn[0] / torch.sqrt(bn[3] + 1e-5)
+    t = bn[1] - bn[2] * s
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        rnd = (lambda v: v.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda v: v)
+        y = F.relu(F.conv2d(rnd(x), w, None, 1, 1, 1, groups=C) * s.view(1, -1, 1, 1) + t.view(1, -1, 1, 1))
+        pd = ops.pack_dwconv(w.cuda(), tuple(v.cuda() if torch.is_tensor(v) else v for v in bn))
+        buf = torch.zeros(2, 12, 20, 3 * C, dtype=dtype, device='cuda')
+        buf[..., C:2 * C] = x.permute(0, 2, 3, 1).cuda().to(dtype)
+        ops.dwconv3x3(buf[..., C:2 * C], pd, out=buf[..., 2 * C:], relu=True)
+        got = buf[..., 2 * C:].float().cpu().permute(0, 3, 1, 2)
+        assert ((got - y).abs().max() / y.abs().max()).item() < tol
+        ops.copy_channels(buf[..., 2 * C:], buf[..., :C])
+        assert torch.equal(buf[..., :C], buf[..., 2 * C:])

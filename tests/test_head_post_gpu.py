@@ -1,0 +1,80 @@
+"""GPU: device-side get_bboxes (vd3d_head_postprocess) and vd3d_nms against the oracle on IDENTICAL inputs.
+Index selection (which anchors survive mask / threshold / z-prior filter / NMS, and in which order) must be
+bit-exact; decoded fields agree to fp32 round-off (expf/atan2f/sigmoid are within a few ulp of the host's)."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detector_oracle as orc
+from oracle.nms_ref import nms_numpy
+from visualdet3d_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(H, W, B, seed, logit_bias=-1.0, logit_std=1.0):
+    from visualdet3d_amd.networks.heads.detection_3d_head import StereoHead
+    tmp = tempfile.mkdtemp()
+    cfg = syn.stereo3d_cfg(tmp, score_thr=0.6, nms_iou_thr=0.4)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    cfg.head.layer_cfg.num_features_in = 16   # tiny towers: only the post-processing is under test
+    cfg.head.layer_cfg.reg_feature_size = 16
+    cfg.head.layer_cfg.cls_feature_size = 16
+    head = StereoHead(**cfg.head).cuda().eval()
+    N = (H // 16) * (W // 16) * 48
+    g = torch.Generator().manual_seed(seed)
+    cls = torch.randn(B, N, 3, generator=g) * logit_std + logit_bias
+    reg = torch.randn(B, N, 12, generator=g) * 0.7
+    P2, _ = syn.kitti_calib(W, batch=B)
+    P2[:, 1, 2] += torch.arange(B) * 7.0   # per-sample calibration -> per-sample ground masks
+    return cfg, head, cls, reg, P2
+
+
+@pytest.mark.parametrize('H,W,B,seed,std', [(96, 320, 3, 0, 1.0), (384, 1280, 2, 1, 0.8), (96, 320, 1, 2, 2.5)])
+def test_head_postprocess_matches_oracle(H, W, B, seed, std):
+    cfg, head, cls, reg, P2 = _setup(H, W, B, seed, logit_std=std)
+    mean_npy, std_npy = orc.load_priors(cfg.head.preprocessed_path, cfg.obj_types)
+    anchors, means, mean_std = orc.anchors_for_image(H, W, cfg.head.anchors_cfg, mean_npy, std_npy)
+    mask = orc.anchor_mask(anchors, means, P2)
+    padded = head.get_bboxes_batched(cls.cuda(), reg.cuda(), P2.cuda(), (H, W))
+    torch.cuda.synchronize()
+    scores, boxes, labels, aidx, count = [t.cpu() for t in padded]
+    total = 0
+    for b in range(B):
+        s, bx, l, idx = orc.get_bboxes(cls[b], reg[b], anchors, mean_std, mask[b], (H, W), 2, 0.6, 0.4)
+        k = int(count[b])
+        assert k == len(s), (b, k, len(s))
+        assert torch.equal(aidx[b, :k].long(), idx), 'sample %d: anchor selection / order differs' % b
+        assert torch.equal(labels[b, :k].long(), l)
+        assert torch.allclose(scores[b, :k], s, rtol=1e-5, atol=1e-6)
+        sc = bx.abs().amax(dim=0).clamp_min(1.0) if k else 1.0
+        assert k == 0 or ((boxes[b, :k] - bx).abs() / sc).max().item() < 1e-5
+        total += k
+    assert total > 10, 'test inputs produced too few detections to be meaningful'
+
+
+def test_head_candidate_overflow_is_reported():
+    cfg, head, cls, reg, P2 = _setup(96, 320, 1, 3, logit_bias=3.0)
+    head.max_candidates = 64
+    padded = head.get_bboxes_batched(cls.cuda(), reg.cuda(), P2.cuda(), (96, 320))
+    with pytest.raises(RuntimeError):
+        head.unpad(padded)
+
+
+@pytest.mark.parametrize('n,seed', [(0, 0), (1, 1), (37, 2), (64, 3), (65, 4), (1000, 5), (5000, 6)])
+def test_nms_bit_exact(n, seed):
+    from visualdet3d_amd import hip_ops as ops
+    rng = np.random.default_rng(seed)
+    ctr = rng.uniform(0, 300, (n, 2)).astype(np.float32)
+    wh = rng.uniform(5, 80, (n, 2)).astype(np.float32)
+    boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    scores = rng.uniform(0, 1, n).astype(np.float32)
+    if n > 10:
+        scores[5] = scores[3]          # exact ties -> lower index first
+        boxes[7] = boxes[2]            # duplicate boxes
+        boxes[9, 2:] = boxes[9, :2]    # zero-area box (0/0 -> NaN IoU, never suppresses)
+    want = nms_numpy(boxes, scores, 0.45)
+    got = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.45).cpu().numpy()
+    assert np.array_equal(got, want)

@@ -1,0 +1,54 @@
+"""GPU: stereo cost-volume kernels against the oracle (oracle/detector_oracle.py psm_cosine / cost_volume)."""
+import pytest
+import torch
+
+from oracle import detector_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('C,H,W,D', [(64, 6, 80, 24), (128, 5, 40, 24), (64, 3, 70, 24), (256, 2, 33, 24), (24, 4, 20, 12)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_psm_cosine(C, H, W, D, dtype):
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(C + W)
+    L = torch.randn(2, C, H, W, generator=g)
+    R = torch.randn(2, C, H, W, generator=g)
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else orc.identity
+    c = orc.Ctx({}, rnd)
+    ref = orc.psm_cosine(c, rnd(L), rnd(R), D * 4, 4)
+    buf = torch.full((2, H, W, D + 8), 3.0, dtype=dtype, device='cuda')
+    out = ops.psm_cosine(L.permute(0, 2, 3, 1).contiguous().cuda().to(dtype), R.permute(0, 2, 3, 1).contiguous().cuda().to(dtype), D,
+                         out=buf[..., 8:] if D % 8 == 0 else None)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < tol
+    # zero where x < d, exactly
+    for d in range(1, D):
+        assert bool((got[:, d, :, :d] == 0).all())
+    if D % 8 == 0:
+        assert bool((buf[..., :8] == 3.0).all())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cost_volume_module(dtype):
+    from visualdet3d_amd.networks.lib.PSM_cost_volume import CostVolume
+    from visualdet3d_amd.utils import synthetic as syn
+    m = CostVolume(downsample_scale=16, max_disp=192, input_features=256, PSM_features=8)
+    sd = syn.seeded_state_dict({'x.' + k: v for k, v in m.state_dict().items()}, seed=5)
+    sd = {k[2:]: v for k, v in sd.items()}
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    L = torch.randn(2, 256, 6, 20, generator=g)
+    R = torch.randn(2, 256, 6, 20, generator=g)
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else orc.identity
+    c = orc.Ctx({'cv.' + k: v for k, v in sd.items()}, rnd)
+    ref = orc.cost_volume(c, 'cv', rnd(L), rnd(R), 192, 16)
+    x = torch.cat([L, R], 0).permute(0, 2, 3, 1).contiguous().cuda().to(dtype)
+    with torch.no_grad():
+        out = m.forward_nhwc(x, 2)
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert got.shape == ref.shape
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < tol

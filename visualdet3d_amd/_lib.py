@@ -1,0 +1,104 @@
+"""ctypes binding of libvd3d_hip.so (the C-ABI declared in include/vd3d.h).
+
+The product path has NO fallback: if the shared library is missing or an entry point fails, this raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvd3d_hip.so')
+
+VD3D_BF16 = 0
+VD3D_F32 = 1
+ABI_VERSION = 1
+
+c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class ConvParams(C.Structure):
+    _fields_ = [
+        ('in_', c_void_p), ('weight', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
+        ('residual', c_void_p), ('out', c_void_p),
+        ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('Cin', C.c_int32),
+        ('in_pix_stride', C.c_int32), ('in_row_stride', C.c_int32),
+        ('in_batch_stride', C.c_int64), ('in_bytes', C.c_int64),
+        ('Ho', C.c_int32), ('Wo', C.c_int32), ('Cout', C.c_int32),
+        ('out_pix_stride', C.c_int32), ('res_pix_stride', C.c_int32),
+        ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32), ('dil', C.c_int32),
+        ('Kpad', C.c_int32), ('CoutPad', C.c_int32), ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32),
+    ]
+
+
+class HeadParams(C.Structure):
+    _fields_ = [
+        ('cls', c_void_p), ('reg', c_void_p), ('anchors', c_void_p), ('prior_mean_std', c_void_p), ('P2', c_void_p),
+        ('B', C.c_int32), ('N', C.c_int32), ('A', C.c_int32), ('n_cls', C.c_int32), ('n_types', C.c_int32),
+        ('img_h', C.c_int32), ('img_w', C.c_int32),
+        ('score_thr', c_float), ('nms_iou_thr', c_float),
+        ('filter_y_min', c_float), ('filter_y_max', c_float), ('filter_x_max', c_float),
+        ('use_filter', C.c_int32), ('max_cand', C.c_int32), ('max_det', C.c_int32),
+        ('workspace', c_void_p), ('out_scores', c_void_p), ('out_boxes', c_void_p), ('out_labels', c_void_p),
+        ('out_anchor', c_void_p), ('out_count', c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol include/vd3d.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    'vd3d_abi_version': (c_int, []),
+    'vd3d_last_error': (C.c_char_p, []),
+    'vd3d_conv2d_igemm': (c_int, [C.POINTER(ConvParams), c_void_p]),
+    'vd3d_pack_image_nhwc4': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'vd3d_maxpool3x3s2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'vd3d_avgpool2x2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'vd3d_dwconv3x3': (c_int, [c_void_p] * 5 + [c_int] * 8 + [c_void_p]),
+    'vd3d_copy_channels': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    'vd3d_nhwc_to_nchw_f32': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    'vd3d_nchw_f32_to_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    'vd3d_psm_cosine': (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
+    'vd3d_costvol_build': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
+    'vd3d_conv3d_3x3x3': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
+    'vd3d_head_workspace_bytes': (c_int64, [c_int, c_int]),
+    'vd3d_head_postprocess': (c_int, [C.POINTER(HeadParams), c_void_p]),
+    'vd3d_nms': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'vd3d_nms_workspace_bytes': (c_int64, [c_int]),
+}
+# declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)
+PENDING = {
+    'vd3d_boxes_overlap_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'vd3d_boxes_iou_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    'vd3d_nms_bev': (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'vd3d_nms_bev_workspace_bytes': (c_int64, [c_int]),
+    'vd3d_deform_conv_forward': (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_void_p]),
+    'vd3d_look_ground_sample': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+class Vd3dError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Fails loudly when the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Vd3dError('%s not found -- run `python -m visualdet3d_amd.build` (hipcc, gfx950). '
+                            'There is no CPU / PyTorch fallback for the HIP path.' % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        v = h.vd3d_abi_version()
+        if v != ABI_VERSION:
+            raise Vd3dError('libvd3d_hip.so ABI %d != expected %d; rebuild' % (v, ABI_VERSION))
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vd3d_last_error()
+        raise Vd3dError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))

@@ -1,0 +1,60 @@
+// common.h -- shared device/host helpers for libvd3d_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vd3d.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = 16 B (MFMA A/B fragment)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(2))) short bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+
+#define VD3D_DEV __device__ __forceinline__
+
+// bf16 <-> f32.  gfx950 has v_cvt_pk_bf16_f32 (RNE); clang emits it for __bf16 conversions.
+VD3D_DEV float bf2f(short v) { return __builtin_bit_cast(float, ((uint32_t)(uint16_t)v) << 16); }
+VD3D_DEV short f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(short, b);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<short> {  // bf16 storage
+    static constexpr int kVec = 8;      // elements per 16-byte vector
+    static VD3D_DEV float to_f(short v) { return bf2f(v); }
+    static VD3D_DEV short from_f(float f) { return f2bf(f); }
+};
+template <> struct ElemTraits<float> {
+    static constexpr int kVec = 4;
+    static VD3D_DEV float to_f(float v) { return v; }
+    static VD3D_DEV float from_f(float f) { return f; }
+};
+
+// 16-byte vector of T <-> floats
+template <typename T> struct Vec16;
+template <> struct Vec16<short> {
+    i32x4 raw;
+    VD3D_DEV float get(int i) const {
+        uint32_t w = (uint32_t)raw[i >> 1];
+        return __builtin_bit_cast(float, (i & 1) ? (w & 0xffff0000u) : (w << 16));
+    }
+    VD3D_DEV void set2(int pair, float lo, float hi) {
+        uint32_t l = (uint16_t)f2bf(lo), h = (uint16_t)f2bf(hi);
+        raw[pair] = (int)(l | (h << 16));
+    }
+};
+template <> struct Vec16<float> {
+    i32x4 raw;
+    VD3D_DEV float get(int i) const { return __builtin_bit_cast(float, raw[i]); }
+    VD3D_DEV void set(int i, float v) { raw[i] = __builtin_bit_cast(int, v); }
+};
+
+// host-side error plumbing ------------------------------------------------------------------------
+void vd3d_set_error(const char* msg);
+int vd3d_check_launch(const char* what);
+
+static inline int vd3d_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,343 @@
+// conv_igemm.hip -- fused implicit-GEMM convolution for gfx950 (MI355X), NHWC activations.
+//
+//   out[m][n] = act( (sum_k A[m][k] * Wt[n][k]) * scale[n] + shift[n] (+ residual[m][n]) )
+//   m = output pixel (b, oy, ox), n = output channel, k = (ky*kw + kx)*Cin + c
+//
+// Replaces the reference's nn.Conv2d + BatchNorm2d + ReLU (+ residual) chains (cuDNN + separate elementwise
+// kernels): backbones/resnet.py:23-52,55-91; lib/blocks.py:24-43; lib/ghost_module.py:27-32;
+// heads/detection_3d_head.py:54-79,508-530.
+//
+// CDNA4 mapping
+//   * one workgroup = WARPS_M x WARPS_N waves (64 lanes each) computing a BM(pixels) x BN(channels) tile;
+//   * K is walked in 128-byte slices (64 bf16 / 32 fp32 per row); both operand tiles are staged in LDS,
+//     double buffered, XOR-swizzled on the 16-byte slot so that ds_read_b128 fragment reads and
+//     ds_write_b128 staging writes are bank-conflict free;
+//   * global loads are raw buffer loads (SRD bounds check supplies the zero padding: an out-of-image tap
+//     gets an out-of-range offset and the hardware returns 0 -- no divergent branches in the loader);
+//   * MFMA 32x32: the WEIGHT tile is the A operand (rows = channels), the PIXEL tile is the B operand
+//     (cols = pixels), so each lane ends up holding 4 consecutive output channels of ONE pixel per
+//     accumulator quad -> the NHWC epilogue stores 8/16 contiguous bytes per lane;
+//   * bf16: v_mfma_f32_32x32x16_bf16; fp32 validation mode: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain);
+//   * the 1-D grid is remapped so each XCD (private 4 MiB L2) walks a contiguous run of pixel tiles that
+//     share one weight panel.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const char* in;
+    const char* weight;
+    const float* scale;
+    const float* shift;
+    const char* residual;
+    char* out;
+    int B, H, W, Cin;
+    int in_pix_stride, in_row_stride;
+    int64_t in_batch_stride;
+    uint32_t in_bytes, w_bytes;
+    int Ho, Wo, Cout;
+    int out_pix_stride, res_pix_stride;
+    int kh, kw, stride, pad, dil;
+    int Kpad, relu, out_f32;
+    int M, tiles_m, tiles_n, ntaps, nk;
+    int vec_epilogue;
+};
+
+constexpr uint32_t kOOB = 0x80000000u;  // byte offset guaranteed >= num_records (host enforces in_bytes < 2^31)
+
+template <typename T> struct Mma;
+template <> struct Mma<short> {
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane half h holds 4 consecutive k of an 8-wide k group; MFMA j pairs k = j (h=0) with k = 4 + j (h=1):
+    // any bijection k -> (mfma, half) is valid as long as A and B use the same one.
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[j]), __builtin_bit_cast(float, b[j]), acc, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const ConvArgs p) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VE = 16 / ES;    // elements per 16-byte vector
+    constexpr int BKE = 128 / ES;  // elements per K slice
+    constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int ROWS_PER_IT = NT / 8;
+    constexpr int A_IT = BM / ROWS_PER_IT, W_IT = BN / ROWS_PER_IT;
+    constexpr int A_STAGE = BM * 128, W_STAGE = BN * 128, STAGE = A_STAGE + W_STAGE;
+    static_assert(A_IT >= 1 && W_IT >= 1, "tile too small for the loader");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    // ---- tile id: XCD-aware bijective remap (block b runs on XCD b % 8) -----------------------------
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+
+    // ---- loader state -------------------------------------------------------------------------------
+    const int slot = tid & 7, lrow = tid >> 3;
+    int a_off[A_IT], a_iy[A_IT], a_ix[A_IT];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int m = m0 + lrow + it * ROWS_PER_IT;
+        if (m < p.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_iy[it] = oy * p.stride - p.pad;
+            a_ix[it] = ox * p.stride - p.pad;
+            a_off[it] = (int)(b * p.in_batch_stride) + a_iy[it] * p.in_row_stride + a_ix[it] * p.in_pix_stride;
+        } else {
+            a_iy[it] = -(1 << 28);
+            a_ix[it] = 0;
+            a_off[it] = 0;
+        }
+    }
+    int kc = slot * VE, tap = 0, dy = 0, dx = 0;
+    while (kc >= p.Cin) {
+        kc -= p.Cin;
+        ++tap;
+        if (++dx == p.kw) { dx = 0; ++dy; }
+    }
+    uint32_t w_off = (uint32_t)(((n0 + lrow) * p.Kpad + slot * VE) * ES);
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.weight, 0, p.w_bytes, 0x00020000);
+
+    i32x4 ra[A_IT], rw[W_IT];
+    auto load_tile = [&]() {
+        const bool kvalid = tap < p.ntaps;
+        const int ddy = dy * p.dil, ddx = dx * p.dil;
+        const int tap_off = ddy * p.in_row_stride + ddx * p.in_pix_stride + kc;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const bool v = kvalid && (unsigned)(a_iy[it] + ddy) < (unsigned)p.H && (unsigned)(a_ix[it] + ddx) < (unsigned)p.W;
+            const uint32_t off = v ? (uint32_t)(a_off[it] + tap_off) * ES : kOOB;
+            ra[it] = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it)
+            rw[it] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_off + (uint32_t)(it * ROWS_PER_IT * p.Kpad * ES), 0, 0);
+        // advance to the next K slice
+        w_off += BKE * ES;
+        kc += BKE;
+        while (kc >= p.Cin) {
+            kc -= p.Cin;
+            ++tap;
+            if (++dx == p.kw) { dx = 0; ++dy; }
+        }
+    };
+    auto store_tile = [&](int st) {
+        char* As = smem + st * STAGE;
+        char* Ws = As + A_STAGE;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int row = lrow + it * ROWS_PER_IT;
+            *(i32x4*)(As + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < W_IT; ++it) {
+            const int row = lrow + it * ROWS_PER_IT;
+            *(i32x4*)(Ws + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = rw[it];
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, half = lane >> 5;
+    auto compute = [&](int st) {
+        const char* As = smem + st * STAGE;
+        const char* Ws = As + A_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int sk = 2 * ks + half;
+            i32x4 fa[TN], fb[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int row = wn * WTN + i * 32 + lr;
+                fa[i] = *(const i32x4*)(Ws + row * 128 + ((sk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = wm * WTM + j * 32 + lr;
+                fb[j] = *(const i32x4*)(As + row * 128 + ((sk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    // ---- main loop: global->reg prefetch of slice k+1 overlaps the MFMAs of slice k ------------------
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < p.nk; ++kt) {
+        const bool more = kt + 1 < p.nk;
+        if (more) load_tile();
+        compute(kt & 1);
+        if (more) store_tile((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store ---------------------------------------
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WTM + j * 32 + lr;
+        if (m >= p.M) continue;
+        const int64_t obase = (int64_t)m * p.out_pix_stride;
+        const int64_t rbase = (int64_t)m * p.res_pix_stride;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + wn * WTN + i * 32 + 8 * g + 4 * half;
+                if (nb >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (p.vec_epilogue) {
+                    if (p.scale) {
+                        const f32x4 s = *(const f32x4*)(p.scale + nb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= s[e];
+                    }
+                    if (p.shift) {
+                        const f32x4 s = *(const f32x4*)(p.shift + nb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += s[e];
+                    }
+                    if (p.residual) {
+                        if constexpr (sizeof(T) == 2) {
+                            const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
+                            v[0] += __builtin_bit_cast(float, (uint32_t)rr[0] << 16);
+                            v[1] += __builtin_bit_cast(float, (uint32_t)rr[0] & 0xffff0000u);
+                            v[2] += __builtin_bit_cast(float, (uint32_t)rr[1] << 16);
+                            v[3] += __builtin_bit_cast(float, (uint32_t)rr[1] & 0xffff0000u);
+                        } else {
+                            const f32x4 rr = *(const f32x4*)(p.residual + (rbase + nb) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (sizeof(T) == 4 || p.out_f32) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(p.out + (obase + nb) * 4) = o;
+                    } else {
+                        i32x2 o;
+                        o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+                        o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                        *(i32x2*)(p.out + (obase + nb) * 2) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = nb + e;
+                        if (n >= p.Cout) break;
+                        float x = v[e];
+                        if (p.scale) x *= p.scale[n];
+                        if (p.shift) x += p.shift[n];
+                        if (p.residual) x += ElemTraits<T>::to_f(((const T*)p.residual)[rbase + n]);
+                        if (p.relu) x = fmaxf(x, 0.f);
+                        if (sizeof(T) == 4 || p.out_f32) ((float*)p.out)[obase + n] = x;
+                        else ((short*)p.out)[obase + n] = f2bf(x);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
+int launch(ConvArgs& a, hipStream_t stream) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int LDS = 2 * (BM + BN) * 128;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    static bool attr_done = false;
+    auto kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return vd3d_check_launch("hipFuncSetAttribute(conv_igemm)");
+        attr_done = true;
+    }
+    const int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffff) return VD3D_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS, stream, a);
+    return vd3d_check_launch("conv_igemm");
+}
+
+template <typename T>
+int dispatch(ConvArgs& a, hipStream_t stream) {
+    if (a.Cout <= 32) return launch<T, 256, 32, 4, 1>(a, stream);
+    if (a.Cout <= 64) return launch<T, 256, 64, 4, 1>(a, stream);
+    return launch<T, 128, 128, 2, 2>(a, stream);
+}
+
+}  // namespace
+
+extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
+    if (!p || !p->in || !p->weight || !p->out) { vd3d_set_error("conv2d_igemm: null pointer"); return VD3D_EINVAL; }
+    const int es = p->dtype == VD3D_BF16 ? 2 : (p->dtype == VD3D_F32 ? 4 : 0);
+    if (!es) { vd3d_set_error("conv2d_igemm: bad dtype"); return VD3D_EINVAL; }
+    const int ve = 16 / es, bke = 128 / es;
+    if (p->Cin % ve || p->in_pix_stride % ve || p->in_row_stride % ve || p->in_batch_stride % ve ||
+        ((uintptr_t)p->in & 15) || ((uintptr_t)p->weight & 15)) {
+        vd3d_set_error("conv2d_igemm: input channels / strides / pointers must be 16-byte aligned");
+        return VD3D_EINVAL;
+    }
+    if (p->Kpad % bke || p->Kpad < p->kh * p->kw * p->Cin || p->CoutPad % 128 || p->CoutPad < p->Cout) {
+        vd3d_set_error("conv2d_igemm: packed weight padding does not match");
+        return VD3D_EINVAL;
+    }
+    if (p->in_bytes <= 0 || p->in_bytes > 0x7ffffff0ll || (int64_t)p->CoutPad * p->Kpad * es > 0x7ffffff0ll) {
+        vd3d_set_error("conv2d_igemm: tensor exceeds 2 GiB (32-bit buffer offsets); split the batch");
+        return VD3D_ERANGE;
+    }
+    ConvArgs a;
+    a.in = (const char*)p->in; a.weight = (const char*)p->weight; a.scale = p->scale; a.shift = p->shift;
+    a.residual = (const char*)p->residual; a.out = (char*)p->out;
+    a.B = p->B; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
+    a.in_pix_stride = p->in_pix_stride; a.in_row_stride = p->in_row_stride; a.in_batch_stride = p->in_batch_stride;
+    a.in_bytes = (uint32_t)p->in_bytes; a.w_bytes = (uint32_t)((int64_t)p->CoutPad * p->Kpad * es);
+    a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout;
+    a.out_pix_stride = p->out_pix_stride; a.res_pix_stride = p->res_pix_stride;
+    a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
+    a.Kpad = p->Kpad; a.relu = p->relu; a.out_f32 = p->out_f32;
+    const int64_t M = (int64_t)p->B * p->Ho * p->Wo;
+    if (M <= 0 || M > 0x7fffffff) return VD3D_ERANGE;
+    a.M = (int)M;
+    a.ntaps = p->kh * p->kw;
+    a.nk = (p->kh * p->kw * p->Cin + bke - 1) / bke;
+    const int oes = (es == 4 || p->out_f32) ? 4 : 2;
+    // vector epilogue needs 4-channel groups fully inside Cout and 4-element aligned rows
+    a.vec_epilogue = (p->Cout % 4 == 0) && (p->out_pix_stride % 4 == 0) && (((uintptr_t)p->out % (4 * oes)) == 0) &&
+                     (!p->residual || (p->res_pix_stride % 4 == 0 && ((uintptr_t)p->residual % (4 * es)) == 0)) &&
+                     (!p->scale || ((uintptr_t)p->scale % 16) == 0) && (!p->shift || ((uintptr_t)p->shift % 16) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : dispatch<float>(a, s);
+}

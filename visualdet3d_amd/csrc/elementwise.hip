@@ -1,0 +1,266 @@
+// elementwise.hip -- HBM-bound NHWC helpers: image packing, pools, depth-wise 3x3, slice copies,
+// boundary layout converters.  All loads/stores are 16-byte vectors along the channel axis (coalesced:
+// consecutive lanes -> consecutive 16 B of one pixel, then the next pixel).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------------
+// NCHW fp32 image -> zero-bordered NHWC4 (stem input).  One thread per output pixel (8 or 16 bytes).
+template <typename T>
+__global__ void pack_image_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int H, int W,
+                                  int pad_y, int pad_l, int Hp, int Wp) {
+    const int64_t total = (int64_t)B * Hp * Wp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const int yp = (int)((i / Wp) % Hp);
+        const int b = (int)(i / ((int64_t)Wp * Hp));
+        const int x = xp - pad_l, y = yp - pad_y;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+            const int64_t base = ((int64_t)b * 3 * H + y) * W + x;
+            v0 = in[base];
+            v1 = in[base + (int64_t)H * W];
+            v2 = in[base + 2 * (int64_t)H * W];
+        }
+        if constexpr (sizeof(T) == 2) {
+            i32x2 o;
+            o[0] = (int)((uint32_t)(uint16_t)f2bf(v0) | ((uint32_t)(uint16_t)f2bf(v1) << 16));
+            o[1] = (int)((uint32_t)(uint16_t)f2bf(v2));
+            *(i32x2*)(out + i * 4) = o;
+        } else {
+            f32x4 o = {v0, v1, v2, 0.f};
+            *(f32x4*)(out + i * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C,
+                                    int Ho, int Wo, int ips, int ops) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int cv = C / VE;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t pix = i / cv;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        float m[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                Vec16<T> v;
+                v.raw = *(const i32x4*)(in + (((int64_t)b * H + iy) * W + ix) * ips + c);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) m[e] = fmaxf(m[e], v.get(e));
+            }
+        }
+        Vec16<T> o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, m[2 * e], m[2 * e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, m[e]);
+        }
+        *(i32x4*)(out + pix * ops + c) = o.raw;
+    }
+}
+
+template <typename T>
+__global__ void avgpool2x2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C,
+                                  int Ho, int Wo, int ips, int ops) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int cv = C / VE;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t pix = i / cv;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        float s[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[e] = 0.f;
+        // torch avg_pool2d accumulates the window row-major in fp32: ((a00 + a01) + a10) + a11, then * 0.25
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                Vec16<T> v;
+                v.raw = *(const i32x4*)(in + (((int64_t)b * H + oy * 2 + dy) * W + ox * 2 + dx) * ips + c);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] += v.get(e);
+            }
+        Vec16<T> o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, s[2 * e] * 0.25f, s[2 * e + 1] * 0.25f);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, s[e] * 0.25f);
+        }
+        *(i32x4*)(out + pix * ops + c) = o.raw;
+    }
+}
+
+// depth-wise 3x3, pad 1, stride 1; weight [9][C] fp32
+template <typename T>
+__global__ void dwconv3x3_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
+                                 const float* __restrict__ shift, T* __restrict__ out, int B, int H, int W, int C,
+                                 int ips, int ops, int relu) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int cv = C / VE;
+    const int64_t total = (int64_t)B * H * W * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t pix = i / cv;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        float s[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = y - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = x - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                Vec16<T> v;
+                v.raw = *(const i32x4*)(in + (((int64_t)b * H + iy) * W + ix) * ips + c);
+                const float* wt = w + (dy * 3 + dx) * C + c;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] = fmaf(v.get(e), wt[e], s[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float v = s[e] * scale[c + e] + shift[c + e];
+            s[e] = relu ? fmaxf(v, 0.f) : v;
+        }
+        Vec16<T> o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, s[2 * e], s[2 * e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, s[e]);
+        }
+        *(i32x4*)(out + pix * ops + c) = o.raw;
+    }
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n_pix, int C, int ips, int ops) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int cv = C / VE;
+    const int64_t total = n_pix * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t pix = i / cv;
+        *(i32x4*)(out + pix * ops + c) = *(const i32x4*)(in + pix * ips + c);
+    }
+}
+
+// boundary converters (scalar per element; only used at the module boundary / in tests)
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int ips) {
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const int c = (int)((i / ((int64_t)W * H)) % C), b = (int)(i / ((int64_t)W * H * C));
+        out[i] = ElemTraits<T>::to_f(in[(((int64_t)b * H + y) * W + x) * ips + c]);
+    }
+}
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int ops) {
+    const int64_t total = (int64_t)B * C * H * W;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t pix = i / C;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        out[pix * ops + c] = ElemTraits<T>::from_f(in[(((int64_t)b * C + c) * H + y) * W + x]);
+    }
+}
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + kThreads - 1) / kThreads;
+    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+inline bool vec_ok(int dtype, int C, int s1, int s2, const void* a, const void* b) {
+    const int ve = dtype == VD3D_BF16 ? 8 : 4;
+    return (C % ve == 0) && (s1 % ve == 0) && (s2 % ve == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)b & 15) == 0);
+}
+#define VD3D_DISPATCH(dtype, ...)                         \
+    if ((dtype) == VD3D_BF16) { using T = short; __VA_ARGS__; } \
+    else if ((dtype) == VD3D_F32) { using T = float; __VA_ARGS__; } \
+    else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }
+
+}  // namespace
+
+extern "C" int vd3d_pack_image_nhwc4(const float* in, void* out, int B, int H, int W, int pad_y, int pad_l, int pad_r,
+                                     int dtype, void* stream) {
+    if (!in || !out || B <= 0 || H <= 0 || W <= 0) { vd3d_set_error("pack_image: bad args"); return VD3D_EINVAL; }
+    const int Hp = H + 2 * pad_y, Wp = W + pad_l + pad_r;
+    const int64_t total = (int64_t)B * Hp * Wp;
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(pack_image_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             in, (T*)out, B, H, W, pad_y, pad_l, Hp, Wp));
+    return vd3d_check_launch("pack_image");
+}
+
+extern "C" int vd3d_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int ips, int ops, int dtype, void* stream) {
+    if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("maxpool: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)in, (T*)out, B, H, W, C, Ho, Wo, ips, ops));
+    return vd3d_check_launch("maxpool3x3s2");
+}
+
+extern "C" int vd3d_avgpool2x2(const void* in, void* out, int B, int H, int W, int C, int ips, int ops, int dtype, void* stream) {
+    if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("avgpool: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(avgpool2x2_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)in, (T*)out, B, H, W, C, Ho, Wo, ips, ops));
+    return vd3d_check_launch("avgpool2x2");
+}
+
+extern "C" int vd3d_dwconv3x3(const void* in, const float* weight, const float* scale, const float* shift, void* out,
+                              int B, int H, int W, int C, int ips, int ops, int relu, int dtype, void* stream) {
+    if (!vec_ok(dtype, C, ips, ops, in, out) || !weight || !scale || !shift) { vd3d_set_error("dwconv3x3: bad args"); return VD3D_EINVAL; }
+    const int64_t total = (int64_t)B * H * W * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(dwconv3x3_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)in, weight, scale, shift, (T*)out, B, H, W, C, ips, ops, relu));
+    return vd3d_check_launch("dwconv3x3");
+}
+
+extern "C" int vd3d_copy_channels(const void* in, void* out, int64_t n_pix, int C, int ips, int ops, int dtype, void* stream) {
+    if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("copy_channels: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
+    const int64_t total = n_pix * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)in, (T*)out, n_pix, C, ips, ops));
+    return vd3d_check_launch("copy_channels");
+}
+
+extern "C" int vd3d_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int ips, int dtype, void* stream) {
+    const int64_t total = (int64_t)B * H * W * C;
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)in, out, B, H, W, C, ips));
+    return vd3d_check_launch("nhwc_to_nchw");
+}
+extern "C" int vd3d_nchw_f32_to_nhwc(const float* in, void* out, int B, int H, int W, int C, int ops, int dtype, void* stream) {
+    const int64_t total = (int64_t)B * H * W * C;
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             in, (T*)out, B, H, W, C, ops));
+    return vd3d_check_launch("nchw_to_nhwc");
+}

@@ -1,0 +1,416 @@
+// postprocess.hip -- anchor-head post-processing and NMS for gfx950.
+//
+// Replaces, per sample and without any host round trip:
+//   heads/detection_3d_head.py:341-400 get_bboxes (sigmoid, ground-filter mask, score threshold, argmax),
+//   :218-263 _decode, networks/utils/utils.py:186-196 ClipBoxes, heads/anchors.py:99-111 (ground filter),
+//   and torchvision.ops.nms (third party; semantics restated in oracle/nms_ref.py).
+// The reference does this with ~8 boolean-index ops (each a device->host sync) at batch 1 only.
+//
+// Numerics: everything here is plain fp32 with FMA contraction OFF and the same operation order as the
+// reference's torch ops, so that the discrete decisions (mask, threshold, NMS suppression) agree.
+// NMS keep order = decreasing score, ties -> lower index (stable), exactly the oracle's.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace {
+
+constexpr int kSelThreads = 256;
+constexpr int kNmsThreads = 1024;
+constexpr int kMaxSort = 8192;  // LDS bitonic sort capacity (64 KiB of keys)
+
+VD3D_DEV uint32_t orderable_desc(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;  // ascending-orderable
+    return ~u;                                   // ascending key == descending score
+}
+VD3D_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct Workspace {  // per-sample slices of one flat buffer
+    int32_t* count;       // [B]
+    int32_t* cand_idx;    // [B][max_cand]
+    float* cand_score;    // [B][max_cand]
+    float* boxes;         // [B][max_cand][11]  (sorted, decoded, compacted)
+    float* scores;        // [B][max_cand]
+    int32_t* labels;      // [B][max_cand]
+    int32_t* anchor;      // [B][max_cand]
+};
+__host__ __device__ inline int64_t ws_bytes(int B, int max_cand) {
+    return 256 + (int64_t)B * 4 + (int64_t)B * max_cand * (4 + 4 + 44 + 4 + 4 + 4) + 256;
+}
+__host__ __device__ inline Workspace carve(void* base, int B, int max_cand) {
+    Workspace w;
+    char* p = (char*)base;
+    w.count = (int32_t*)p; p += ((int64_t)B * 4 + 255) / 256 * 256;
+    const int64_t n = (int64_t)B * max_cand;
+    w.cand_idx = (int32_t*)p; p += n * 4;
+    w.cand_score = (float*)p; p += n * 4;
+    w.boxes = (float*)p; p += n * 44;
+    w.scores = (float*)p; p += n * 4;
+    w.labels = (int32_t*)p; p += n * 4;
+    w.anchor = (int32_t*)p;
+    return w;
+}
+
+struct HeadArgs {
+    const float* cls; const float* reg; const float* anchors; const float* prior; const float* P2;
+    int B, N, A, n_cls, n_types, img_h, img_w;
+    float score_thr, nms_thr, y_min, y_max, x_max;
+    int use_filter, max_cand, max_det;
+    Workspace ws;
+    float* out_scores; float* out_boxes; int32_t* out_labels; int32_t* out_anchor; int32_t* out_count;
+};
+
+// ---- stage 1: mask + sigmoid + threshold -> candidate list (unordered, atomics) ----------------------
+__global__ void __launch_bounds__(kSelThreads) head_select_kernel(const HeadArgs p) {
+    const int64_t total = (int64_t)p.B * p.N;
+    const int nc1 = p.n_cls + 1;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / p.N), n = (int)(i - (int64_t)b * p.N);
+        const int a = n % p.A;
+        if (p.use_filter) {
+            // heads/anchors.py:99-111 -- both back-projections divide by fy
+            const float* P = p.P2 + b * 12;
+            const float fy = P[5], cy = P[6], cx = P[2];
+            const f32x4 an = *(const f32x4*)(p.anchors + (int64_t)n * 4);
+            const float xc = (an[0] + an[2]) / 2.0f, yc = (an[1] + an[3]) / 2.0f;
+            bool useful = false;
+            for (int t = 0; t < p.n_types; ++t) {
+                const float z = p.prior[((a * p.n_types + t) * 6 + 0) * 2 + 0];
+                const float x3d = (xc * z - cx * z) / fy;
+                const float y3d = (yc * z - cy * z) / fy;
+                useful |= (y3d > p.y_min) && (y3d < p.y_max) && (fabsf(x3d) < p.x_max);
+            }
+            if (!useful) continue;
+        }
+        const float* c = p.cls + i * nc1;
+        float best = sigmoidf_(c[0]);
+        for (int k = 1; k < p.n_cls; ++k) best = fmaxf(best, sigmoidf_(c[k]));
+        if (best > p.score_thr) {
+            const int pos = atomicAdd(p.ws.count + b, 1);
+            if (pos < p.max_cand) {
+                p.ws.cand_idx[(int64_t)b * p.max_cand + pos] = n;
+                p.ws.cand_score[(int64_t)b * p.max_cand + pos] = best;
+            }
+        }
+    }
+}
+
+// ---- shared device pieces ----------------------------------------------------------------------------
+// in-LDS bitonic sort of n (padded to pow2 P) 64-bit keys, ascending
+__device__ void bitonic_sort(uint64_t* keys, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+VD3D_DEV bool iou_gt(const f32x4& a, float area_a, const f32x4& b, float area_b, float thr) {
+    const float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+    const float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+    const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+    const float inter = w * h;
+    const float iou = inter / ((area_a + area_b) - inter);
+    return iou > thr;
+}
+
+// Greedy NMS over K boxes already in decreasing-score order.  box(i) -> f32x4.  alive[] in LDS (bytes).
+// 64-box chunks: wave 0 resolves a chunk wave-synchronously, then every thread tests later boxes against the
+// chunk's survivors.
+template <typename BoxFn>
+__device__ void nms_sorted(BoxFn box, int K, float thr, unsigned char* alive, f32x4* chunk_box, float* chunk_area,
+                           unsigned char* chunk_alive) {
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) alive[i] = 1;
+    __syncthreads();
+    for (int c0 = 0; c0 < K; c0 += 64) {
+        if (threadIdx.x < 64) {
+            const int j = c0 + lane;
+            const bool in = j < K;
+            f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+            if (in) bj = box(j);
+            const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+            bool a = in && alive[j];
+            const int cn = min(64, K - c0);
+            for (int i = 0; i < cn; ++i) {
+                const bool ai = __shfl((int)a, i) != 0;
+                if (!ai) continue;  // wave-uniform
+                f32x4 bi;
+                bi[0] = __shfl(bj[0], i); bi[1] = __shfl(bj[1], i); bi[2] = __shfl(bj[2], i); bi[3] = __shfl(bj[3], i);
+                const float areai = __shfl(aj, i);
+                if (lane > i && a && iou_gt(bi, areai, bj, aj, thr)) a = false;
+            }
+            if (in) alive[j] = a;
+            chunk_box[lane] = bj;
+            chunk_area[lane] = aj;
+            chunk_alive[lane] = a;
+        }
+        __syncthreads();
+        const int cn = min(64, K - c0);
+        for (int j = c0 + 64 + threadIdx.x; j < K; j += blockDim.x) {
+            if (!alive[j]) continue;
+            const f32x4 bj = box(j);
+            const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+            for (int i = 0; i < cn; ++i) {
+                if (chunk_alive[i] && iou_gt(chunk_box[i], chunk_area[i], bj, aj, thr)) { alive[j] = 0; break; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// block-wide order-preserving compaction positions: pos[i] = number of set flags before i; *total = count.
+// Each thread owns a contiguous span; span sums are scanned with wave shuffles + one cross-wave step.
+__device__ void compact_positions(const unsigned char* flag, int K, int* pos, int* scratch, int* total) {
+    const int per = (K + blockDim.x - 1) / blockDim.x;
+    const int beg = threadIdx.x * per, end = min(K, beg + per);
+    int s = 0;
+    for (int i = beg; i < end; ++i) s += flag[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) scratch[wv] = inc;
+    __syncthreads();
+    if (wv == 0) {
+        const int ws = lane < nw ? scratch[lane] : 0;
+        int inc2 = ws;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(inc2, o);
+            if (lane >= o) inc2 += t;
+        }
+        if (lane < nw) scratch[lane] = inc2 - ws;
+        if (lane == nw - 1) *total = inc2;
+    }
+    __syncthreads();
+    int run = scratch[wv] + inc - s;
+    for (int i = beg; i < end; ++i) { pos[i] = run; run += flag[i]; }
+    __syncthreads();
+}
+
+// ---- stage 2: per-sample decode + clip + z-mask + score sort + NMS -----------------------------------
+// Order of operations mirrors get_bboxes: candidates in ANCHOR order -> decode -> z-prior mask -> nms (which
+// sorts by score, stable) -> outputs in decreasing-score order.
+// QUIRK reproduced from the reference (detection_3d_head.py:375-379,392-394): bboxes / max_score are filtered by
+// the z-prior mask but `label` is not, and is then indexed with keep indices of the FILTERED list.  The label
+// reported for the detection at filtered position q is therefore the label of the q-th UNFILTERED candidate.
+__global__ void __launch_bounds__(kNmsThreads) head_nms_kernel(const HeadArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    const int cnt = p.ws.count[b];
+    if (cnt > p.max_cand) {
+        if (threadIdx.x == 0) p.out_count[b] = -1;
+        return;
+    }
+    const int K = cnt;
+    int P = 1;
+    while (P < K) P <<= 1;
+    // LDS carve
+    uint64_t* keys = (uint64_t*)smem;                                  // [max_cand]
+    int* pos = (int*)(keys + p.max_cand);                              // [max_cand]
+    int* cidx = pos + p.max_cand;                                      // [max_cand] filtered position q -> anchor-order p
+    int* scratch = cidx + p.max_cand;                                  // [kNmsThreads]
+    f32x4* chunk_box = (f32x4*)(scratch + kNmsThreads);                // [64]
+    float* chunk_area = (float*)(chunk_box + 64);                      // [64]
+    unsigned char* flag = (unsigned char*)(chunk_area + 64);           // [max_cand]
+    unsigned char* alive = flag + p.max_cand;                          // [max_cand]
+    unsigned char* chunk_alive = alive + p.max_cand;                   // [64]
+    int* total = (int*)(chunk_alive + 64);
+
+    const int64_t cb = (int64_t)b * p.max_cand;
+    // 1. anchor order (boolean-mask indexing in the reference preserves anchor order)
+    for (int i = threadIdx.x; i < P; i += blockDim.x) keys[i] = i < K ? (uint64_t)(uint32_t)p.ws.cand_idx[cb + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort(keys, P);
+
+    // 2. decode (heads/detection_3d_head.py:218-263) + clip (utils.py:186-196); flag = prior z-mean > 0
+    const int nc1 = p.n_cls + 1;
+    float* tbox = p.ws.boxes + cb * 11;
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        const int n = (int)(uint32_t)keys[i];
+        const int a = n % p.A;
+        const float* c = p.cls + ((int64_t)b * p.N + n) * nc1;
+        float best = sigmoidf_(c[0]);
+        int label = 0;
+        for (int k = 1; k < p.n_cls; ++k) {
+            const float s = sigmoidf_(c[k]);
+            if (s > best) { best = s; label = k; }
+        }
+        const float alpha_score = sigmoidf_(c[p.n_cls]);
+        const float* ms = p.prior + ((a * p.n_types + label) * 6) * 2;  // [6][2] = (mean, std)
+        const f32x4 an = *(const f32x4*)(p.anchors + (int64_t)n * 4);
+        const float* d = p.reg + ((int64_t)b * p.N + n) * 12;
+        const float w = an[2] - an[0], h = an[3] - an[1];
+        const float cx = an[0] + 0.5f * w, cy = an[1] + 0.5f * h;
+        const float pcx = cx + (d[0] * 0.1f) * w, pcy = cy + (d[1] * 0.1f) * h;
+        const float pw = expf(d[2] * 0.2f) * w, ph = expf(d[3] * 0.2f) * h;
+        float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+        const float c3x = cx + (d[4] * 0.1f) * w, c3y = cy + (d[5] * 0.1f) * h;
+        const float z = d[6] * ms[1] + ms[0];
+        const float s2 = d[7] * ms[3] + ms[2];
+        const float c2 = d[8] * ms[5] + ms[4];
+        const float w3 = d[9] * ms[7] + ms[6];
+        const float h3 = d[10] * ms[9] + ms[8];
+        const float l3 = d[11] * ms[11] + ms[10];
+        float alpha = atan2f(s2, c2) / 2.0f;
+        if (alpha_score < 0.5f) alpha += 3.14159265358979323846f;
+        x1 = fmaxf(x1, 0.0f); y1 = fmaxf(y1, 0.0f);
+        x2 = fminf(x2, (float)p.img_w); y2 = fminf(y2, (float)p.img_h);
+        float* o = tbox + (int64_t)i * 11;
+        o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = c3x; o[5] = c3y; o[6] = z; o[7] = w3; o[8] = h3; o[9] = l3; o[10] = alpha;
+        p.ws.scores[cb + i] = best;
+        p.ws.labels[cb + i] = label;
+        p.ws.anchor[cb + i] = n;
+        flag[i] = ms[0] > 0.0f;
+    }
+    __syncthreads();
+    // 3. z-prior filter (order preserving)
+    compact_positions(flag, K, pos, scratch, total);
+    const int Kc = *total;
+    int P2 = 1;
+    while (P2 < Kc) P2 <<= 1;
+    __syncthreads();
+    for (int i = threadIdx.x; i < P2; i += blockDim.x) keys[i] = ~0ull;
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += blockDim.x) {
+        if (!flag[i]) continue;
+        const int q = pos[i];
+        cidx[q] = i;
+        keys[q] = ((uint64_t)orderable_desc(p.ws.scores[cb + i]) << 32) | (uint32_t)q;  // score desc, then list order
+    }
+    __syncthreads();
+    // 4. NMS order
+    bitonic_sort(keys, P2);
+    auto box = [&](int j) -> f32x4 {
+        const float* o = tbox + (int64_t)cidx[(uint32_t)keys[j]] * 11;
+        f32x4 r = {o[0], o[1], o[2], o[3]};
+        return r;
+    };
+    nms_sorted(box, Kc, p.nms_thr, alive, chunk_box, chunk_area, chunk_alive);
+    compact_positions(alive, Kc, pos, scratch, total);
+    const int kept = *total;
+    const int nout = min(kept, p.max_det);
+    for (int j = threadIdx.x; j < Kc; j += blockDim.x) {
+        if (!alive[j] || pos[j] >= nout) continue;
+        const int q = (int)(uint32_t)keys[j];
+        const int i = cidx[q], o_ = pos[j];
+        const int64_t ob = (int64_t)b * p.max_det + o_;
+        for (int e = 0; e < 11; ++e) p.out_boxes[ob * 11 + e] = tbox[(int64_t)i * 11 + e];
+        p.out_scores[ob] = p.ws.scores[cb + i];
+        p.out_labels[ob] = p.ws.labels[cb + q];  // the reference's unfiltered-label quirk (see above)
+        p.out_anchor[ob] = p.ws.anchor[cb + i];
+    }
+    if (threadIdx.x == 0) p.out_count[b] = kept > p.max_det ? -2 : kept;
+}
+
+// ---- standalone torchvision.ops.nms replacement --------------------------------------------------------
+__global__ void __launch_bounds__(kNmsThreads) nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          int n, float thr, int32_t* keep, int32_t* count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int P = 1;
+    while (P < n) P <<= 1;
+    uint64_t* keys = (uint64_t*)smem;                      // [P]
+    unsigned char* alive = (unsigned char*)(keys + P);     // [n]
+    int* pos = (int*)(alive + ((n + 15) / 16) * 16);       // [n]
+    int* scratch = pos + n;                                // [kNmsThreads]
+    f32x4* chunk_box = (f32x4*)(scratch + kNmsThreads);
+    float* chunk_area = (float*)(chunk_box + 64);
+    unsigned char* chunk_alive = (unsigned char*)(chunk_area + 64);
+    int* total = (int*)(chunk_alive + 64);
+    for (int i = threadIdx.x; i < P; i += blockDim.x)
+        keys[i] = i < n ? (((uint64_t)orderable_desc(scores[i]) << 32) | (uint32_t)i) : ~0ull;
+    __syncthreads();
+    bitonic_sort(keys, P);
+    auto box = [&](int j) -> f32x4 { return *(const f32x4*)(boxes + (int64_t)(uint32_t)keys[j] * 4); };
+    nms_sorted(box, n, thr, alive, chunk_box, chunk_area, chunk_alive);
+    compact_positions(alive, n, pos, scratch, total);
+    for (int j = threadIdx.x; j < n; j += blockDim.x)
+        if (alive[j]) keep[pos[j]] = (int32_t)(uint32_t)keys[j];
+    if (threadIdx.x == 0) *count = *total;
+}
+
+inline int64_t head_nms_lds(int max_cand) {
+    return (int64_t)max_cand * 8 + (int64_t)max_cand * 8 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + max_cand * 2 + 64 + 16;
+}
+inline int64_t nms_lds(int n) {
+    int P = 1;
+    while (P < n) P <<= 1;
+    return (int64_t)P * 8 + ((n + 15) / 16) * 16 + (int64_t)n * 4 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + 64 + 16;
+}
+
+}  // namespace
+
+extern "C" int64_t vd3d_head_workspace_bytes(int B, int max_cand) { return ws_bytes(B, max_cand); }
+
+extern "C" int vd3d_head_postprocess(const vd3d_head_params* q, void* stream) {
+    if (!q || !q->cls || !q->reg || !q->anchors || !q->prior_mean_std || !q->P2 || !q->workspace || !q->out_scores ||
+        !q->out_boxes || !q->out_labels || !q->out_anchor || !q->out_count) {
+        vd3d_set_error("head_postprocess: null pointer");
+        return VD3D_EINVAL;
+    }
+    if (q->B <= 0 || q->N <= 0 || q->A <= 0 || q->N % q->A || q->n_cls < 1 || q->n_types < q->n_cls ||
+        q->max_cand < 1 || q->max_cand > kMaxSort || (q->max_cand & (q->max_cand - 1)) || q->max_det < 1 ||
+        ((uintptr_t)q->anchors & 15)) {
+        vd3d_set_error("head_postprocess: bad sizes (max_cand must be a power of two <= 8192)");
+        return VD3D_EINVAL;
+    }
+    HeadArgs a;
+    a.cls = q->cls; a.reg = q->reg; a.anchors = q->anchors; a.prior = q->prior_mean_std; a.P2 = q->P2;
+    a.B = q->B; a.N = q->N; a.A = q->A; a.n_cls = q->n_cls; a.n_types = q->n_types; a.img_h = q->img_h; a.img_w = q->img_w;
+    a.score_thr = q->score_thr; a.nms_thr = q->nms_iou_thr; a.y_min = q->filter_y_min; a.y_max = q->filter_y_max; a.x_max = q->filter_x_max;
+    a.use_filter = q->use_filter; a.max_cand = q->max_cand; a.max_det = q->max_det;
+    a.ws = carve(q->workspace, q->B, q->max_cand);
+    a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_labels = q->out_labels; a.out_anchor = q->out_anchor; a.out_count = q->out_count;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(a.ws.count, 0, (size_t)q->B * 4, s) != hipSuccess) return vd3d_check_launch("head_postprocess memset");
+    const int64_t total = (int64_t)q->B * q->N;
+    int64_t g = (total + kSelThreads - 1) / kSelThreads;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(head_select_kernel, dim3((unsigned)g), dim3(kSelThreads), 0, s, a);
+    int rc = vd3d_check_launch("head_select");
+    if (rc) return rc;
+    const int lds = (int)head_nms_lds(q->max_cand);
+    static int attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute((const void*)head_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return vd3d_check_launch("hipFuncSetAttribute(head_nms)");
+        attr = lds;
+    }
+    hipLaunchKernelGGL(head_nms_kernel, dim3(q->B), dim3(kNmsThreads), lds, s, a);
+    return vd3d_check_launch("head_nms");
+}
+
+extern "C" int64_t vd3d_nms_workspace_bytes(int n) { (void)n; return 256; }
+
+extern "C" int vd3d_nms(const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep, int32_t* count,
+                        void* workspace, void* stream) {
+    (void)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    if (!keep || !count || n < 0) { vd3d_set_error("nms: bad args"); return VD3D_EINVAL; }
+    if (n == 0) return hipMemsetAsync(count, 0, 4, s) == hipSuccess ? VD3D_OK : vd3d_check_launch("nms memset");
+    if (!boxes || !scores || ((uintptr_t)boxes & 15) || n > kMaxSort) {
+        vd3d_set_error("nms: boxes must be 16-byte aligned and n <= 8192");
+        return VD3D_EINVAL;
+    }
+    const int lds = (int)nms_lds(n);
+    static int attr = 0;
+    if (lds > attr) {
+        if (hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return vd3d_check_launch("hipFuncSetAttribute(nms)");
+        attr = lds;
+    }
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(kNmsThreads), lds, s, boxes, scores, n, iou_thr, keep, count);
+    return vd3d_check_launch("nms");
+}

@@ -1,0 +1,245 @@
+// stereo.hip -- stereo cost-volume kernels for gfx950 (NHWC activations).
+//
+//  * psm_cosine   : PSMCosineModule.forward (lib/PSM_cost_volume.py:81-96).  The reference walks the D
+//                   disparities with a Python loop (slice, mul, mean, scatter per disparity: ~100 tiny
+//                   kernels, L and R re-read D times).  Here one workgroup stages a 64-pixel LEFT tile and
+//                   the (64 + D - 1)-pixel RIGHT window of one image row in LDS (XOR-swizzled 16-byte slots,
+//                   conflict-free ds_read_b128) and produces all D disparities from that single read of
+//                   L and R -- HBM traffic = read L + read R + write cost.
+//  * costvol_build: concat-volume of CostVolume.forward (lib/PSM_cost_volume.py:49-64), channels-last.
+//  * conv3d_3x3x3 : the two Conv3d+BN3d+ReLU of CostVolume (lib/PSM_cost_volume.py:34-41), direct fp32 FMA
+//                   (C <= 16: 0.25 GFLOP per pair, not MFMA-shaped); weights are wave-uniform -> scalar loads.
+#include "common.h"
+
+namespace {
+
+constexpr int XT = 64;  // pixels per workgroup
+
+template <typename T>
+__global__ void __launch_bounds__(256) psm_cosine_kernel(const T* __restrict__ left, const T* __restrict__ right,
+                                                         T* __restrict__ cost, int H, int W, int C, int D,
+                                                         int ips, int ops, int xtiles) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    constexpr int CHUNK = 128 / (int)sizeof(T);  // channels staged per pass (128 B per pixel)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ls = smem;                  // [XT][128 B]
+    char* Rs = smem + XT * 128;       // [XT + D - 1][128 B], window pixel wp <-> image x = x0 - (D-1) + wp
+
+    const int xt = blockIdx.x % xtiles;
+    const int row = blockIdx.x / xtiles;  // b*H + y
+    const int x0 = xt * XT;
+    const int tid = threadIdx.x;
+    const int px = tid & 63, dg = tid >> 6;  // pixel within tile, disparity group (8 disparities each)
+    const int64_t rowbase = (int64_t)row * W;
+    const int wpix = XT + D - 1;
+
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+
+    for (int c0 = 0; c0 < C; c0 += CHUNK) {
+        const int cw = min(CHUNK, C - c0);  // channels in this pass (multiple of VE)
+        const int nv = cw / VE;             // 16-byte vectors per pixel (<= 8)
+        // ---- stage L tile and R window (zero outside the row) ----
+        for (int v = tid; v < XT * 8; v += 256) {
+            const int p = v >> 3, s = v & 7;
+            i32x4 val = {0, 0, 0, 0};
+            if (s < nv && x0 + p < W) val = *(const i32x4*)(left + (rowbase + x0 + p) * ips + c0 + s * VE);
+            *(i32x4*)(Ls + p * 128 + ((s ^ ((p >> 1) & 7)) << 4)) = val;
+        }
+        for (int v = tid; v < wpix * 8; v += 256) {
+            const int p = v >> 3, s = v & 7;
+            const int x = x0 - (D - 1) + p;
+            i32x4 val = {0, 0, 0, 0};
+            if (s < nv && x >= 0 && x < W) val = *(const i32x4*)(right + (rowbase + x) * ips + c0 + s * VE);
+            *(i32x4*)(Rs + p * 128 + ((s ^ ((p >> 1) & 7)) << 4)) = val;
+        }
+        __syncthreads();
+        if (dg * 8 < D) {
+            for (int s = 0; s < nv; ++s) {
+                Vec16<T> l;
+                l.raw = *(const i32x4*)(Ls + px * 128 + ((s ^ ((px >> 1) & 7)) << 4));
+                float lf[VE];
+#pragma unroll
+                for (int e = 0; e < VE; ++e) lf[e] = l.get(e);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int d = dg * 8 + i;
+                    if (d < D) {
+                        const int wp = px + (D - 1) - d;
+                        Vec16<T> r;
+                        r.raw = *(const i32x4*)(Rs + wp * 128 + ((s ^ ((wp >> 1) & 7)) << 4));
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) acc[i] = fmaf(lf[e], r.get(e), acc[i]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- mean over C, store 8 disparities per thread ----
+    const int x = x0 + px;
+    if (x < W && dg * 8 < D) {
+        const float inv = 1.0f / (float)C;
+        T* o = cost + (rowbase + x) * ops + dg * 8;
+        const int nd = min(8, D - dg * 8);
+        if (nd == 8) {
+            if constexpr (sizeof(T) == 2) {
+                Vec16<T> v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v.set2(e, acc[2 * e] * inv, acc[2 * e + 1] * inv);
+                *(i32x4*)o = v.raw;
+            } else {
+                f32x4 a = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+                f32x4 b = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+                *(f32x4*)o = a;
+                *(f32x4*)(o + 4) = b;
+            }
+        } else {
+            for (int i = 0; i < nd; ++i) o[i] = ElemTraits<T>::from_f(acc[i] * inv);
+        }
+    }
+}
+
+template <typename T>
+__global__ void costvol_build_kernel(const T* __restrict__ left, const T* __restrict__ right, T* __restrict__ vol,
+                                     int B, int H, int W, int F, int D, int ips) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int fv = F / VE;
+    const int64_t total = (int64_t)B * D * H * W * fv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int f = (int)(i % fv) * VE;
+        int64_t r = i / fv;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int d = (int)(r % D);
+        const int b = (int)(r / D);
+        i32x4 l = {0, 0, 0, 0}, rr = {0, 0, 0, 0};
+        if (x >= d) {
+            const int64_t pl = ((int64_t)b * H + y) * W + x;
+            l = *(const i32x4*)(left + pl * ips + f);
+            rr = *(const i32x4*)(right + (pl - d) * ips + f);
+        }
+        T* o = vol + ((((int64_t)b * D + d) * H + y) * W + x) * (2 * F);
+        *(i32x4*)(o + f) = l;
+        *(i32x4*)(o + F + f) = rr;
+    }
+}
+
+// Direct 3x3x3 conv, channels-last; one thread per output voxel, all COUT outputs in registers.
+template <typename T, int CIN, int COUT>
+__global__ void __launch_bounds__(256) conv3d_kernel(const T* __restrict__ in, const float* __restrict__ w,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     T* __restrict__ out, int B, int D, int H, int W, int relu,
+                                                     int out_fd_major, int ops) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int64_t total = (int64_t)B * D * H * W;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int64_t r = i;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H); r /= H;
+    const int d = (int)(r % D);
+    const int b = (int)(r / D);
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+        const int id = d - 1 + kd;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y - 1 + ky;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x - 1 + kx;
+                const bool ok = (unsigned)id < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const float* wt = w + ((kd * 3 + ky) * 3 + kx) * (CIN * COUT);  // wave-uniform -> s_load
+                const T* src = in + ((((int64_t)b * D + id) * H + iy) * W + ix) * CIN;
+#pragma unroll
+                for (int cv = 0; cv < CIN / VE; ++cv) {
+                    Vec16<T> v;
+                    v.raw = i32x4{0, 0, 0, 0};
+                    if (ok) v.raw = *(const i32x4*)(src + cv * VE);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const float xv = v.get(e);
+#pragma unroll
+                        for (int o = 0; o < COUT; ++o) acc[o] = fmaf(xv, wt[(cv * VE + e) * COUT + o], acc[o]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+        float v = acc[o] * scale[o] + shift[o];
+        acc[o] = relu ? fmaxf(v, 0.f) : v;
+    }
+    if (out_fd_major) {
+        T* dst = out + (((int64_t)b * H + y) * W + x) * ops;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) dst[o * D + d] = ElemTraits<T>::from_f(acc[o]);
+    } else {
+        T* dst = out + i * COUT;
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) dst[o] = ElemTraits<T>::from_f(acc[o]);
+    }
+}
+
+inline int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+extern "C" int vd3d_psm_cosine(const void* left, const void* right, void* cost, int B, int H, int W, int C, int D,
+                               int ips, int ops, int dtype, void* stream) {
+    const int ve = dtype == VD3D_BF16 ? 8 : 4;
+    if (!left || !right || !cost || C % ve || ips % ve || D < 1 || D > 32 || ((uintptr_t)left & 15) || ((uintptr_t)right & 15)) {
+        vd3d_set_error("psm_cosine: need C, stride multiples of 16 bytes, 1 <= D <= 32");
+        return VD3D_EINVAL;
+    }
+    const int es = dtype == VD3D_BF16 ? 2 : 4;
+    if ((ops * es) % 16 || ((uintptr_t)cost & 15)) { vd3d_set_error("psm_cosine: output slice must be 16-byte aligned"); return VD3D_EINVAL; }
+    const int xtiles = (W + XT - 1) / XT;
+    const int64_t grid = (int64_t)B * H * xtiles;
+    const int lds = (XT + XT + D - 1) * 128;
+    if (dtype == VD3D_BF16)
+        hipLaunchKernelGGL(psm_cosine_kernel<short>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream,
+                           (const short*)left, (const short*)right, (short*)cost, H, W, C, D, ips, ops, xtiles);
+    else if (dtype == VD3D_F32)
+        hipLaunchKernelGGL(psm_cosine_kernel<float>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream,
+                           (const float*)left, (const float*)right, (float*)cost, H, W, C, D, ips, ops, xtiles);
+    else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }
+    return vd3d_check_launch("psm_cosine");
+}
+
+extern "C" int vd3d_costvol_build(const void* left, const void* right, void* vol, int B, int H, int W, int F, int D,
+                                  int ips, int dtype, void* stream) {
+    const int ve = dtype == VD3D_BF16 ? 8 : 4;
+    if (!left || !right || !vol || F % ve || ips % ve) { vd3d_set_error("costvol_build: F and stride must be 16-byte multiples"); return VD3D_EINVAL; }
+    const int64_t total = (int64_t)B * D * H * W * (F / ve);
+    if (dtype == VD3D_BF16)
+        hipLaunchKernelGGL(costvol_build_kernel<short>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const short*)left, (const short*)right, (short*)vol, B, H, W, F, D, ips);
+    else
+        hipLaunchKernelGGL(costvol_build_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)left, (const float*)right, (float*)vol, B, H, W, F, D, ips);
+    return vd3d_check_launch("costvol_build");
+}
+
+extern "C" int vd3d_conv3d_3x3x3(const void* in, const float* weight, const float* scale, const float* shift, void* out,
+                                 int B, int D, int H, int W, int Cin, int Cout, int relu, int out_fd_major,
+                                 int ops, int dtype, void* stream) {
+    if (!in || !weight || !scale || !shift || !out) { vd3d_set_error("conv3d: null pointer"); return VD3D_EINVAL; }
+    const int64_t total = (int64_t)B * D * H * W;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+#define VD3D_C3D(T, CI, CO)                                                                                         \
+    hipLaunchKernelGGL((conv3d_kernel<T, CI, CO>), dim3(grid), dim3(256), 0, s, (const T*)in, weight, scale, shift, \
+                       (T*)out, B, D, H, W, relu, out_fd_major, ops)
+    if (Cin == 16 && Cout == 8) { if (dtype == VD3D_BF16) VD3D_C3D(short, 16, 8); else VD3D_C3D(float, 16, 8); }
+    else if (Cin == 8 && Cout == 8) { if (dtype == VD3D_BF16) VD3D_C3D(short, 8, 8); else VD3D_C3D(float, 8, 8); }
+    else { vd3d_set_error("conv3d: only (Cin,Cout) in {(16,8),(8,8)} are instantiated (CostVolume PSM_features=8)"); return VD3D_EINVAL; }
+#undef VD3D_C3D
+    return vd3d_check_launch("conv3d_3x3x3");
+}

@@ -1,0 +1,359 @@
+"""torch-tensor front end of the C-ABI in libvd3d_hip.so.
+
+PyTorch is plumbing here (device memory, streams); every arithmetic op below is a hand-written HIP kernel.
+Activation convention: NHWC tensors ``[B, H, W, C]`` (bf16 or fp32) with unit channel stride; a tensor may be a
+channel-slice view of a wider buffer (``buf[..., off:off+C]``) -- that is how ``torch.cat`` along channels is
+fused away: producers write straight into their slice of the concat buffer.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import VD3D_BF16, VD3D_F32, ConvParams, HeadParams, check
+
+
+def dtype_code(dt):
+    if dt == torch.bfloat16:
+        return VD3D_BF16
+    if dt == torch.float32:
+        return VD3D_F32
+    raise TypeError('HIP path supports bfloat16 / float32 activations, got %s' % dt)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.Vd3dError('HIP op called with a CPU tensor: there is no CPU fallback in the product path')
+
+
+def _nhwc_strides(x):
+    """(pix_stride, row_stride, batch_stride) in elements of an NHWC (possibly channel-sliced) tensor."""
+    assert x.dim() == 4 and x.stride(3) == 1, 'expected NHWC with unit channel stride'
+    return x.stride(2), x.stride(1), x.stride(0)
+
+
+def _dense_pixels(x):
+    B, H, W, _ = x.shape
+    ps, rs, bs = _nhwc_strides(x)
+    return rs == W * ps and (B == 1 or bs == H * W * ps)
+
+
+def _bytes_from(x):
+    return x.untyped_storage().nbytes() - x.storage_offset() * x.element_size()
+
+
+def new_act(B, H, W, C_, dtype, device):
+    return torch.empty((B, H, W, C_), dtype=dtype, device=device)
+
+
+# --------------------------------------------------------------------------------------------- conv
+class PackedConv:
+    """Conv weight packed for the implicit-GEMM kernel: ``[CoutPad, Kpad]`` with K = (ky, kx, c), plus the folded
+    epilogue ``y = conv * scale + shift`` (bias and eval-mode BatchNorm)."""
+
+    def __init__(self, w, scale, shift, Cin, Cout, kh, kw, stride, pad, dil, Kpad, CoutPad, dtype):
+        self.w, self.scale, self.shift = w, scale, shift
+        self.Cin, self.Cout, self.kh, self.kw = Cin, Cout, kh, kw
+        self.stride, self.pad, self.dil = stride, pad, dil
+        self.Kpad, self.CoutPad, self.dtype = Kpad, CoutPad, dtype
+
+
+def fold_bn(bias, bn, cout, device):
+    """(scale, shift) fp32 from an optional conv bias and optional eval-mode BN ``(gamma, beta, mean, var, eps)``."""
+    shift = bias.detach().float() if bias is not None else torch.zeros(cout, device=device)
+    scale = None
+    if bn is not None:
+        gamma, beta, mean, var, eps = bn
+        scale = gamma.detach().float() / torch.sqrt(var.detach().float() + eps)
+        shift = shift * scale + (beta.detach().float() - mean.detach().float() * scale)
+    return (scale.contiguous() if scale is not None else None), shift.contiguous()
+
+
+def pack_conv(weight, bias=None, bn=None, dtype=torch.bfloat16, stride=1, pad=0, dil=1, cin_pad=None):
+    """weight: OIHW fp32 (on the GPU).  cin_pad: pad input channels with zeros up to this count (the activation
+    buffer then has that many channels)."""
+    O, I, kh, kw = weight.shape
+    dev = weight.device
+    ve = 8 if dtype == torch.bfloat16 else 4
+    bke = 64 if dtype == torch.bfloat16 else 32
+    Cin = cin_pad or I
+    assert Cin % ve == 0, 'input channels must be a multiple of %d for %s' % (ve, dtype)
+    w = weight.detach().float().permute(0, 2, 3, 1)  # O, kh, kw, I
+    if Cin != I:
+        w = torch.nn.functional.pad(w, (0, Cin - I))
+    K = kh * kw * Cin
+    Kpad = (K + bke - 1) // bke * bke
+    CoutPad = (O + 127) // 128 * 128
+    packed = torch.zeros((CoutPad, Kpad), dtype=dtype, device=dev)
+    packed[:O, :K] = w.reshape(O, K).to(dtype)
+    scale, shift = fold_bn(bias, bn, O, dev)
+    return PackedConv(packed, scale, shift, Cin, O, kh, kw, stride, pad, dil, Kpad, CoutPad, dtype)
+
+
+def pack_stem_conv(weight, bn, dtype):
+    """7x7/s2 stem (backbones/resnet.py:118) as a (7 x 1)-tap conv over 32-element rows: the packed image
+    (vd3d_pack_image_nhwc4) is NHWC4 with a 3-px zero border, so kernel row ky of output pixel (oy, ox) is the 8
+    consecutive pixels starting at padded (2*oy + ky, 2*ox): 8 px * 4 ch = 32 contiguous elements (8th px and 4th
+    channel carry zero weights)."""
+    O, I, kh, kw = weight.shape
+    assert (I, kh, kw) == (3, 7, 7)
+    dev = weight.device
+    w = torch.zeros((O, 7, 8, 4), dtype=torch.float32, device=dev)
+    w[:, :, :7, :3] = weight.detach().float().permute(0, 2, 3, 1)
+    K = 7 * 32
+    bke = 64 if dtype == torch.bfloat16 else 32
+    Kpad = (K + bke - 1) // bke * bke
+    CoutPad = (O + 127) // 128 * 128
+    packed = torch.zeros((CoutPad, Kpad), dtype=dtype, device=dev)
+    packed[:O, :K] = w.reshape(O, K).to(dtype)
+    scale, shift = fold_bn(None, bn, O, dev)
+    return PackedConv(packed, scale, shift, 32, O, 7, 1, 2, 0, 1, Kpad, CoutPad, dtype)
+
+
+def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
+    """Fused conv (+bias/BN) (+residual) (+ReLU).  x: NHWC (C >= pc.Cin used), returns NHWC ``[B,Ho,Wo,Cout]``."""
+    _require_cuda(x, pc.w, out, residual)
+    B, H, W, Cx = x.shape
+    assert x.dtype == pc.dtype and Cx == pc.Cin, (x.dtype, pc.dtype, Cx, pc.Cin)
+    ips, irs, ibs = _nhwc_strides(x)
+    Ho = (H + 2 * pc.pad - pc.dil * (pc.kh - 1) - 1) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.dil * (pc.kw - 1) - 1) // pc.stride + 1
+    odt = torch.float32 if out_f32 else x.dtype
+    if out is None:
+        out = torch.empty((B, Ho, Wo, pc.Cout), dtype=odt, device=x.device)
+    assert out.shape == (B, Ho, Wo, pc.Cout) and out.dtype == odt and _dense_pixels(out)
+    p = ConvParams()
+    p.in_, p.weight, p.out = x.data_ptr(), pc.w.data_ptr(), out.data_ptr()
+    p.scale = pc.scale.data_ptr() if pc.scale is not None else None
+    p.shift = pc.shift.data_ptr() if pc.shift is not None else None
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype and _dense_pixels(residual)
+        p.residual, p.res_pix_stride = residual.data_ptr(), residual.stride(2)
+    p.B, p.H, p.W, p.Cin = B, H, W, pc.Cin
+    p.in_pix_stride, p.in_row_stride, p.in_batch_stride = ips, irs, ibs
+    p.in_bytes = _bytes_from(x)
+    p.Ho, p.Wo, p.Cout = Ho, Wo, pc.Cout
+    p.out_pix_stride = out.stride(2)
+    p.kh, p.kw, p.stride, p.pad, p.dil = pc.kh, pc.kw, pc.stride, pc.pad, pc.dil
+    p.Kpad, p.CoutPad, p.relu = pc.Kpad, pc.CoutPad, int(relu)
+    p.dtype, p.out_f32 = dtype_code(x.dtype), int(out_f32)
+    check(_lib.lib().vd3d_conv2d_igemm(C.byref(p), _stream()), 'vd3d_conv2d_igemm')
+    return out
+
+
+def stem_conv(img_nchw, pc, dtype):
+    """Stem: pack NCHW fp32 image to bordered NHWC4, then the 7x7/s2 conv + BN + ReLU as an implicit GEMM."""
+    _require_cuda(img_nchw)
+    B, Cc, H, W = img_nchw.shape
+    assert Cc == 3 and img_nchw.dtype == torch.float32 and img_nchw.is_contiguous()
+    Hp, Wp = H + 6, W + 8  # 3 px border top/bottom/left, 5 px right (keeps rows 16-byte aligned, covers the 8-px tap)
+    packed = torch.empty((B, Hp, Wp, 4), dtype=dtype, device=img_nchw.device)
+    check(_lib.lib().vd3d_pack_image_nhwc4(_p(img_nchw), _p(packed), B, H, W, 3, 3, 5, dtype_code(dtype), _stream()),
+          'vd3d_pack_image_nhwc4')
+    Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    out = torch.empty((B, Ho, Wo, pc.Cout), dtype=dtype, device=img_nchw.device)
+    p = ConvParams()
+    p.in_, p.weight, p.out = packed.data_ptr(), pc.w.data_ptr(), out.data_ptr()
+    p.scale = pc.scale.data_ptr() if pc.scale is not None else None
+    p.shift = pc.shift.data_ptr()
+    # "pixel" = 4-element NHWC4 pixel; Cin = 32 contiguous elements per tap row; bounds never trigger (bordered)
+    p.B, p.H, p.W, p.Cin = B, Hp, Wp, 32
+    p.in_pix_stride, p.in_row_stride, p.in_batch_stride = 4, Wp * 4, Hp * Wp * 4
+    p.in_bytes = _bytes_from(packed)
+    p.Ho, p.Wo, p.Cout = Ho, Wo, pc.Cout
+    p.out_pix_stride = pc.Cout
+    p.kh, p.kw, p.stride, p.pad, p.dil = 7, 1, 2, 0, 1
+    p.Kpad, p.CoutPad, p.relu = pc.Kpad, pc.CoutPad, 1
+    p.dtype, p.out_f32 = dtype_code(dtype), 0
+    check(_lib.lib().vd3d_conv2d_igemm(C.byref(p), _stream()), 'vd3d_conv2d_igemm(stem)')
+    return out
+
+
+# --------------------------------------------------------------------------------------------- elementwise
+def maxpool3x3s2(x, out=None):
+    _require_cuda(x)
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    assert _dense_pixels(x) and _dense_pixels(out)
+    check(_lib.lib().vd3d_maxpool3x3s2(_p(x), _p(out), B, H, W, Cc, x.stride(2), out.stride(2), dtype_code(x.dtype), _stream()),
+          'vd3d_maxpool3x3s2')
+    return out
+
+
+def avgpool2x2(x, out=None):
+    _require_cuda(x)
+    B, H, W, Cc = x.shape
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+    assert _dense_pixels(x) and _dense_pixels(out)
+    check(_lib.lib().vd3d_avgpool2x2(_p(x), _p(out), B, H, W, Cc, x.stride(2), out.stride(2), dtype_code(x.dtype), _stream()),
+          'vd3d_avgpool2x2')
+    return out
+
+
+class PackedDW:
+    def __init__(self, w, scale, shift, C_):
+        self.w, self.scale, self.shift, self.C = w, scale, shift, C_
+
+
+def pack_dwconv(weight, bn):
+    """weight [C,1,3,3] -> [9][C] fp32 + folded BN."""
+    Cc = weight.shape[0]
+    w = weight.detach().float().reshape(Cc, 9).t().contiguous()
+    scale, shift = fold_bn(None, bn, Cc, weight.device)
+    return PackedDW(w, scale, shift, Cc)
+
+
+def dwconv3x3(x, pd, out=None, relu=True):
+    _require_cuda(x)
+    B, H, W, Cc = x.shape
+    assert Cc == pd.C
+    if out is None:
+        out = torch.empty((B, H, W, Cc), dtype=x.dtype, device=x.device)
+    assert _dense_pixels(x) and _dense_pixels(out)
+    check(_lib.lib().vd3d_dwconv3x3(_p(x), _p(pd.w), _p(pd.scale), _p(pd.shift), _p(out), B, H, W, Cc,
+                                    x.stride(2), out.stride(2), int(relu), dtype_code(x.dtype), _stream()), 'vd3d_dwconv3x3')
+    return out
+
+
+def copy_channels(x, out):
+    _require_cuda(x, out)
+    B, H, W, Cc = x.shape
+    assert out.shape == x.shape and out.dtype == x.dtype and _dense_pixels(x) and _dense_pixels(out)
+    check(_lib.lib().vd3d_copy_channels(_p(x), _p(out), B * H * W, Cc, x.stride(2), out.stride(2), dtype_code(x.dtype), _stream()),
+          'vd3d_copy_channels')
+    return out
+
+
+def nhwc_to_nchw_f32(x):
+    _require_cuda(x)
+    B, H, W, Cc = x.shape
+    assert _dense_pixels(x)
+    out = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+    check(_lib.lib().vd3d_nhwc_to_nchw_f32(_p(x), _p(out), B, H, W, Cc, x.stride(2), dtype_code(x.dtype), _stream()),
+          'vd3d_nhwc_to_nchw_f32')
+    return out
+
+
+def nchw_f32_to_nhwc(x, dtype, out=None):
+    _require_cuda(x)
+    B, Cc, H, W = x.shape
+    x = x.float().contiguous()
+    if out is None:
+        out = torch.empty((B, H, W, Cc), dtype=dtype, device=x.device)
+    check(_lib.lib().vd3d_nchw_f32_to_nhwc(_p(x), _p(out), B, H, W, Cc, out.stride(2), dtype_code(dtype), _stream()),
+          'vd3d_nchw_f32_to_nhwc')
+    return out
+
+
+# --------------------------------------------------------------------------------------------- stereo
+def psm_cosine(left, right, D, out=None):
+    _require_cuda(left, right)
+    B, H, W, Cc = left.shape
+    assert right.shape == left.shape and left.dtype == right.dtype
+    assert _dense_pixels(left) and _dense_pixels(right) and left.stride(2) == right.stride(2)
+    if out is None:
+        out = torch.empty((B, H, W, D), dtype=left.dtype, device=left.device)
+    assert out.shape == (B, H, W, D) and _dense_pixels(out)
+    check(_lib.lib().vd3d_psm_cosine(_p(left), _p(right), _p(out), B, H, W, Cc, D, left.stride(2), out.stride(2),
+                                     dtype_code(left.dtype), _stream()), 'vd3d_psm_cosine')
+    return out
+
+
+def costvol_build(left, right, D):
+    _require_cuda(left, right)
+    B, H, W, F = left.shape
+    assert _dense_pixels(left) and _dense_pixels(right) and left.stride(2) == right.stride(2)
+    vol = torch.empty((B, D, H, W, 2 * F), dtype=left.dtype, device=left.device)
+    check(_lib.lib().vd3d_costvol_build(_p(left), _p(right), _p(vol), B, H, W, F, D, left.stride(2),
+                                        dtype_code(left.dtype), _stream()), 'vd3d_costvol_build')
+    return vol
+
+
+class PackedConv3d:
+    def __init__(self, w, scale, shift, Cin, Cout):
+        self.w, self.scale, self.shift, self.Cin, self.Cout = w, scale, shift, Cin, Cout
+
+
+def pack_conv3d(weight, bias, bn):
+    """weight [O,I,3,3,3] -> [27][I][O] fp32 + folded bias/BN3d."""
+    O, I = weight.shape[:2]
+    w = weight.detach().float().permute(2, 3, 4, 1, 0).reshape(27, I, O).contiguous()
+    scale, shift = fold_bn(bias, bn, O, weight.device)
+    if scale is None:
+        scale = torch.ones(O, device=weight.device)
+    return PackedConv3d(w, scale, shift, I, O)
+
+
+def conv3d_3x3x3(vol, pc, relu=True, out_nhwc=None):
+    """vol: [B,D,H,W,Cin] channels-last.  out_nhwc given => write NHWC [B,H,W,Cout*D] (channel = f*D + d)."""
+    _require_cuda(vol)
+    B, D, H, W, Cin = vol.shape
+    assert Cin == pc.Cin and vol.is_contiguous()
+    if out_nhwc is not None:
+        assert out_nhwc.shape == (B, H, W, pc.Cout * D) and _dense_pixels(out_nhwc)
+        out, fd, ops = out_nhwc, 1, out_nhwc.stride(2)
+    else:
+        out, fd, ops = torch.empty((B, D, H, W, pc.Cout), dtype=vol.dtype, device=vol.device), 0, 0
+    check(_lib.lib().vd3d_conv3d_3x3x3(_p(vol), _p(pc.w), _p(pc.scale), _p(pc.shift), _p(out), B, D, H, W, Cin, pc.Cout,
+                                       int(relu), fd, ops, dtype_code(vol.dtype), _stream()), 'vd3d_conv3d_3x3x3')
+    return out
+
+
+# --------------------------------------------------------------------------------------------- head
+def head_postprocess(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr,
+                     use_filter=True, y_min_max=(-0.5, 1.8), x_max=40.0, max_cand=4096, max_det=None, workspace=None):
+    """Device-side get_bboxes for a whole batch.  Returns padded (scores [B,K], boxes [B,K,11], labels [B,K] i32,
+    anchor_idx [B,K] i32, count [B] i32) -- all on the device, no host sync."""
+    _require_cuda(cls, reg, anchors, prior, P2)
+    B, N, nc1 = cls.shape
+    assert nc1 == n_cls + 1 and reg.shape == (B, N, 12) and cls.dtype == torch.float32 and reg.dtype == torch.float32
+    assert cls.is_contiguous() and reg.is_contiguous() and anchors.is_contiguous() and prior.is_contiguous()
+    assert anchors.shape == (N, 4) and prior.shape == (A, n_types, 6, 2) and P2.shape == (B, 3, 4)
+    P2 = P2.float().contiguous()
+    max_det = max_det or max_cand
+    dev = cls.device
+    need = _lib.lib().vd3d_head_workspace_bytes(B, max_cand)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    scores = torch.empty((B, max_det), dtype=torch.float32, device=dev)
+    boxes = torch.empty((B, max_det, 11), dtype=torch.float32, device=dev)
+    labels = torch.empty((B, max_det), dtype=torch.int32, device=dev)
+    aidx = torch.empty((B, max_det), dtype=torch.int32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    p = HeadParams()
+    p.cls, p.reg, p.anchors, p.prior_mean_std, p.P2 = cls.data_ptr(), reg.data_ptr(), anchors.data_ptr(), prior.data_ptr(), P2.data_ptr()
+    p.B, p.N, p.A, p.n_cls, p.n_types = B, N, A, n_cls, n_types
+    p.img_h, p.img_w = int(img_hw[0]), int(img_hw[1])
+    p.score_thr, p.nms_iou_thr = float(score_thr), float(nms_iou_thr)
+    p.filter_y_min, p.filter_y_max, p.filter_x_max = float(y_min_max[0]), float(y_min_max[1]), float(x_max)
+    p.use_filter, p.max_cand, p.max_det = int(use_filter), int(max_cand), int(max_det)
+    p.workspace = workspace.data_ptr()
+    p.out_scores, p.out_boxes, p.out_labels, p.out_anchor, p.out_count = (
+        scores.data_ptr(), boxes.data_ptr(), labels.data_ptr(), aidx.data_ptr(), count.data_ptr())
+    check(_lib.lib().vd3d_head_postprocess(C.byref(p), _stream()), 'vd3d_head_postprocess')
+    return scores, boxes, labels, aidx, count
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms drop-in on the GPU: int64 keep indices in decreasing-score order."""
+    _require_cuda(boxes, scores)
+    n = boxes.shape[0]
+    boxes = boxes.float().contiguous()
+    scores = scores.float().contiguous()
+    keep = torch.empty((max(n, 1),), dtype=torch.int32, device=boxes.device)
+    count = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    check(_lib.lib().vd3d_nms(_p(boxes), _p(scores), n, float(iou_threshold), _p(keep), _p(count), None, _stream()), 'vd3d_nms')
+    k = int(count.item())
+    return keep[:k].long()

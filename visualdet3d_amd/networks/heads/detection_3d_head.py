@@ -1,0 +1,215 @@
+"""Anchor-based 3D detection heads with the reference's constructor and parameter names
+(heads/detection_3d_head.py:21-100,218-263,310-400,500-533), inference path only.
+
+Towers are fused implicit-GEMM convs on NHWC; the last conv of each tower writes fp32 ``[B,H,W,A*C]`` which *is* the
+``AnchorFlatten`` layout.  ``get_bboxes`` runs entirely on the device for the whole batch
+(``vd3d_head_postprocess``: ground filter, sigmoid, threshold, argmax, decode, clip, z-prior mask, NMS) and
+synchronises with the host exactly once, to learn the detection counts.
+
+Training-side members (``_assign``, ``_encode``, ``_sample``, ``loss``) are out of scope; the loss buffers
+are registered so reference checkpoints load with identical keys."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import hip_ops as ops
+from ...utils.config import EasyDict
+from ..backbones.resnet import BasicBlock
+from ..lib import fused
+from ..lib.blocks import AnchorFlatten, ConvBnReLU
+from ..utils.utils import BackProjection, ClipBoxes
+from .anchors import Anchors
+
+
+class _LossStub(nn.Module):
+    """Holds the buffers the reference's SigmoidFocalLoss registers (heads/losses.py) -- checkpoint-key parity only."""
+
+    def __init__(self, balance_weights=None):
+        super(_LossStub, self).__init__()
+        if balance_weights is not None:
+            self.register_buffer('balance_weights', balance_weights)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('training losses are out of scope of the inference path')
+
+
+def _conv_pack(cache, key, conv, bn, dtype):
+    srcs = [conv.weight, conv.bias] + (fused.bn_sources(bn) if bn is not None else [])
+    return cache.get((key, dtype), srcs,
+                     lambda: ops.pack_conv(conv.weight, conv.bias, fused.bn_tuple(bn) if bn is not None else None, dtype,
+                                           conv.stride[0], conv.padding[0], conv.dilation[0]))
+
+
+class AnchorBasedDetection3DHead(nn.Module):
+    def __init__(self, num_features_in: int = 1024, num_classes: int = 3, num_regression_loss_terms=12,
+                 preprocessed_path: str = '', anchors_cfg=EasyDict(), layer_cfg=EasyDict(), loss_cfg=EasyDict(),
+                 test_cfg=EasyDict(), read_precompute_anchor: bool = True):
+        super(AnchorBasedDetection3DHead, self).__init__()
+        self.anchors = Anchors(preprocessed_path=preprocessed_path, readConfigFile=read_precompute_anchor, **anchors_cfg)
+        self.num_classes = num_classes
+        self.num_regression_loss_terms = num_regression_loss_terms
+        self.decode_before_loss = getattr(loss_cfg, 'decode_before_loss', False)
+        self.loss_cfg = loss_cfg
+        self.test_cfg = test_cfg
+        self.build_loss(**loss_cfg)
+        self.backprojector = BackProjection()
+        self.clipper = ClipBoxes()
+        if getattr(layer_cfg, 'num_anchors', None) is None:
+            layer_cfg['num_anchors'] = self.anchors.num_anchors
+        self.init_layers(**layer_cfg)
+        self._cache = fused.PackCache()
+        self.max_candidates = 4096   # per-sample capacity of the device candidate list (power of two <= 8192)
+        self._workspace = None
+
+    # ---- layers ---------------------------------------------------------------------------------------------
+    def _cls_tower(self, num_features_in, cls_feature_size, num_anchors, num_cls_output):
+        tower = nn.Sequential(
+            nn.Conv2d(num_features_in, cls_feature_size, kernel_size=3, padding=1),
+            nn.Dropout2d(0.3),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(cls_feature_size, cls_feature_size, kernel_size=3, padding=1),
+            nn.Dropout2d(0.3),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(cls_feature_size, num_anchors * num_cls_output, kernel_size=3, padding=1),
+            AnchorFlatten(num_cls_output),
+        )
+        tower[-2].weight.data.fill_(0)
+        tower[-2].bias.data.fill_(0)
+        return tower
+
+    def init_layers(self, num_features_in, num_anchors: int, num_cls_output: int, num_reg_output: int,
+                    cls_feature_size: int = 1024, reg_feature_size: int = 1024, **kwargs):
+        """Base head: reg tower opens with DCNv2 (detection_3d_head.py:69-79)."""
+        from ..lib.ops import ModulatedDeformConvPack
+        self.cls_feature_extraction = self._cls_tower(num_features_in, cls_feature_size, num_anchors, num_cls_output)
+        self.reg_feature_extraction = nn.Sequential(
+            ModulatedDeformConvPack(num_features_in, reg_feature_size, 3, padding=1),
+            nn.BatchNorm2d(reg_feature_size),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(reg_feature_size, reg_feature_size, kernel_size=3, padding=1),
+            nn.BatchNorm2d(reg_feature_size),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(reg_feature_size, num_anchors * num_reg_output, kernel_size=3, padding=1),
+            AnchorFlatten(num_reg_output),
+        )
+        self.reg_feature_extraction[-2].weight.data.fill_(0)
+        self.reg_feature_extraction[-2].bias.data.fill_(0)
+
+    def build_loss(self, focal_loss_gamma=0.0, balance_weight=[0], L1_regression_alpha=9, **kwargs):
+        self.focal_loss_gamma = focal_loss_gamma
+        self.register_buffer('balance_weights', torch.tensor(balance_weight, dtype=torch.float32))
+        self.loss_cls = _LossStub(self.balance_weights)
+        regression_weight = kwargs.get('regression_weight', [1 for _ in range(self.num_regression_loss_terms)])
+        self.register_buffer('regression_weight', torch.tensor(regression_weight, dtype=torch.float))
+
+    # ---- towers ---------------------------------------------------------------------------------------------
+    def _cls_forward_nhwc(self, feat):
+        t, dt = self.cls_feature_extraction, feat.dtype
+        x = ops.conv2d(feat, _conv_pack(self._cache, 'cls0', t[0], None, dt), relu=True)
+        x = ops.conv2d(x, _conv_pack(self._cache, 'cls3', t[3], None, dt), relu=True)
+        x = ops.conv2d(x, _conv_pack(self._cache, 'cls6', t[6], None, dt), relu=False, out_f32=True)
+        return t[7].forward_nhwc(x)
+
+    def _reg_forward_nhwc(self, feat, inputs=None):
+        t, dt = self.reg_feature_extraction, feat.dtype
+        x = t[0].forward_nhwc(feat, bn=t[1], relu=True)     # DCNv2 + BN + ReLU
+        x = ops.conv2d(x, _conv_pack(self._cache, 'reg3', t[3], t[4], dt), relu=True)
+        x = ops.conv2d(x, _conv_pack(self._cache, 'reg6', t[6], None, dt), relu=False, out_f32=True)
+        return t[7].forward_nhwc(x)
+
+    def forward_nhwc(self, inputs):
+        feat = inputs['features']
+        return self._cls_forward_nhwc(feat), self._reg_forward_nhwc(feat, inputs)
+
+    def forward(self, inputs):
+        """Reference signature: ``inputs['features']`` is NCHW fp32."""
+        d = dict(inputs)
+        d['features'] = fused.to_nhwc(inputs['features'])
+        return self.forward_nhwc(d)
+
+    # ---- anchors ----------------------------------------------------------------------------------------------
+    def _is_filtering(self):
+        is_filtering = getattr(self.loss_cfg, 'filter_anchor', True)
+        if not self.training:
+            is_filtering = getattr(self.test_cfg, 'filter_anchor', is_filtering)
+        return is_filtering
+
+    def get_anchor(self, img_batch, P2):
+        anchors, useful_mask, anchor_mean_std = self.anchors(img_batch, P2, is_filtering=self._is_filtering())
+        return dict(anchors=anchors, mask=useful_mask, anchor_mean_std_3d=anchor_mean_std)
+
+    # ---- post-processing ------------------------------------------------------------------------------------
+    def get_bboxes_batched(self, cls_preds, reg_preds, P2s, img_hw):
+        """Device-side ``get_bboxes`` for B samples.  Returns padded device tensors
+        (scores [B,K], boxes [B,K,11], labels [B,K] int32, anchor_idx [B,K] int32, count [B] int32); no host sync."""
+        dev = cls_preds.device
+        anchors, prior, A = self.anchors.device_tables(img_hw, dev)
+        B = cls_preds.shape[0]
+        need = ops._lib.lib().vd3d_head_workspace_bytes(B, self.max_candidates)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        lo, hi = self.anchors.filter_y_threshold_min_max
+        return ops.head_postprocess(
+            cls_preds, reg_preds, anchors, prior, P2s.to(dev), A, self.num_classes, len(self.anchors.obj_types), img_hw,
+            getattr(self.test_cfg, 'score_thr', 0.5), getattr(self.test_cfg, 'nms_iou_thr', 0.5),
+            use_filter=bool(self._is_filtering() and self.anchors.readConfigFile), y_min_max=(lo, hi),
+            x_max=self.anchors.filter_x_threshold, max_cand=self.max_candidates, workspace=self._workspace)
+
+    @staticmethod
+    def unpad(padded):
+        """One host sync: slice the padded batch results into per-sample (scores, boxes, labels int64) tuples."""
+        scores, boxes, labels, aidx, count = padded
+        counts = count.tolist()
+        outs = []
+        for b, k in enumerate(counts):
+            if k < 0:
+                raise RuntimeError('sample %d: more candidates than max_candidates (or detections than max_det); '
+                                   'raise AnchorBasedDetection3DHead.max_candidates' % b)
+            outs.append((scores[b, :k], boxes[b, :k], labels[b, :k].long()))
+        return outs
+
+    def get_bboxes(self, cls_scores, reg_preds, anchors, P2s, img_batch=None):
+        """Reference signature (batch 1).  ``anchors`` (the get_anchor dict) is accepted for compatibility; the device
+        kernel uses the cached tables for ``img_batch``'s shape."""
+        assert cls_scores.shape[0] == 1
+        assert img_batch is not None, 'image batch (for its H, W) is required'
+        padded = self.get_bboxes_batched(cls_scores.float().contiguous(), reg_preds.float().contiguous(), P2s, img_batch.shape[2:])
+        max_score, bboxes, label = self.unpad(padded)[0]
+        if getattr(self.test_cfg, 'post_optimization', False):
+            max_score, bboxes, label = self._post_process(max_score, bboxes, label, P2s)
+        return max_score, bboxes, label
+
+    def _post_process(self, scores, bboxes, labels, P2s):
+        from ..lib.fast_utils.hill_climbing import post_opt
+        N = len(scores)
+        bbox2d = bboxes[:, 0:4]
+        bbox3d = bboxes[:, 4:]
+        state = self.backprojector.forward(bbox3d, P2s[0])
+        for i in range(N):
+            if state[i, 2] > 3 and labels[i] == 0:
+                bbox3d[i] = post_opt(bbox2d[i], state[i], P2s[0].cpu().numpy(), bbox3d[i, 0].item(), bbox3d[i, 1].item())
+        return scores, torch.cat([bbox2d, bbox3d], dim=-1), labels
+
+
+class StereoHead(AnchorBasedDetection3DHead):
+    """heads/detection_3d_head.py:500-533: reg tower = ConvBnReLU -> BasicBlock -> ReLU -> conv."""
+
+    def init_layers(self, num_features_in, num_anchors: int, num_cls_output: int, num_reg_output: int,
+                    cls_feature_size: int = 1024, reg_feature_size: int = 1024, **kwargs):
+        self.cls_feature_extraction = self._cls_tower(num_features_in, cls_feature_size, num_anchors, num_cls_output)
+        self.reg_feature_extraction = nn.Sequential(
+            ConvBnReLU(num_features_in, reg_feature_size, (3, 3)),
+            BasicBlock(reg_feature_size, reg_feature_size),
+            nn.ReLU(),
+            nn.Conv2d(reg_feature_size, num_anchors * num_reg_output, kernel_size=3, padding=1),
+            AnchorFlatten(num_reg_output),
+        )
+        self.reg_feature_extraction[-2].weight.data.fill_(0)
+        self.reg_feature_extraction[-2].bias.data.fill_(0)
+
+    def _reg_forward_nhwc(self, feat, inputs=None):
+        t, dt = self.reg_feature_extraction, feat.dtype
+        x = t[0].forward_nhwc(feat)
+        x = t[1].forward_nhwc(x)      # ends in ReLU; the extra nn.ReLU (t[2]) is a no-op
+        x = ops.conv2d(x, _conv_pack(self._cache, 'reg3', t[3], None, dt), relu=False, out_f32=True)
+        return t[4].forward_nhwc(x)
