@@ -16,6 +16,10 @@ typedef __attribute__((ext_vector_type(2))) int i32x2;
 #define VD3D_DEV __device__ __forceinline__
 
 // bf16 <-> f32.  gfx950 has v_cvt_pk_bf16_f32 (RNE); clang emits it for __bf16 conversions.
+// NB: __builtin_bit_cast applied directly to an ext-vector ELEMENT lvalue (v[i]) reads lane 0 of the vector with
+// this compiler; always go through a by-value helper.
+VD3D_DEV float i2f(int v) { return __builtin_bit_cast(float, v); }
+VD3D_DEV int f2i(float v) { return __builtin_bit_cast(int, v); }
 VD3D_DEV float bf2f(short v) { return __builtin_bit_cast(float, ((uint32_t)(uint16_t)v) << 16); }
 VD3D_DEV short f2bf(float f) {
     __bf16 b = (__bf16)f;
@@ -39,8 +43,9 @@ template <typename T> struct Vec16;
 template <> struct Vec16<short> {
     i32x4 raw;
     VD3D_DEV float get(int i) const {
-        uint32_t w = (uint32_t)raw[i >> 1];
-        return __builtin_bit_cast(float, (i & 1) ? (w & 0xffff0000u) : (w << 16));
+        const int wi = raw[i >> 1];
+        const uint32_t w = (uint32_t)wi;
+        return i2f((int)((i & 1) ? (w & 0xffff0000u) : (w << 16)));
     }
     VD3D_DEV void set2(int pair, float lo, float hi) {
         uint32_t l = (uint16_t)f2bf(lo), h = (uint16_t)f2bf(hi);
@@ -49,8 +54,8 @@ template <> struct Vec16<short> {
 };
 template <> struct Vec16<float> {
     i32x4 raw;
-    VD3D_DEV float get(int i) const { return __builtin_bit_cast(float, raw[i]); }
-    VD3D_DEV void set(int i, float v) { raw[i] = __builtin_bit_cast(int, v); }
+    VD3D_DEV float get(int i) const { const int w = raw[i]; return i2f(w); }
+    VD3D_DEV void set(int i, float v) { raw[i] = f2i(v); }
 };
 
 // host-side error plumbing ------------------------------------------------------------------------

@@ -56,8 +56,10 @@ template <> struct Mma<float> {
     // any bijection k -> (mfma, half) is valid as long as A and B use the same one.
     static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a[j]), __builtin_bit_cast(float, b[j]), acc, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const int aj = a[j], bj = b[j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(i2f(aj), i2f(bj), acc, 0, 0, 0);
+        }
     }
 };
 
@@ -230,10 +232,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
                     if (p.residual) {
                         if constexpr (sizeof(T) == 2) {
                             const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
-                            v[0] += __builtin_bit_cast(float, (uint32_t)rr[0] << 16);
-                            v[1] += __builtin_bit_cast(float, (uint32_t)rr[0] & 0xffff0000u);
-                            v[2] += __builtin_bit_cast(float, (uint32_t)rr[1] << 16);
-                            v[3] += __builtin_bit_cast(float, (uint32_t)rr[1] & 0xffff0000u);
+                            const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
+                            v[0] += i2f((int)(r0 << 16));
+                            v[1] += i2f((int)(r0 & 0xffff0000u));
+                            v[2] += i2f((int)(r1 << 16));
+                            v[3] += i2f((int)(r1 & 0xffff0000u));
                         } else {
                             const f32x4 rr = *(const f32x4*)(p.residual + (rbase + nb) * 4);
 #pragma unroll
