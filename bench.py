@@ -82,6 +82,12 @@ def profile_convs(model, inputs, reps=3):
         torch.cuda.synchronize()
     finally:
         ops.conv2d = orig
+    if os.environ.get('VD3D_BENCH_LAYERS'):
+        per = len(records) // reps
+        for i in range(per):
+            fl = records[i][0]
+            t = sum(records[i + r * per][1].elapsed_time(records[i + r * per][2]) for r in range(reps)) / reps
+            print('  conv %2d  %8.2f GF  %8.1f us  %7.1f TF/s' % (i, fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     flops = sum(r[0] for r in records) / reps
     secs = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3 / reps
     return flops, secs, len(records) // reps
@@ -91,7 +97,7 @@ def cpu_baseline(cfg, sd, args):
     """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) on a bounded sample."""
     from oracle import detector_oracle as orc
     from visualdet3d_amd.utils import synthetic as syn
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))   # more threads than this is slower on the 256-thread host
     L, R = syn.stereo_pair(1, args.height, args.width, seed=0)
     P2, _ = syn.kitti_calib(args.width, batch=1)
     sd_cpu = {k: v.detach().cpu() for k, v in sd.items()}

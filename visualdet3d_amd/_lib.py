@@ -86,6 +86,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise Vd3dError('%s not found -- run `python -m visualdet3d_amd.build` (hipcc, gfx950). '
                             'There is no CPU / PyTorch fallback for the HIP path.' % LIB_PATH)
+        # torch bundles its own libamdhip64 (soname libamdhip64.so.7, NEEDED by torch as "libamdhip64.so").  Import torch
+        # FIRST so the HIP runtime that owns torch's device context is the one this library binds to; loading
+        # /opt/rocm's copy first would leave two HIP runtimes in the process ("no ROCm-capable device").
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(h, name)  # AttributeError if the .so is stale

@@ -308,7 +308,11 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
     const int es = p->dtype == VD3D_BF16 ? 2 : (p->dtype == VD3D_F32 ? 4 : 0);
     if (!es) { vd3d_set_error("conv2d_igemm: bad dtype"); return VD3D_EINVAL; }
     const int ve = 16 / es, bke = 128 / es;
-    if (p->Cin % ve || p->in_pix_stride % ve || p->in_row_stride % ve || p->in_batch_stride % ve ||
+    // every 16-byte vector must start on a 16-byte boundary: normally the pixel stride is a vector multiple; the
+    // stem (NHWC4, pad 0, kw 1) only needs stride * pix_stride to be one
+    const bool pix_ok = (p->in_pix_stride % ve == 0) ||
+                        (p->pad == 0 && p->kw == 1 && (p->stride * p->in_pix_stride) % ve == 0);
+    if (p->Cin % ve || !pix_ok || p->in_row_stride % ve || p->in_batch_stride % ve ||
         ((uintptr_t)p->in & 15) || ((uintptr_t)p->weight & 15)) {
         vd3d_set_error("conv2d_igemm: input channels / strides / pointers must be 16-byte aligned");
         return VD3D_EINVAL;

@@ -18,7 +18,7 @@ constexpr int XT = 64;  // pixels per workgroup
 template <typename T>
 __global__ void __launch_bounds__(256) psm_cosine_kernel(const T* __restrict__ left, const T* __restrict__ right,
                                                          T* __restrict__ cost, int H, int W, int C, int D,
-                                                         int ips, int ops, int xtiles) {
+                                                         int ips, int ops, int xtiles, int vec_store) {
     constexpr int VE = ElemTraits<T>::kVec;
     constexpr int CHUNK = 128 / (int)sizeof(T);  // channels staged per pass (128 B per pixel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) psm_cosine_kernel(const T* __restrict__ l
         const float inv = 1.0f / (float)C;
         T* o = cost + (rowbase + x) * ops + dg * 8;
         const int nd = min(8, D - dg * 8);
-        if (nd == 8) {
+        if (nd == 8 && vec_store) {
             if constexpr (sizeof(T) == 2) {
                 Vec16<T> v;
 #pragma unroll
@@ -199,16 +199,16 @@ extern "C" int vd3d_psm_cosine(const void* left, const void* right, void* cost, 
         return VD3D_EINVAL;
     }
     const int es = dtype == VD3D_BF16 ? 2 : 4;
-    if ((ops * es) % 16 || ((uintptr_t)cost & 15)) { vd3d_set_error("psm_cosine: output slice must be 16-byte aligned"); return VD3D_EINVAL; }
+    const int vec_store = ((ops * es) % 16 == 0) && (((uintptr_t)cost & 15) == 0);
     const int xtiles = (W + XT - 1) / XT;
     const int64_t grid = (int64_t)B * H * xtiles;
     const int lds = (XT + XT + D - 1) * 128;
     if (dtype == VD3D_BF16)
         hipLaunchKernelGGL(psm_cosine_kernel<short>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream,
-                           (const short*)left, (const short*)right, (short*)cost, H, W, C, D, ips, ops, xtiles);
+                           (const short*)left, (const short*)right, (short*)cost, H, W, C, D, ips, ops, xtiles, vec_store);
     else if (dtype == VD3D_F32)
         hipLaunchKernelGGL(psm_cosine_kernel<float>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream,
-                           (const float*)left, (const float*)right, (float*)cost, H, W, C, D, ips, ops, xtiles);
+                           (const float*)left, (const float*)right, (float*)cost, H, W, C, D, ips, ops, xtiles, vec_store);
     else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }
     return vd3d_check_launch("psm_cosine");
 }
