@@ -130,7 +130,7 @@ def main():
     from visualdet3d_amd.utils import synthetic as syn
     model, cfg, sd = build_model(args, device)
     B = args.batch
-    L, R = syn.stereo_pair(B, args.height, args.width, seed=100 + rank)
+    L, R = syn.stereo_pair(B, args.height, args.width, seed=int(os.environ.get('VD3D_BENCH_SEED', '100')) + rank)
     P2, P3 = syn.kitti_calib(args.width, batch=B)
     L, R, P2 = L.to(device), R.to(device), P2.to(device)   # inputs resident in HBM before the timed region
     inputs = (L, R, P2)
@@ -142,11 +142,12 @@ def main():
             static_out = model.forward_device(*inputs)
         torch.cuda.synchronize()
         if not args.no_graph:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                model.forward_device(*inputs)
-            torch.cuda.current_stream().wait_stream(side)
+            if not os.environ.get('VD3D_BENCH_NOSIDE'):
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    model.forward_device(*inputs)
+                torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_out = model.forward_device(*inputs)
@@ -174,8 +175,13 @@ def main():
             count = torch.stack(cnts)
         return count.cpu()                       # the one host sync: detection counts
 
+    dbg = bool(os.environ.get('VD3D_BENCH_DEBUG'))
+    if dbg:
+        print('[bench] captured=%s, entering warmup' % (graph is not None), file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         step()
+    if dbg:
+        print('[bench] warmup done', file=sys.stderr, flush=True)
     if dist:
         td.barrier()
     torch.cuda.synchronize()
@@ -186,6 +192,8 @@ def main():
     if dist:
         td.barrier()
     elapsed = time.perf_counter() - t0
+    if dbg:
+        print('[bench] timed region done %.3f s' % elapsed, file=sys.stderr, flush=True)
     if dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)

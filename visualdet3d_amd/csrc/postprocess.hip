@@ -60,6 +60,13 @@ struct HeadArgs {
     float* out_scores; float* out_boxes; int32_t* out_labels; int32_t* out_anchor; int32_t* out_count;
 };
 
+// counters are cleared by a kernel (not hipMemsetAsync): a memset issued on a capturing stream was observed not to be
+// replayed by the hipGraph on ROCm 7.2, which let the candidate counters accumulate across replays.
+__global__ void zero_counts_kernel(int32_t* c, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = 0;
+}
+
 // ---- stage 1: mask + sigmoid + threshold -> candidate list (unordered, atomics) ----------------------
 __global__ void __launch_bounds__(kSelThreads) head_select_kernel(const HeadArgs p) {
     const int64_t total = (int64_t)p.B * p.N;
@@ -374,7 +381,7 @@ extern "C" int vd3d_head_postprocess(const vd3d_head_params* q, void* stream) {
     a.ws = carve(q->workspace, q->B, q->max_cand);
     a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_labels = q->out_labels; a.out_anchor = q->out_anchor; a.out_count = q->out_count;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(a.ws.count, 0, (size_t)q->B * 4, s) != hipSuccess) return vd3d_check_launch("head_postprocess memset");
+    hipLaunchKernelGGL(zero_counts_kernel, dim3((q->B + 63) / 64), dim3(64), 0, s, a.ws.count, q->B);
     const int64_t total = (int64_t)q->B * q->N;
     int64_t g = (total + kSelThreads - 1) / kSelThreads;
     if (g > 4096) g = 4096;
@@ -399,7 +406,10 @@ extern "C" int vd3d_nms(const float* boxes, const float* scores, int n, float io
     (void)workspace;
     hipStream_t s = (hipStream_t)stream;
     if (!keep || !count || n < 0) { vd3d_set_error("nms: bad args"); return VD3D_EINVAL; }
-    if (n == 0) return hipMemsetAsync(count, 0, 4, s) == hipSuccess ? VD3D_OK : vd3d_check_launch("nms memset");
+    if (n == 0) {
+        hipLaunchKernelGGL(zero_counts_kernel, dim3(1), dim3(64), 0, s, count, 1);
+        return vd3d_check_launch("nms zero");
+    }
     if (!boxes || !scores || ((uintptr_t)boxes & 15) || n > kMaxSort) {
         vd3d_set_error("nms: boxes must be 16-byte aligned and n <= 8192");
         return VD3D_EINVAL;
