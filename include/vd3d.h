@@ -69,6 +69,9 @@ typedef struct vd3d_conv_params {
 } vd3d_conv_params;
 
 int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream);
+/* Tuning hook for tools/bench_conv.py: force a tile configuration (0 = built-in heuristic). Not part of the
+ * drop-in surface. */
+int vd3d_conv2d_set_tuning(int cfg);
 
 /* Stem input packing: NCHW fp32 image -> zero-bordered NHWC4 (3 channels + 1 zero) so that one kernel row of
  * the 7x7/s2 stem (backbones/resnet.py:118, conv1) is 8 px * 4 ch = 32 contiguous elements.

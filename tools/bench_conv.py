@@ -1,0 +1,55 @@
+"""Micro-benchmark of the implicit-GEMM conv tile configurations on the hot layer shapes (MI355X).
+    python tools/bench_conv.py [cfg ids...]"""
+import sys
+import torch
+sys.path.insert(0, '.')
+from visualdet3d_amd import hip_ops as ops, _lib
+
+SHAPES = [  # name, B, H, W, Cin, Cout
+    ('layer1 64->64', 16, 96, 320, 64, 64),
+    ('layer2 128->128', 16, 48, 160, 128, 128),
+    ('layer3 256->256', 16, 24, 80, 256, 256),
+    ('neck 1152->1152', 8, 24, 80, 1152, 1152),
+    ('head 1408->1408', 8, 24, 80, 1408, 1408),
+    ('head 1408->576', 8, 24, 80, 1408, 576),
+    ('head 1408->256', 8, 24, 80, 1408, 256),
+]
+cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+torch.manual_seed(0)
+for name, B, H, W, Cin, Cout in SHAPES:
+    x = torch.randn(B, H, W, Cin, device='cuda').to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda') * (2.0 / (9 * Cin)) ** 0.5
+    pc = ops.pack_conv(w, None, None, torch.bfloat16, 1, 1, 1)
+    res = torch.randn(B, H, W, Cout, device='cuda').to(torch.bfloat16)
+    flops = 2.0 * B * H * W * Cout * 9 * Cin
+    ref = None
+    line = '%-18s' % name
+    for c in cfgs:
+        if Cout <= 64 and c in (1, 2, 3, 4, 7, 8):
+            line += '  cfg%d    --   ' % c
+            continue
+        _lib.lib().vd3d_conv2d_set_tuning(c)
+        try:
+            out = ops.conv2d(x, pc, residual=res, relu=True)
+            torch.cuda.synchronize()
+        except Exception as e:
+            line += '  cfg%d ERR' % c
+            continue
+        if ref is None:
+            ref = out.float()
+            err = 0.0
+        else:
+            err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            ops.conv2d(x, pc, out=out, residual=res, relu=True)
+        s.record()
+        n = 20
+        for _ in range(n):
+            ops.conv2d(x, pc, out=out, residual=res, relu=True)
+        e.record()
+        torch.cuda.synchronize()
+        t = s.elapsed_time(e) / n * 1e-3
+        line += '  cfg%d %6.0f TF%s' % (c, flops / t / 1e12, '' if err < 2e-2 else ' BAD(%.1e)' % err)
+    _lib.lib().vd3d_conv2d_set_tuning(0)
+    print(line, flush=True)

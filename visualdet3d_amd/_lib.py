@@ -47,6 +47,7 @@ SIGNATURES = {
     'vd3d_abi_version': (c_int, []),
     'vd3d_last_error': (C.c_char_p, []),
     'vd3d_conv2d_igemm': (c_int, [C.POINTER(ConvParams), c_void_p]),
+    'vd3d_conv2d_set_tuning': (c_int, [c_int]),
     'vd3d_pack_image_nhwc4': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_maxpool3x3s2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_avgpool2x2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

@@ -63,6 +63,81 @@ template <> struct Mma<float> {
     }
 };
 
+// ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store ------------------------------------------------
+template <typename T, int TM, int TN, int WTM, int WTN>
+VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], int m0, int n0, int wm, int wn, int lr, int half) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WTM + j * 32 + lr;
+        if (m >= p.M) continue;
+        const int64_t obase = (int64_t)m * p.out_pix_stride;
+        const int64_t rbase = (int64_t)m * p.res_pix_stride;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = n0 + wn * WTN + i * 32 + 8 * g + 4 * half;
+                if (nb >= p.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (p.vec_epilogue) {
+                    if (p.scale) {
+                        const f32x4 s = *(const f32x4*)(p.scale + nb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= s[e];
+                    }
+                    if (p.shift) {
+                        const f32x4 s = *(const f32x4*)(p.shift + nb);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += s[e];
+                    }
+                    if (p.residual) {
+                        if constexpr (sizeof(T) == 2) {
+                            const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
+                            const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
+                            v[0] += i2f((int)(r0 << 16));
+                            v[1] += i2f((int)(r0 & 0xffff0000u));
+                            v[2] += i2f((int)(r1 << 16));
+                            v[3] += i2f((int)(r1 & 0xffff0000u));
+                        } else {
+                            const f32x4 rr = *(const f32x4*)(p.residual + (rbase + nb) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    if (sizeof(T) == 4 || p.out_f32) {
+                        f32x4 o = {v[0], v[1], v[2], v[3]};
+                        *(f32x4*)(p.out + (obase + nb) * 4) = o;
+                    } else {
+                        i32x2 o;
+                        o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+                        o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                        *(i32x2*)(p.out + (obase + nb) * 2) = o;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int n = nb + e;
+                        if (n >= p.Cout) break;
+                        float x = v[e];
+                        if (p.scale) x *= p.scale[n];
+                        if (p.shift) x += p.shift[n];
+                        if (p.residual) x += ElemTraits<T>::to_f(((const T*)p.residual)[rbase + n]);
+                        if (p.relu) x = fmaxf(x, 0.f);
+                        if (sizeof(T) == 4 || p.out_f32) ((float*)p.out)[obase + n] = x;
+                        else ((short*)p.out)[obase + n] = f2bf(x);
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
@@ -202,87 +277,151 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
         __syncthreads();
     }
 
-    // ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store ---------------------------------------
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * WTM + j * 32 + lr;
-        if (m >= p.M) continue;
-        const int64_t obase = (int64_t)m * p.out_pix_stride;
-        const int64_t rbase = (int64_t)m * p.res_pix_stride;
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = n0 + wn * WTN + i * 32 + 8 * g + 4 * half;
-                if (nb >= p.Cout) continue;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (p.vec_epilogue) {
-                    if (p.scale) {
-                        const f32x4 s = *(const f32x4*)(p.scale + nb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= s[e];
-                    }
-                    if (p.shift) {
-                        const f32x4 s = *(const f32x4*)(p.shift + nb);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += s[e];
-                    }
-                    if (p.residual) {
-                        if constexpr (sizeof(T) == 2) {
-                            const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
-                            const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
-                            v[0] += i2f((int)(r0 << 16));
-                            v[1] += i2f((int)(r0 & 0xffff0000u));
-                            v[2] += i2f((int)(r1 << 16));
-                            v[3] += i2f((int)(r1 & 0xffff0000u));
-                        } else {
-                            const f32x4 rr = *(const f32x4*)(p.residual + (rbase + nb) * 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += rr[e];
-                        }
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (sizeof(T) == 4 || p.out_f32) {
-                        f32x4 o = {v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(p.out + (obase + nb) * 4) = o;
-                    } else {
-                        i32x2 o;
-                        o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-                        o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
-                        *(i32x2*)(p.out + (obase + nb) * 2) = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int n = nb + e;
-                        if (n >= p.Cout) break;
-                        float x = v[e];
-                        if (p.scale) x *= p.scale[n];
-                        if (p.shift) x += p.shift[n];
-                        if (p.residual) x += ElemTraits<T>::to_f(((const T*)p.residual)[rbase + n]);
-                        if (p.relu) x = fmaxf(x, 0.f);
-                        if (sizeof(T) == 4 || p.out_f32) ((float*)p.out)[obase + n] = x;
-                        else ((short*)p.out)[obase + n] = f2bf(x);
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lr, half);
 }
 
+// =====================================================================================================
+// v2: same tile math, but both operand tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds): no VGPR
+// staging, no ds_write pass.  An LDS-DMA instruction writes wave-uniform-base + lane*16, i.e. the LDS image is
+// lane-linear: piece j (1 KiB = 8 rows x 128 B) is written by one wave instruction, lane L landing on
+// (row 8j + L/8, physical slot L%8).  The XOR swizzle therefore moves to the SOURCE address: lane L fetches the
+// logical slot (L%8) ^ ((row/2)%8) of its row -- the same 128 contiguous bytes per row, permuted among 8 lanes, so
+// global coalescing is unchanged and the fragment reads keep the conflict-free swizzled addressing.
+// Zero padding still comes from the SRD bounds check (out-of-range lanes write zeros into LDS).
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
+    constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VE = 16 / ES;
+    constexpr int BKE = 128 / ES;
+    constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int A_PIECES = BM / 8 / NW, W_PIECES = BN / 8 / NW;  // per wave
+    constexpr int A_STAGE = BM * 128, STAGE = (BM + BN) * 128;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly into 8-row pieces per wave");
+    static_assert((8 * NW) % 16 == 0, "piece stride must keep the swizzle phase constant");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+
+    // ---- loader state: lane -> (row within piece, logical 16-byte slot) ---------------------------------
+    const int prow = lane >> 3;
+    const int slot = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);  // = (L%8) ^ ((row/2)%8), constant over pieces
+    int a_off[A_PIECES], a_iy[A_PIECES], a_ix[A_PIECES];
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int it = 0; it < A_PIECES; ++it) {
+        const int m = m0 + 8 * (wave + it * NW) + prow;
+        if (m < p.M) {
+            const int b = m / HoWo, rem = m - b * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_iy[it] = oy * p.stride - p.pad;
+            a_ix[it] = ox * p.stride - p.pad;
+            a_off[it] = (int)(b * p.in_batch_stride) + a_iy[it] * p.in_row_stride + a_ix[it] * p.in_pix_stride;
+        } else {
+            a_iy[it] = -(1 << 28);
+            a_ix[it] = 0;
+            a_off[it] = 0;
+        }
+    }
+    int kc = slot * VE, tap = 0, dy = 0, dx = 0;
+    while (kc >= p.Cin) {
+        kc -= p.Cin;
+        ++tap;
+        if (++dx == p.kw) { dx = 0; ++dy; }
+    }
+    uint32_t w_off = (uint32_t)(((n0 + 8 * wave + prow) * p.Kpad + slot * VE) * ES);
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.weight, 0, p.w_bytes, 0x00020000);
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto issue_tile = [&](int st) {
+        char* base = smem + st * STAGE + wave * 1024;
+        const bool kvalid = tap < p.ntaps;
+        const int ddy = dy * p.dil, ddx = dx * p.dil;
+        const int tap_off = ddy * p.in_row_stride + ddx * p.in_pix_stride + kc;
+#pragma unroll
+        for (int it = 0; it < A_PIECES; ++it) {
+            const bool v = kvalid && (unsigned)(a_iy[it] + ddy) < (unsigned)p.H && (unsigned)(a_ix[it] + ddx) < (unsigned)p.W;
+            const uint32_t off = v ? (uint32_t)(a_off[it] + tap_off) * ES : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + it * NW * 1024), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < W_PIECES; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + A_STAGE + it * NW * 1024), 16,
+                                                     w_off + (uint32_t)(it * NW * 8 * p.Kpad * ES), 0, 0, 0);
+        w_off += BKE * ES;
+        kc += BKE;
+        while (kc >= p.Cin) {
+            kc -= p.Cin;
+            ++tap;
+            if (++dx == p.kw) { dx = 0; ++dy; }
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, half = lane >> 5;
+    auto compute = [&](int st) {
+        const char* As = smem + st * STAGE;
+        const char* Ws = As + A_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int sk = 2 * ks + half;
+            i32x4 fa[TN], fb[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int row = wn * WTN + i * 32 + lr;
+                fa[i] = *(const i32x4*)(Ws + row * 128 + ((sk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = wm * WTM + j * 32 + lr;
+                fb[j] = *(const i32x4*)(As + row * 128 + ((sk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    issue_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < p.nk; ++kt) {
+        if (kt + 1 < p.nk) issue_tile((kt + 1) & 1);   // DMA of slice k+1 overlaps the MFMAs of slice k
+        compute(kt & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lr, half);
+}
+
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static bool attr_done = false;
-    auto kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
+    auto kern = DMA ? conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N> : conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
             return vd3d_check_launch("hipFuncSetAttribute(conv_igemm)");
@@ -294,14 +433,43 @@ int launch(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_igemm");
 }
 
+// tuning override (tools/bench_conv.py): 0 = heuristic, otherwise a config id
+static int g_force_cfg = 0;
+
 template <typename T>
 int dispatch(ConvArgs& a, hipStream_t stream) {
-    if (a.Cout <= 32) return launch<T, 256, 32, 4, 1>(a, stream);
-    if (a.Cout <= 64) return launch<T, 256, 64, 4, 1>(a, stream);
-    return launch<T, 128, 128, 2, 2>(a, stream);
+    switch (g_force_cfg) {
+        case 1: return launch<T, 128, 128, 2, 2>(a, stream);
+        case 2: return launch<T, 128, 128, 2, 2, true>(a, stream);
+        case 3: return launch<T, 256, 128, 2, 2, true>(a, stream);
+        case 4: return launch<T, 256, 128, 4, 2, true>(a, stream);
+        case 5: return launch<T, 256, 64, 4, 1, true>(a, stream);
+        case 6: return launch<T, 256, 64, 4, 1>(a, stream);
+        case 7: return launch<T, 128, 256, 2, 2, true>(a, stream);
+        case 8: return launch<T, 256, 256, 2, 4, true>(a, stream);
+        default: break;
+    }
+    if (a.Cout <= 32) return launch<T, 256, 32, 4, 1, true>(a, stream);
+    if (a.Cout <= 64) return launch<T, 256, 64, 4, 1, true>(a, stream);
+    // 128x128 (2 workgroups / CU) vs 256x256 (1 / CU): pick by modelled throughput = full-occupancy rate of the
+    // tile shape (measured on MI355X: ~970 vs ~1350 TFLOP/s bf16) x tile-edge waste x last-round occupancy.
+    auto util = [&](int bm, int bn, int slots) {
+        const double tm = (a.M + bm - 1) / bm, tn = (a.Cout + bn - 1) / bn;
+        const double tiles = tm * tn;
+        const double rounds = (double)((int64_t)((tiles + slots - 1) / slots));
+        return ((double)a.M * a.Cout) / (tm * bm * tn * bn) * tiles / (rounds * slots);
+    };
+    const double r128 = 970.0 * util(128, 128, 512), r256 = 1350.0 * util(256, 256, 256);
+    if (r256 > r128) return launch<T, 256, 256, 2, 4, true>(a, stream);
+    return launch<T, 128, 128, 2, 2, true>(a, stream);
 }
 
 }  // namespace
+
+extern "C" int vd3d_conv2d_set_tuning(int cfg) {
+    g_force_cfg = cfg;
+    return VD3D_OK;
+}
 
 extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
     if (!p || !p->in || !p->weight || !p->out) { vd3d_set_error("conv2d_igemm: null pointer"); return VD3D_EINVAL; }
