@@ -168,15 +168,31 @@ int vd3d_nms_bev(const float* boxes, int n, float thr, int normal, int32_t* keep
 int64_t vd3d_nms_bev_workspace_bytes(int n);
 
 /* ------------------------------------------------------------------------------------------------
- * Deformable convolution forward (lib/ops/dcn/src/deform_conv_ext.cpp:149-163; kernels
- * deform_conv_cuda_kernel.cu:190-243 (v1), :570-633 (v2)).  NCHW fp32 in/out exactly like the reference
- * extension; the bilinear-sampled columns are never materialised in HBM.
- *   input [B][C][H][W], offset [B][dg*2*kh*kw][Ho][Wo] (y,x interleaved per tap), mask [B][dg*kh*kw][Ho][Wo]
- *   (NULL => DCNv1), weight [O][C/g][kh][kw], bias [O] or NULL, output [B][O][Ho][Wo]. */
+ * Deformable convolution forward, v1 (mask == NULL) and v2 / modulated
+ * (lib/ops/dcn/src/deform_conv_ext.cpp:149-163; host deform_conv_cuda.cpp:152-260,491-570; kernels
+ * deform_conv_cuda_kernel.cu:190-243, :570-633).  The bilinear-sampled columns are never materialised in HBM.
+ *
+ * vd3d_deform_conv_forward: the reference extension's tensors, NCHW fp32 contiguous:
+ *   input [B][C][H][W], offset [B][dg*2*kh*kw][Ho][Wo] (y,x interleaved per tap), mask [B][dg*kh*kw][Ho][Wo] or NULL,
+ *   weight [O][C/g][kh][kw], bias [O] or NULL, output [B][O][Ho][Wo];  workspace: vd3d_deform_conv_workspace_bytes. */
+int64_t vd3d_deform_conv_workspace_bytes(int O, int C, int groups, int kh, int kw);
 int vd3d_deform_conv_forward(const float* input, const float* weight, const float* bias, const float* offset,
-                             const float* mask, float* output, int B, int C, int H, int W, int O,
+                             const float* mask, float* output, void* workspace, int B, int C, int H, int W, int O,
                              int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
                              int dil_h, int dil_w, int groups, int deformable_groups, void* stream);
+
+/* General form used by the engine: any layout through element strides {batch, channel, y, x}, bf16 or fp32
+ * activations, pre-packed weight (vd3d_dcn_pack_weight: [O][Kpad], K = tap*C/g + c), fused epilogue
+ * y = relu?((acc + bias) * scale + shift), optional in-kernel sigmoid of the modulation logits. */
+typedef struct vd3d_dcn_params {
+    const void* in; const void* weight; const float* bias; const float* scale; const float* shift;
+    const float* offset; const float* mask; void* out;
+    int32_t B, C, H, W, O, kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int32_t groups, deformable_groups, Kpad, dtype, mask_sigmoid, relu;
+    int64_t in_strides[4], offset_strides[4], mask_strides[4], out_strides[4];
+} vd3d_dcn_params;
+int vd3d_dcn_pack_weight(const float* w_oihw, void* packed, int O, int Cg, int kh, int kw, int Kpad, int dtype, void* stream);
+int vd3d_deform_conv(const vd3d_dcn_params* p, void* stream);
 
 /* LookGround sampling (lib/look_ground.py:44-69): builds [prior disparity; x] and bilinear-samples it
  * (grid_sample, border padding, align_corners=True) at (x, y + y_shift).  NHWC.

@@ -29,6 +29,20 @@ class ConvParams(C.Structure):
     ]
 
 
+class DcnParams(C.Structure):
+    _fields_ = [
+        ('in_', c_void_p), ('weight', c_void_p), ('bias', c_void_p), ('scale', c_void_p), ('shift', c_void_p),
+        ('offset', c_void_p), ('mask', c_void_p), ('out', c_void_p),
+        ('B', C.c_int32), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('O', C.c_int32),
+        ('kh', C.c_int32), ('kw', C.c_int32), ('stride_h', C.c_int32), ('stride_w', C.c_int32),
+        ('pad_h', C.c_int32), ('pad_w', C.c_int32), ('dil_h', C.c_int32), ('dil_w', C.c_int32),
+        ('groups', C.c_int32), ('deformable_groups', C.c_int32), ('Kpad', C.c_int32), ('dtype', C.c_int32),
+        ('mask_sigmoid', C.c_int32), ('relu', C.c_int32),
+        ('in_strides', C.c_int64 * 4), ('offset_strides', C.c_int64 * 4), ('mask_strides', C.c_int64 * 4),
+        ('out_strides', C.c_int64 * 4),
+    ]
+
+
 class HeadParams(C.Structure):
     _fields_ = [
         ('cls', c_void_p), ('reg', c_void_p), ('anchors', c_void_p), ('prior_mean_std', c_void_p), ('P2', c_void_p),
@@ -62,14 +76,17 @@ SIGNATURES = {
     'vd3d_head_postprocess': (c_int, [C.POINTER(HeadParams), c_void_p]),
     'vd3d_nms': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vd3d_nms_workspace_bytes': (c_int64, [c_int]),
-}
-# declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)
-PENDING = {
     'vd3d_boxes_overlap_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'vd3d_boxes_iou_bev': (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'vd3d_nms_bev': (c_int, [c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vd3d_nms_bev_workspace_bytes': (c_int64, [c_int]),
-    'vd3d_deform_conv_forward': (c_int, [c_void_p] * 6 + [c_int] * 15 + [c_void_p]),
+    'vd3d_deform_conv_workspace_bytes': (c_int64, [c_int] * 5),
+    'vd3d_deform_conv_forward': (c_int, [c_void_p] * 7 + [c_int] * 15 + [c_void_p]),
+    'vd3d_dcn_pack_weight': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    'vd3d_deform_conv': (c_int, [C.POINTER(DcnParams), c_void_p]),
+}
+# declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)
+PENDING = {
     'vd3d_look_ground_sample': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_int, c_void_p]),
 }
 

@@ -1,0 +1,299 @@
+// deform_conv.hip -- deformable convolution v1 / v2 (modulated) forward for gfx950.
+//
+// Replaces deform_conv_ext.{deform_conv_forward, modulated_deform_conv_forward}
+// (lib/ops/dcn/src/deform_conv_ext.cpp:149-163; host deform_conv_cuda.cpp:152-260,491-570; kernels
+// deform_conv_cuda_kernel.cu:190-243 (v1 im2col), :570-633 (v2 im2col), bilinear :84-115 / :467-497).
+// The reference materialises `columns` (C*kh*kw x Ho*Wo fp32 per image) in HBM, then calls a GEMM per image and per
+// group.  Here the bilinear-sampled (and mask-modulated) column tile is produced straight into LDS and consumed by
+// MFMA in the same workgroup: columns never touch HBM, one launch covers the whole batch, bias / folded BN / ReLU are
+// applied in the epilogue.
+//
+//   out[b,o,y,x] = bias[o] + sum_{tap,c} W[o,c,tap] * m[b,tap,y,x] * bilinear(in[b,c], y*s - p + ty*d + dy, x*s - p + tx*d + dx)
+//   a sample is taken iff -1 < h < H and -1 < w < W; corners outside the image contribute 0 (exactly the reference).
+//
+// Tensors are addressed through element strides, so the same kernel serves the reference's NCHW fp32 extension ABI
+// and the engine's NHWC bf16/fp32 activations.  K is ordered tap-major (k = tap*Cg + c): one K slice is one tap x a
+// run of channels, so the sampling geometry (4 corner offsets + 4 weights) is computed once per (pixel, tap) and reused
+// for the whole channel run.  fp32: v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA chains); bf16: v_mfma_f32_32x32x16_bf16.
+#pragma clang fp contract(off)
+#include "common.h"
+
+namespace {
+
+struct DcnArgs {
+    const void* in; const void* w; const float* bias; const float* scale; const float* shift;
+    const float* offset; const float* mask; void* out;
+    int B, C, H, W, O, Ho, Wo;
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    int groups, dgroups, Cg, Og, Kg, Kpad;   // per-group channels, K = kh*kw*Cg, padded K of the packed weight rows
+    int64_t in_sb, in_sc, in_sy, in_sx;      // element strides
+    int64_t off_sb, off_sc, off_sy, off_sx;
+    int64_t msk_sb, msk_sc, msk_sy, msk_sx;
+    int64_t out_sb, out_sc, out_sy, out_sx;
+    int mask_sigmoid, relu;
+};
+
+template <typename T> VD3D_DEV float ld(const void* p, int64_t i);
+template <> VD3D_DEV float ld<float>(const void* p, int64_t i) { return ((const float*)p)[i]; }
+template <> VD3D_DEV float ld<short>(const void* p, int64_t i) { return bf2f(((const short*)p)[i]); }
+template <typename T> VD3D_DEV void st(void* p, int64_t i, float v);
+template <> VD3D_DEV void st<float>(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
+template <> VD3D_DEV void st<short>(void* p, int64_t i, float v) { ((short*)p)[i] = f2bf(v); }
+
+template <typename T> struct DMma;
+template <> struct DMma<short> {
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+template <> struct DMma<float> {
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int aj = a[j], bj = b[j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(i2f(aj), i2f(bj), acc, 0, 0, 0);
+        }
+    }
+};
+
+struct Sample {  // bilinear geometry of one (pixel, tap)
+    int64_t o1, o2, o3, o4;   // element offsets of the 4 corners inside one channel plane
+    float w1, w2, w3, w4;     // hh*hw, hh*lw, lh*hw, lh*lw -- zeroed for corners outside the image
+    float m;                  // modulation (1 for DCNv1); 0 when the sample point itself is out of range
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) dcn_kernel(const DcnArgs p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VE = 16 / ES, BKE = 128 / ES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 64 * 128];
+    char* Cs = smem;             // sampled columns  [64 pixels][128 B]
+    char* Ws = smem + 64 * 128;  // weights          [64 out-channels][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z;
+    const int o0 = blockIdx.y * 64;
+    const int grp = o0 / p.Og;           // conv group of this tile (host guarantees a tile never straddles groups)
+    const int HoWo = p.Ho * p.Wo;
+    const int pix0 = blockIdx.x * 64;
+    const int KK = p.kh * p.kw;
+
+    // this thread samples pixel (tid & 63), vectors (tid >> 6) and (tid >> 6) + 4 of each K slice
+    const int mypix = pix0 + (tid & 63);
+    const bool pvalid = mypix < HoWo;
+    const int ho = pvalid ? mypix / p.Wo : 0, wo = pvalid ? mypix - (mypix / p.Wo) * p.Wo : 0;
+    const int h_in = ho * p.sh - p.ph, w_in = wo * p.sw - p.pw;
+    const int srow = tid & 63;
+
+    auto geometry = [&](int tap, int dgi) {
+        Sample s;
+        s.o1 = s.o2 = s.o3 = s.o4 = 0;
+        s.w1 = s.w2 = s.w3 = s.w4 = 0.f;
+        s.m = 0.f;
+        if (!pvalid) return s;
+        const int ti = tap / p.kw, tj = tap - ti * p.kw;
+        const int64_t ob = b * p.off_sb + ho * p.off_sy + wo * p.off_sx;
+        const float off_h = p.offset[ob + (int64_t)(dgi * 2 * KK + 2 * tap) * p.off_sc];
+        const float off_w = p.offset[ob + (int64_t)(dgi * 2 * KK + 2 * tap + 1) * p.off_sc];
+        float m = 1.f;
+        if (p.mask) {
+            m = p.mask[b * p.msk_sb + ho * p.msk_sy + wo * p.msk_sx + (int64_t)(dgi * KK + tap) * p.msk_sc];
+            if (p.mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
+        }
+        const float h_im = (float)(h_in + ti * p.dh) + off_h;
+        const float w_im = (float)(w_in + tj * p.dw) + off_w;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
+            if (t_ok && l_ok) { s.w1 = hh * hw; s.o1 = h_low * p.in_sy + w_low * p.in_sx; }
+            if (t_ok && r_ok) { s.w2 = hh * lw; s.o2 = h_low * p.in_sy + w_high * p.in_sx; }
+            if (b_ok && l_ok) { s.w3 = lh * hw; s.o3 = h_high * p.in_sy + w_low * p.in_sx; }
+            if (b_ok && r_ok) { s.w4 = lh * lw; s.o4 = h_high * p.in_sy + w_high * p.in_sx; }
+            s.m = m;
+        }
+        return s;
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int wn = wave & 1, wm = wave >> 1;     // 2 x 2 waves over (out-channels, pixels)
+    const int lr = lane & 31, half = lane >> 5;
+    const int cpd = p.C / p.dgroups;             // channels per deformable group
+
+    const int nk = (p.Kg + BKE - 1) / BKE;
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- sampled column tile -> LDS -------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int vec = (tid >> 6) + 4 * i;
+            const int k0 = kt * BKE + vec * VE;
+            float vals[VE];
+#pragma unroll
+            for (int e = 0; e < VE; ++e) vals[e] = 0.f;
+            if (k0 < p.Kg) {
+                int tap = k0 / p.Cg, c = k0 - tap * p.Cg;
+                int cabs = grp * p.Cg + c;
+                Sample s = geometry(tap, cabs / cpd);
+                int cur_dg = cabs / cpd;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    if (k0 + e < p.Kg) {
+                        if (c >= p.Cg) {            // vector crosses into the next tap
+                            c = 0; ++tap; cabs = grp * p.Cg;
+                            s = geometry(tap, cabs / cpd); cur_dg = cabs / cpd;
+                        } else if (cabs / cpd != cur_dg) {
+                            cur_dg = cabs / cpd; s = geometry(tap, cur_dg);
+                        }
+                        const int64_t base = b * p.in_sb + (int64_t)cabs * p.in_sc;
+                        const float v1 = s.w1 != 0.f ? ld<T>(p.in, base + s.o1) : 0.f;
+                        const float v2 = s.w2 != 0.f ? ld<T>(p.in, base + s.o2) : 0.f;
+                        const float v3 = s.w3 != 0.f ? ld<T>(p.in, base + s.o3) : 0.f;
+                        const float v4 = s.w4 != 0.f ? ld<T>(p.in, base + s.o4) : 0.f;
+                        const float val = s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4;
+                        vals[e] = val * s.m;
+                        ++c; ++cabs;
+                    }
+                }
+            }
+            Vec16<T> o;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set(e, vals[e]);
+            }
+            *(i32x4*)(Cs + srow * 128 + ((vec ^ ((srow >> 1) & 7)) << 4)) = o.raw;
+        }
+        // ---- weight tile -> LDS (packed [O][Kpad], tap-major K) --------------------------------------------
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i;
+            const int row = v >> 3, slot = v & 7;
+            i32x4 wv = {0, 0, 0, 0};
+            if (o0 + row < p.O) wv = *(const i32x4*)((const char*)p.w + ((int64_t)(o0 + row) * p.Kpad + kt * BKE + slot * VE) * ES);
+            *(i32x4*)(Ws + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = wv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int sk = 2 * ks + half;
+            const int rw = wn * 32 + lr, rc = wm * 32 + lr;
+            const i32x4 fa = *(const i32x4*)(Ws + rw * 128 + ((sk ^ ((rw >> 1) & 7)) << 4));
+            const i32x4 fb = *(const i32x4*)(Cs + rc * 128 + ((sk ^ ((rc >> 1) & 7)) << 4));
+            DMma<T>::run(fa, fb, acc);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, optional folded BN, ReLU; strided store ------------------------------------------
+    const int pix = pix0 + wm * 32 + lr;
+    if (pix >= HoWo) return;
+    const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+    const int64_t ob = b * p.out_sb + oy * p.out_sy + ox * p.out_sx;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = o0 + wn * 32 + 8 * g + 4 * half + e;
+            if (o >= p.O) continue;
+            float v = acc[4 * g + e];
+            if (p.bias) v += p.bias[o];
+            if (p.scale) v = v * p.scale[o];
+            if (p.shift) v = v + p.shift[o];
+            if (p.relu) v = fmaxf(v, 0.f);
+            st<T>(p.out, ob + (int64_t)o * p.out_sc, v);
+        }
+}
+
+int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
+    if (!q || !q->in || !q->weight || !q->offset || !q->out) { vd3d_set_error("deform_conv: null pointer"); return VD3D_EINVAL; }
+    if (q->dtype != VD3D_BF16 && q->dtype != VD3D_F32) { vd3d_set_error("deform_conv: bad dtype"); return VD3D_EINVAL; }
+    if (q->groups < 1 || q->deformable_groups < 1 || q->C % q->groups || q->O % q->groups || q->C % q->deformable_groups) {
+        vd3d_set_error("deform_conv: channels must divide by groups / deformable_groups");
+        return VD3D_EINVAL;
+    }
+    const int Og = q->O / q->groups;
+    if (q->groups > 1 && Og % 64) { vd3d_set_error("deform_conv: groups > 1 needs out-channels per group to be a multiple of 64"); return VD3D_EINVAL; }
+    const int es = q->dtype == VD3D_BF16 ? 2 : 4, bke = 128 / es;
+    DcnArgs a;
+    a.in = q->in; a.w = q->weight; a.bias = q->bias; a.scale = q->scale; a.shift = q->shift; a.offset = q->offset; a.mask = q->mask; a.out = q->out;
+    a.B = q->B; a.C = q->C; a.H = q->H; a.W = q->W; a.O = q->O;
+    a.kh = q->kh; a.kw = q->kw; a.sh = q->stride_h; a.sw = q->stride_w; a.ph = q->pad_h; a.pw = q->pad_w; a.dh = q->dil_h; a.dw = q->dil_w;
+    a.Ho = (q->H + 2 * q->pad_h - (q->dil_h * (q->kh - 1) + 1)) / q->stride_h + 1;
+    a.Wo = (q->W + 2 * q->pad_w - (q->dil_w * (q->kw - 1) + 1)) / q->stride_w + 1;
+    a.groups = q->groups; a.dgroups = q->deformable_groups; a.Cg = q->C / q->groups; a.Og = Og;
+    a.Kg = q->kh * q->kw * a.Cg; a.Kpad = q->Kpad;
+    if (a.Kpad % bke || a.Kpad < a.Kg || ((uintptr_t)q->weight & 15)) { vd3d_set_error("deform_conv: packed weight padding / alignment"); return VD3D_EINVAL; }
+    a.in_sb = q->in_strides[0]; a.in_sc = q->in_strides[1]; a.in_sy = q->in_strides[2]; a.in_sx = q->in_strides[3];
+    a.off_sb = q->offset_strides[0]; a.off_sc = q->offset_strides[1]; a.off_sy = q->offset_strides[2]; a.off_sx = q->offset_strides[3];
+    a.msk_sb = q->mask_strides[0]; a.msk_sc = q->mask_strides[1]; a.msk_sy = q->mask_strides[2]; a.msk_sx = q->mask_strides[3];
+    a.out_sb = q->out_strides[0]; a.out_sc = q->out_strides[1]; a.out_sy = q->out_strides[2]; a.out_sx = q->out_strides[3];
+    a.mask_sigmoid = q->mask_sigmoid; a.relu = q->relu;
+    if (a.Ho <= 0 || a.Wo <= 0 || q->B <= 0) { vd3d_set_error("deform_conv: empty output"); return VD3D_EINVAL; }
+    dim3 grid((a.Ho * a.Wo + 63) / 64, (q->O + 63) / 64, q->B);
+    if (q->dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_kernel<short>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(dcn_kernel<float>, grid, dim3(256), 0, s, a);
+    return vd3d_check_launch("deform_conv");
+}
+
+// OIHW fp32 -> packed [O][Kpad] (tap-major K) in the compute dtype
+template <typename T>
+__global__ void dcn_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int Cg, int KK, int Kpad) {
+    const int64_t total = (int64_t)O * Kpad;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kpad), o = (int)(i / Kpad);
+        float v = 0.f;
+        if (k < KK * Cg) {
+            const int tap = k / Cg, c = k - tap * Cg;
+            v = w[((int64_t)o * Cg + c) * KK + tap];
+        }
+        out[i] = ElemTraits<T>::from_f(v);
+    }
+}
+
+}  // namespace
+
+extern "C" int vd3d_dcn_pack_weight(const float* w_oihw, void* packed, int O, int Cg, int kh, int kw, int Kpad, int dtype, void* stream) {
+    if (!w_oihw || !packed) { vd3d_set_error("dcn_pack_weight: null pointer"); return VD3D_EINVAL; }
+    const int64_t total = (int64_t)O * Kpad;
+    const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_pack_weight_kernel<short>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (short*)packed, O, Cg, kh * kw, Kpad);
+    else if (dtype == VD3D_F32) hipLaunchKernelGGL(dcn_pack_weight_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)packed, O, Cg, kh * kw, Kpad);
+    else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }
+    return vd3d_check_launch("dcn_pack_weight");
+}
+
+extern "C" int vd3d_deform_conv(const vd3d_dcn_params* p, void* stream) { return launch_dcn(p, (hipStream_t)stream); }
+
+extern "C" int64_t vd3d_deform_conv_workspace_bytes(int O, int C, int groups, int kh, int kw) {
+    const int Kg = kh * kw * (C / (groups > 0 ? groups : 1));
+    return (int64_t)O * ((Kg + 31) / 32 * 32) * 4 + 256;
+}
+
+extern "C" int vd3d_deform_conv_forward(const float* input, const float* weight, const float* bias, const float* offset,
+                                        const float* mask, float* output, void* workspace, int B, int C, int H, int W, int O,
+                                        int kh, int kw, int stride_h, int stride_w, int pad_h, int pad_w,
+                                        int dil_h, int dil_w, int groups, int deformable_groups, void* stream) {
+    if (!workspace || groups < 1 || C % groups) { vd3d_set_error("deform_conv_forward: bad workspace / groups"); return VD3D_EINVAL; }
+    const int Cg = C / groups, Kpad = (kh * kw * Cg + 31) / 32 * 32;
+    int rc = vd3d_dcn_pack_weight(weight, workspace, O, Cg, kh, kw, Kpad, VD3D_F32, stream);
+    if (rc) return rc;
+    vd3d_dcn_params q;
+    q.in = input; q.weight = workspace; q.bias = bias; q.scale = nullptr; q.shift = nullptr; q.offset = offset; q.mask = mask; q.out = output;
+    q.B = B; q.C = C; q.H = H; q.W = W; q.O = O; q.kh = kh; q.kw = kw;
+    q.stride_h = stride_h; q.stride_w = stride_w; q.pad_h = pad_h; q.pad_w = pad_w; q.dil_h = dil_h; q.dil_w = dil_w;
+    q.groups = groups; q.deformable_groups = deformable_groups; q.Kpad = Kpad; q.dtype = VD3D_F32; q.mask_sigmoid = 0; q.relu = 0;
+    const int Ho = (H + 2 * pad_h - (dil_h * (kh - 1) + 1)) / stride_h + 1, Wo = (W + 2 * pad_w - (dil_w * (kw - 1) + 1)) / stride_w + 1;
+    const int KK = kh * kw;
+    // NCHW contiguous, exactly the reference extension's tensors
+    q.in_strides[0] = (int64_t)C * H * W; q.in_strides[1] = (int64_t)H * W; q.in_strides[2] = W; q.in_strides[3] = 1;
+    q.offset_strides[0] = (int64_t)deformable_groups * 2 * KK * Ho * Wo; q.offset_strides[1] = (int64_t)Ho * Wo; q.offset_strides[2] = Wo; q.offset_strides[3] = 1;
+    q.mask_strides[0] = (int64_t)deformable_groups * KK * Ho * Wo; q.mask_strides[1] = (int64_t)Ho * Wo; q.mask_strides[2] = Wo; q.mask_strides[3] = 1;
+    q.out_strides[0] = (int64_t)O * Ho * Wo; q.out_strides[1] = (int64_t)Ho * Wo; q.out_strides[2] = Wo; q.out_strides[3] = 1;
+    return launch_dcn(&q, (hipStream_t)stream);
+}

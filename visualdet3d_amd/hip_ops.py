@@ -357,3 +357,79 @@ def nms(boxes, scores, iou_threshold):
     check(_lib.lib().vd3d_nms(_p(boxes), _p(scores), n, float(iou_threshold), _p(keep), _p(count), None, _stream()), 'vd3d_nms')
     k = int(count.item())
     return keep[:k].long()
+
+
+# --------------------------------------------------------------------------------------------- deformable conv
+class PackedDCN:
+    def __init__(self, w, Kpad, O, Cg, kh, kw, dtype):
+        self.w, self.Kpad, self.O, self.Cg, self.kh, self.kw, self.dtype = w, Kpad, O, Cg, kh, kw, dtype
+
+
+def pack_dcn_weight(weight, dtype):
+    """OIHW fp32 -> [O][Kpad] tap-major in ``dtype`` (device kernel)."""
+    _require_cuda(weight)
+    O, Cg, kh, kw = weight.shape
+    bke = 64 if dtype == torch.bfloat16 else 32
+    Kpad = (kh * kw * Cg + bke - 1) // bke * bke
+    w = weight.detach().float().contiguous()
+    packed = torch.empty((O, Kpad), dtype=dtype, device=weight.device)
+    check(_lib.lib().vd3d_dcn_pack_weight(_p(w), _p(packed), O, Cg, kh, kw, Kpad, dtype_code(dtype), _stream()), 'vd3d_dcn_pack_weight')
+    return PackedDCN(packed, Kpad, O, Cg, kh, kw, dtype)
+
+
+def _strides4(t, layout):
+    """element strides {batch, channel, y, x} of a 4-D tensor given its logical layout ('nchw' or 'nhwc')."""
+    if layout == 'nchw':
+        return (t.stride(0), t.stride(1), t.stride(2), t.stride(3))
+    return (t.stride(0), t.stride(3), t.stride(1), t.stride(2))
+
+
+def deform_conv_general(x, pd, offset, mask, out, layout, bias=None, scale=None, shift=None, stride=(1, 1), padding=(0, 0),
+                        dilation=(1, 1), groups=1, deformable_groups=1, mask_sigmoid=False, relu=False,
+                        offset_layout=None, mask_layout=None):
+    """vd3d_deform_conv on tensors of either layout.  x/out: activations (bf16|fp32, same dtype as the packed weight);
+    offset/mask: fp32."""
+    _require_cuda(x, offset, out)
+    from ._lib import DcnParams
+    if layout == 'nchw':
+        B, Cc, H, W = x.shape
+    else:
+        B, H, W, Cc = x.shape
+    assert x.dtype == pd.dtype == out.dtype and offset.dtype == torch.float32 and (mask is None or mask.dtype == torch.float32)
+    p = DcnParams()
+    p.in_, p.weight, p.out, p.offset = x.data_ptr(), pd.w.data_ptr(), out.data_ptr(), offset.data_ptr()
+    p.bias = bias.data_ptr() if bias is not None else None
+    p.scale = scale.data_ptr() if scale is not None else None
+    p.shift = shift.data_ptr() if shift is not None else None
+    p.mask = mask.data_ptr() if mask is not None else None
+    p.B, p.C, p.H, p.W, p.O, p.kh, p.kw = B, Cc, H, W, pd.O, pd.kh, pd.kw
+    p.stride_h, p.stride_w = stride
+    p.pad_h, p.pad_w = padding
+    p.dil_h, p.dil_w = dilation
+    p.groups, p.deformable_groups, p.Kpad, p.dtype = groups, deformable_groups, pd.Kpad, dtype_code(x.dtype)
+    p.mask_sigmoid, p.relu = int(mask_sigmoid), int(relu)
+    for name, t, lay in (('in_strides', x, layout), ('out_strides', out, layout),
+                         ('offset_strides', offset, offset_layout or layout), ('mask_strides', mask, mask_layout or layout)):
+        s = _strides4(t, lay) if t is not None else (0, 0, 0, 0)
+        setattr(p, name, (C.c_int64 * 4)(*s))
+    check(_lib.lib().vd3d_deform_conv(C.byref(p), _stream()), 'vd3d_deform_conv')
+    return out
+
+
+def deform_conv_forward_nchw(x, weight, bias, offset, mask, stride, padding, dilation, groups, deformable_groups):
+    """The reference extension's call (NCHW fp32 contiguous tensors) through vd3d_deform_conv_forward."""
+    _require_cuda(x, weight, offset)
+    x, weight, offset = x.float().contiguous(), weight.float().contiguous(), offset.float().contiguous()
+    mask = mask.float().contiguous() if mask is not None else None
+    bias = bias.float().contiguous() if bias is not None else None
+    B, Cc, H, W = x.shape
+    O, Cg, kh, kw = weight.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
+    assert offset.shape == (B, deformable_groups * 2 * kh * kw, Ho, Wo), (offset.shape, (B, deformable_groups * 2 * kh * kw, Ho, Wo))
+    out = torch.empty((B, O, Ho, Wo), dtype=torch.float32, device=x.device)
+    ws = torch.empty(_lib.lib().vd3d_deform_conv_workspace_bytes(O, Cc, groups, kh, kw), dtype=torch.uint8, device=x.device)
+    check(_lib.lib().vd3d_deform_conv_forward(_p(x), _p(weight), _p(bias), _p(offset), _p(mask), _p(out), _p(ws), B, Cc, H, W, O, kh, kw,
+                                              stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                              groups, deformable_groups, _stream()), 'vd3d_deform_conv_forward')
+    return out
