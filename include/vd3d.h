@@ -194,10 +194,11 @@ typedef struct vd3d_dcn_params {
 int vd3d_dcn_pack_weight(const float* w_oihw, void* packed, int O, int Cg, int kh, int kw, int Kpad, int dtype, void* stream);
 int vd3d_deform_conv(const vd3d_dcn_params* p, void* stream);
 
-/* LookGround sampling (lib/look_ground.py:44-69): builds [prior disparity; x] and bilinear-samples it
- * (grid_sample, border padding, align_corners=True) at (x, y + y_shift).  NHWC.
- *   x [B][H][W][C], disp [B][H][W] fp32 (= 0.1*tanh(conv)), P2 [B][3][4] (already /16 on rows 0..1)
- *   out [B][H][W][C+1] with channel 0 = sampled prior disparity (cat order of look_ground.py:66). */
+/* LookGround sampling (lib/look_ground.py:24-69): builds [x ; prior disparity] and bilinear-samples it
+ * (grid_sample, border padding, align_corners=True) at (x, y + y_shift), y_shift = geometric prior + 0.1*tanh(disp).
+ *   x [B][H][W][C] NHWC, disp [B][H][W] fp32 = raw output of the disp_create conv (tanh applied here),
+ *   P2 [B][3][4] full-resolution calibration (the /16 of look_ground.py:31 is applied here)
+ *   out [B][H][W][round_up(C+1, 16 bytes)]: channels [0,C) = sampled x, channel C = sampled prior, rest 0. */
 int vd3d_look_ground_sample(const void* x, const float* disp, const float* P2s, void* out, int B, int H, int W,
                             int C, int in_pix_stride, int out_pix_stride, float baseline, float elevation,
                             int dtype, void* stream);

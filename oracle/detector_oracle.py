@@ -314,6 +314,85 @@ def get_bboxes(cls_preds, reg_preds, anchors, mean_std, mask, img_hw, num_classe
     return max_score[keep], boxes[keep], label[keep], idx[keep]
 
 
+# ------------------------------------------------------------------------------------------- mono
+def look_ground(c, p, x, P2, baseline=0.54, elevation=1.65):
+    """lib/look_ground.py:24-71."""
+    P2 = P2.clone().float()
+    P2[:, 0:2] /= 16.0
+    w = c.w(p + '.disp_create.0.weight')
+    disp = torch.tanh(F.conv2d(x, w, c.sd[p + '.disp_create.0.bias'], padding=1))
+    disp = 0.1 * (0.05 * disp + 0.95 * disp)
+    B, _, H, W = x.shape
+    yy = torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(1, H, W)
+    fy, cy, Ty = P2[:, 1:2, 1:2], P2[:, 1:2, 2:3], P2[:, 1:2, 3:4]
+    disparity = F.relu(fy * baseline * (yy - cy) / (torch.abs(fy * elevation + Ty) + 1e-10))
+    x_base = torch.linspace(-1, 1, W).repeat(B, H, 1)
+    y_base = torch.linspace(-1, 1, H).repeat(B, W, 1).transpose(1, 2)
+    h_mean = 1.535
+    y_shifts_base = F.relu(h_mean * (yy - cy) / (2 * (elevation - 0.5 * h_mean))) / (H * 0.5)
+    y_shifts = y_shifts_base + disp[:, 0]
+    flow = torch.stack((x_base, y_base + y_shifts), dim=3)
+    feats = torch.cat([disparity.unsqueeze(1), x], dim=1)
+    out = c.rnd(F.grid_sample(feats, flow, mode='bilinear', padding_mode='border', align_corners=True))
+    we = c.w(p + '.extract.weight')
+    ext = F.conv2d(out, we, c.sd[p + '.extract.bias'])
+    return c.rnd(F.relu(x + ext * c.sd[p + '.alpha']))
+
+
+def cls_tower(c, feats, p):
+    x = conv_bn_act(c, feats, p + '.cls_feature_extraction.0', None, True)
+    x = conv_bn_act(c, x, p + '.cls_feature_extraction.3', None, True)
+    return conv_bn_act(c, x, p + '.cls_feature_extraction.6', None, False, out_round=False)
+
+
+def ground_aware_head(c, feats, P2, num_cls_output, p='bbox_head'):
+    """detectors/yolomono3d_detector.py:12-53 (GroundAwareHead)."""
+    cls = cls_tower(c, feats, p)
+    r = look_ground(c, p + '.reg_feature_extraction.0', feats, P2)
+    r = conv_bn_act(c, r, p + '.reg_feature_extraction.1', p + '.reg_feature_extraction.2', True)
+    r = conv_bn_act(c, r, p + '.reg_feature_extraction.4', p + '.reg_feature_extraction.5', True)
+    reg = conv_bn_act(c, r, p + '.reg_feature_extraction.7', None, False, out_round=False)
+    return anchor_flatten(cls, num_cls_output), anchor_flatten(reg, 12)
+
+
+def dcn_head(c, feats, num_cls_output, p='bbox_head'):
+    """heads/detection_3d_head.py:47-88 (base head): ModulatedDeformConvPack + BN + ReLU, conv + BN + ReLU, conv."""
+    from . import dcn_ref
+    cls = cls_tower(c, feats, p)
+    q = p + '.reg_feature_extraction.0'
+    off_logits = F.conv2d(feats, c.w(q + '.conv_offset.weight'), c.sd[q + '.conv_offset.bias'], padding=1)
+    o1, o2, mask = torch.chunk(off_logits, 3, dim=1)
+    y = dcn_ref.deform_conv_forward(feats, torch.cat((o1, o2), 1), torch.sigmoid(mask), c.sd[q + '.weight'], c.sd[q + '.bias'],
+                                    1, 1, 1, 1, 1, rnd=(c.rnd if c.rnd is not identity else None))
+    s, t = c.bn(p + '.reg_feature_extraction.1')
+    r = c.rnd(F.relu(_affine(y, s, t)))
+    r = conv_bn_act(c, r, p + '.reg_feature_extraction.3', p + '.reg_feature_extraction.4', True)
+    reg = conv_bn_act(c, r, p + '.reg_feature_extraction.6', None, False, out_round=False)
+    return anchor_flatten(cls, num_cls_output), anchor_flatten(reg, 12)
+
+
+def mono3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False):
+    """Yolo3D / GroundAwareYolo3D test_forward (detectors/yolomono3d_detector.py:100-120), B >= 1, no post-optimisation."""
+    c = Ctx(sd, rnd)
+    bb = cfg.backbone
+    feats = resnet(c, 'core.backbone', img.float(), depth=bb.depth, num_stages=bb.num_stages, out_indices=bb.out_indices)[0]
+    ncls = len(cfg.obj_types)
+    if cfg.name == 'GroundAwareYolo3D':
+        cls_preds, reg_preds = ground_aware_head(c, feats, P2, ncls + 1)
+    else:
+        cls_preds, reg_preds = dcn_head(c, feats, ncls + 1)
+    mean_npy, std_npy = load_priors(cfg.head.preprocessed_path, cfg.obj_types)
+    H, W = img.shape[2:]
+    anchors, means, mean_std = anchors_for_image(H, W, cfg.head.anchors_cfg, mean_npy, std_npy)
+    mask = anchor_mask(anchors, means, P2.float())
+    tc = cfg.head.test_cfg
+    outs = [get_bboxes(cls_preds[b], reg_preds[b], anchors, mean_std, mask[b], (H, W), ncls,
+                       getattr(tc, 'score_thr', 0.5), getattr(tc, 'nms_iou_thr', 0.5)) for b in range(img.shape[0])]
+    if return_stages:
+        return outs, dict(features=feats, cls_preds=cls_preds, reg_preds=reg_preds, mask=mask)
+    return outs
+
+
 # ------------------------------------------------------------------------------------------- detectors
 def load_priors(preprocessed_path, obj_types):
     import os

@@ -78,8 +78,62 @@ def run_stereo_case(name, case):
     return model, cfg, sd, (L, R, P2, P3), out
 
 
+MONO_CASES = {
+    'groundaware_r34_96x320': dict(name='GroundAwareYolo3D', depth=34, H=96, W=320, frames=2, wseed=3, iseed=4, score_thr=0.5, head_std=0.02),
+    'groundaware_r34_384x1280': dict(name='GroundAwareYolo3D', depth=34, H=384, W=1280, frames=1, wseed=3, iseed=6, score_thr=0.75, head_std=0.02),
+    'yolo3d_dcn_r34_96x320': dict(name='Yolo3D', depth=34, H=96, W=320, frames=2, wseed=4, iseed=7, score_thr=0.5, head_std=0.02),
+}
+
+
+def build_reference_mono(case, tmp):
+    DD = ref_shim.detector_dict()
+    if case['name'] == 'Yolo3D':
+        # the reference's DCN is CUDA-only: serve its forward with the oracle restatement (pinned to the reference's own
+        # im2col device code through tests/golden/dcn_cases.npz)
+        import visualDet3D.networks.lib.ops.dcn.deform_conv as ref_dcn
+        from oracle import dcn_ref
+        ref_dcn.modulated_deform_conv = lambda x, off, m, w, b, s, p, d, g, dg: dcn_ref.deform_conv_forward(x, off, m, w, b, s, p, d, g, dg)
+    cfg = syn.mono3d_cfg(tmp, depth=case['depth'], score_thr=case['score_thr'], name=case['name'])
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 2)
+    model = DD[case['name']](cfg).eval()
+    sd = syn.seeded_state_dict(model.state_dict(), seed=case['wseed'], head_std=case['head_std'])
+    model.load_state_dict(sd)
+    return model, cfg, sd
+
+
+def run_mono_case(name, case):
+    tmp = tempfile.mkdtemp()
+    model, cfg, sd = build_reference_mono(case, tmp)
+    img = syn.mono_image(case['frames'], case['H'], case['W'], seed=case['iseed'])
+    P2, _ = syn.kitti_calib(case['W'], batch=case['frames'])
+    out = {}
+    with torch.no_grad():
+        for f in range(case['frames']):
+            im, p2 = img[f:f + 1], P2[f:f + 1].clone()
+            feats = model.core(dict(image=im, P2=p2))
+            cls_preds, reg_preds = model.bbox_head(dict(features=feats, P2=p2))
+            model.bbox_head.anchors.P2 = None
+            scores, boxes, labels = model([im, p2])
+            out['f%d_scores' % f] = scores.numpy()
+            out['f%d_boxes' % f] = boxes.numpy()
+            out['f%d_labels' % f] = labels.numpy()
+            out['f%d_features_sub' % f] = subsample(feats).numpy()
+            out['f%d_cls_sub' % f] = subsample(cls_preds).numpy()
+            out['f%d_reg_sub' % f] = subsample(reg_preds).numpy()
+            print(name, 'frame', f, 'detections', len(scores), 'cls std', float(cls_preds.std()), 'reg std', float(reg_preds.std()))
+    out['meta'] = np.array([case['depth'], case['H'], case['W'], case['frames'], case['wseed'], case['iseed']])
+    out['score_thr'] = np.float32(case['score_thr'])
+    out['head_std'] = np.float64(case['head_std'])
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + '.npz'), **out)
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only_ = sys.argv[1:] or None
+    for name, case in MONO_CASES.items():
+        if only_ and name not in only_:
+            continue
+        run_mono_case(name, case)
     only = sys.argv[1:] or None
     for name, case in STEREO_CASES.items():
         if only and name not in only:

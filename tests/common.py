@@ -66,3 +66,14 @@ def assert_detections_close(got, want, rtol=1e-3, what='', allow_missing=0):
             what, missing, float(best[~ok].min()) if missing else 0.0, extra, rtol)
     # order must still be non-increasing in score
     assert bool((gs[1:] <= gs[:-1]).all()), what + ': scores not in decreasing order'
+
+
+def mono_case_from_golden(g, name):
+    depth, H, W, frames, wseed, iseed = [int(v) for v in g['meta']]
+    tmp = tempfile.mkdtemp()
+    det = 'GroundAwareYolo3D' if name.startswith('groundaware') else 'Yolo3D'
+    cfg = syn.mono3d_cfg(tmp, depth=depth, score_thr=float(g['score_thr']), name=det)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 2)
+    img = syn.mono_image(frames, H, W, seed=iseed)
+    P2, _ = syn.kitti_calib(W, batch=frames)
+    return cfg, (img, P2), dict(seed=wseed, head_std=float(g['head_std']))

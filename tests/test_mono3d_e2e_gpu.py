@@ -1,0 +1,50 @@
+"""GPU: GroundAwareYolo3D (LookGround head) and Yolo3D (DCNv2 head) end to end on the HIP path: fp32 mode vs golden
+outputs of the reference itself; bf16 mode vs the bf16-rounding oracle."""
+import pytest
+import torch
+
+from oracle import detector_oracle as orc
+from tests.common import assert_detections_close, load_golden, mono_case_from_golden, rel_err, subsample
+from visualdet3d_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(cfg, winit, dtype):
+    from visualdet3d_amd.networks.utils.registry import DETECTOR_DICT
+    m = DETECTOR_DICT[cfg.name](cfg)
+    sd = syn.seeded_state_dict(m.state_dict(), **winit)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    return m, sd
+
+
+@pytest.mark.parametrize('name', ['groundaware_r34_96x320', 'groundaware_r34_384x1280', 'yolo3d_dcn_r34_96x320'])
+def test_fp32_mode_matches_reference_golden(name):
+    g = load_golden(name)
+    cfg, (img, P2), winit = mono_case_from_golden(g, name)
+    m, _ = _model(cfg, winit, torch.float32)
+    outs = m.test_forward_batched(img.cuda(), P2.cuda())
+    cls, reg = m._last_raw
+    for f in range(img.shape[0]):
+        assert rel_err(subsample(cls[f:f + 1].cpu()), g['f%d_cls_sub' % f]) < 1e-3
+        assert rel_err(subsample(reg[f:f + 1].cpu()), g['f%d_reg_sub' % f]) < 1e-3
+        s, b, l = [t.cpu() for t in outs[f]]
+        assert_detections_close((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=1e-3,
+                                what='%s frame %d' % (name, f))
+    s1, b1, l1 = m([img[:1].cuda(), P2[:1].cuda()])      # the reference's batch-1 entry point
+    assert torch.equal(s1, outs[0][0]) and torch.equal(b1, outs[0][1])
+
+
+@pytest.mark.parametrize('name', ['groundaware_r34_96x320', 'yolo3d_dcn_r34_96x320'])
+def test_bf16_mode_close_to_bf16_oracle(name):
+    g = load_golden(name)
+    cfg, (img, P2), winit = mono_case_from_golden(g, name)
+    m, sd = _model(cfg, winit, torch.bfloat16)
+    m.test_forward_batched(img.cuda(), P2.cuda())
+    cls, reg = m._last_raw
+    with torch.no_grad():
+        _, st = orc.mono3d_forward(sd, cfg, img, P2, rnd=orc.bf16_round, return_stages=True)
+    assert rel_err(cls.cpu(), st['cls_preds']) < 4e-2
+    assert rel_err(reg.cpu(), st['reg_preds']) < 4e-2

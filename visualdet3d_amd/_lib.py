@@ -84,10 +84,10 @@ SIGNATURES = {
     'vd3d_deform_conv_forward': (c_int, [c_void_p] * 7 + [c_int] * 15 + [c_void_p]),
     'vd3d_dcn_pack_weight': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'vd3d_deform_conv': (c_int, [C.POINTER(DcnParams), c_void_p]),
+    'vd3d_look_ground_sample': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_int, c_void_p]),
 }
 # declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)
 PENDING = {
-    'vd3d_look_ground_sample': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_int, c_void_p]),
 }
 
 _lib = None

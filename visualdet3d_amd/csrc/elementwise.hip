@@ -264,3 +264,77 @@ extern "C" int vd3d_nchw_f32_to_nhwc(const float* in, void* out, int B, int H, i
                                              in, (T*)out, B, H, W, C, ops));
     return vd3d_check_launch("nchw_to_nhwc");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// LookGround sampling (lib/look_ground.py:24-69): for each output pixel sample [x ; prior disparity] at
+// (x, y + y_shift) with grid_sample(bilinear, border, align_corners=True) semantics.  The x coordinate of the flow
+// field is the pixel's own column (x_base is the identity grid), so the gather is a 2-row vertical lerp: coalesced
+// 16-byte channel vectors from two rows.  Output layout: channels [0, C) = sampled x, channel C = sampled prior
+// disparity, channels (C, Cpad) = 0 (the 1x1 `extract` conv weight is packed in the same order).
+namespace {
+template <typename T>
+__global__ void look_ground_kernel(const T* __restrict__ x, const float* __restrict__ disp_raw, const float* __restrict__ P2,
+                                   T* __restrict__ out, int B, int H, int W, int C, int Cpad, int ips, int ops,
+                                   float baseline, float elevation) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int cv = Cpad / VE;
+    const int64_t total = (int64_t)B * H * W * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t pix = i / cv;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        const float fy = P2[b * 12 + 5] / 16.0f, cy = P2[b * 12 + 6] / 16.0f, Ty = P2[b * 12 + 7] / 16.0f;
+        // learned offset: 0.1 * (0.05 * d + 0.95 * d), d = tanh(conv)
+        const float d = tanhf(disp_raw[pix]);
+        const float disp = 0.1f * (0.05f * d + 0.95f * d);
+        const float h_mean = 1.535f;
+        const float ysb = fmaxf(h_mean * ((float)h - cy) / (2.0f * (elevation - 0.5f * h_mean)), 0.0f) / ((float)H * 0.5f);
+        const float y_base = H > 1 ? -1.0f + 2.0f * (float)h / (float)(H - 1) : -1.0f;
+        const float gy = y_base + (ysb + disp);
+        float iy = (gy + 1.0f) / 2.0f * (float)(H - 1);
+        iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));          // padding_mode='border'
+        const int y0 = (int)floorf(iy);
+        const int y1 = min(y0 + 1, H - 1);
+        const float wy1 = iy - (float)y0, wy0 = 1.0f - wy1;
+        float v[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) v[e] = 0.f;
+        if (c < C) {
+            Vec16<T> a, bb;
+            a.raw = *(const i32x4*)(x + (((int64_t)b * H + y0) * W + w) * ips + c);
+            bb.raw = *(const i32x4*)(x + (((int64_t)b * H + y1) * W + w) * ips + c);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) v[e] = a.get(e) * wy0 + bb.get(e) * wy1;
+        } else if (c == C) {
+            // prior disparity of a ground point seen at row r: relu(fy * baseline * (r - cy) / (|fy * elev + Ty| + 1e-10))
+            const float den = fabsf(fy * elevation + Ty) + 1e-10f;
+            const float p0 = fmaxf(fy * baseline * ((float)y0 - cy) / den, 0.0f);
+            const float p1 = fmaxf(fy * baseline * ((float)y1 - cy) / den, 0.0f);
+            v[0] = p0 * wy0 + p1 * wy1;
+        }
+        Vec16<T> o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, v[2 * e], v[2 * e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, v[e]);
+        }
+        *(i32x4*)(out + pix * ops + c) = o.raw;
+    }
+}
+}  // namespace
+
+extern "C" int vd3d_look_ground_sample(const void* x, const float* disp, const float* P2s, void* out, int B, int H, int W,
+                                       int C, int ips, int ops, float baseline, float elevation, int dtype, void* stream) {
+    const int ve = dtype == VD3D_BF16 ? 8 : 4;
+    const int Cpad = (C + 1 + ve - 1) / ve * ve;
+    if (!x || !disp || !P2s || !out || C % ve || ips % ve || ops % ve || ops < Cpad || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) {
+        vd3d_set_error("look_ground_sample: C, strides must be 16-byte multiples; out needs round_up(C+1) channels");
+        return VD3D_EINVAL;
+    }
+    const int64_t total = (int64_t)B * H * W * (Cpad / ve);
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(look_ground_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)x, disp, P2s, (T*)out, B, H, W, C, Cpad, ips, ops, baseline, elevation));
+    return vd3d_check_launch("look_ground_sample");
+}
