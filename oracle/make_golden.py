@@ -27,6 +27,7 @@ GOLDEN_DIR = os.path.join(_REPO, 'tests', 'golden')
 STEREO_CASES = {
     'stereo3d_r34_96x320': dict(depth=34, H=96, W=320, frames=2, wseed=1, iseed=3, score_thr=0.5, head_std=0.0005),
     'stereo3d_r34_384x1280': dict(depth=34, H=384, W=1280, frames=2, wseed=1, iseed=0, score_thr=0.75, head_std=0.00042),
+    'stereo3d_r50_96x320': dict(depth=50, H=96, W=320, frames=1, wseed=5, iseed=8, score_thr=0.5, head_std=0.006),
     'stereo3d_r34_384x1280_thr06': dict(depth=34, H=384, W=1280, frames=1, wseed=2, iseed=5, score_thr=0.6, head_std=0.009),
 }
 

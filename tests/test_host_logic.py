@@ -1,0 +1,99 @@
+"""CPU: host-side pieces of the boundary -- registry, config loader, anchors tables vs the oracle restatement,
+checkpoint key layout, weight packing helpers (CPU-only parts)."""
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detector_oracle as orc
+from visualdet3d_amd.utils import synthetic as syn
+
+
+def test_registry_contract():
+    from visualdet3d_amd.networks.utils.registry import DETECTOR_DICT, BACKBONE_DICT, Registry
+    import visualdet3d_amd.networks  # noqa: F401
+    for name in ('Stereo3D', 'Yolo3D', 'GroundAwareYolo3D'):
+        assert name in DETECTOR_DICT
+    assert 'resnet' in BACKBONE_DICT
+    r = Registry('t')
+
+    @r.register_module
+    def f():
+        pass
+    assert r['f'] is f
+    with pytest.raises(KeyError):
+        r.register_module(f)
+    r._register_module(f, force=True)
+    with pytest.raises(TypeError):
+        r._register_module(3)
+
+
+def test_cfg_from_file(tmp_path):
+    from visualdet3d_amd.utils import cfg_from_file, EasyDict
+    p = tmp_path / 'cfg.py'
+    p.write_text("from visualdet3d_amd.utils import EasyDict as edict\ncfg = edict()\ncfg.obj_types=['Car']\ncfg.detector = edict(name='Stereo3D', head=dict(a=1))\n")
+    cfg = cfg_from_file(str(p))
+    assert cfg.detector.name == 'Stereo3D' and cfg.detector.head.a == 1 and isinstance(cfg.detector.head, EasyDict)
+
+
+@pytest.mark.parametrize('H,W', [(96, 320), (384, 1280), (288, 1280)])
+def test_anchor_tables_match_oracle(H, W):
+    from visualdet3d_amd.networks.heads.anchors import Anchors
+    tmp = tempfile.mkdtemp()
+    cfg = syn.stereo3d_cfg(tmp)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    a = Anchors(preprocessed_path=tmp, readConfigFile=True, **cfg.head.anchors_cfg)
+    anchors, prior, A = a.device_tables((H, W), 'cpu')
+    mean_npy, std_npy = orc.load_priors(tmp, cfg.obj_types)
+    want_anchors, means, mean_std = orc.anchors_for_image(H, W, cfg.head.anchors_cfg, mean_npy, std_npy)
+    assert A == 48 and torch.equal(anchors, want_anchors)
+    N = anchors.shape[0]
+    assert N == (H // 16) * (W // 16) * 48
+    assert torch.equal(prior[torch.arange(N) % A], mean_std)
+    # reference-compatible forward: same mask as the oracle
+    img = torch.zeros(2, 3, H, W)
+    P2, _ = syn.kitti_calib(W, batch=2)
+    P2[1, 1, 2] += 11.0
+    anc, mask, ms = a(img, P2, is_filtering=True)
+    assert torch.equal(mask, orc.anchor_mask(want_anchors, means, P2))
+    assert torch.equal(ms, mean_std) and anc.shape == (1, N, 4)
+
+
+def test_checkpoint_key_layouts():
+    from visualdet3d_amd.networks.detectors import GroundAwareYolo3D, Stereo3D, Yolo3D
+    tmp = tempfile.mkdtemp()
+    cfg = syn.stereo3d_cfg(tmp)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    sd = Stereo3D(cfg).state_dict()
+    assert len(sd) == 313 and sum(v.numel() for v in sd.values()) == 107605442   # reference Stereo3D-R34
+    mcfg = syn.mono3d_cfg(tmp)
+    syn.write_synthetic_priors(tmp, mcfg.obj_types, 2)
+    keys = set(GroundAwareYolo3D(mcfg).state_dict())
+    for k in ('bbox_head.reg_feature_extraction.0.disp_create.0.weight', 'bbox_head.reg_feature_extraction.0.extract.bias',
+              'bbox_head.reg_feature_extraction.0.alpha', 'bbox_head.reg_feature_extraction.7.weight', 'core.backbone.layer3.5.bn2.running_var'):
+        assert k in keys, k
+    keys = set(Yolo3D(syn.mono3d_cfg(tmp, name='Yolo3D')).state_dict())
+    for k in ('bbox_head.reg_feature_extraction.0.weight', 'bbox_head.reg_feature_extraction.0.conv_offset.bias',
+              'bbox_head.reg_feature_extraction.1.running_mean', 'bbox_head.reg_feature_extraction.6.bias'):
+        assert k in keys, k
+
+
+def test_dcn_pack_legacy_offset_key_remap():
+    # version < 2 checkpoints name the offset conv "<prefix>_offset.*" (deform_conv.py:468-489)
+    from visualdet3d_amd.networks.lib.ops.dcn.deform_conv import _remap_legacy_offset_keys
+    sd = {'m.conv_offset.weight': 1, 'm.conv_offset.bias': 2, 'm.conv.weight': 3}
+    _remap_legacy_offset_keys(sd, 'm.conv.', {})
+    assert sd == {'m.conv.conv_offset.weight': 1, 'm.conv.conv_offset.bias': 2, 'm.conv.weight': 3}
+    sd2 = {'m.conv_offset.weight': 1}
+    _remap_legacy_offset_keys(sd2, 'm.conv.', {'version': 2})
+    assert sd2 == {'m.conv_offset.weight': 1}
+
+
+def test_nms_oracle_semantics():
+    from oracle.nms_ref import nms_numpy
+    boxes = np.array([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10]], dtype=np.float32)
+    scores = np.array([0.9, 0.8, 0.7, 0.9], dtype=np.float32)
+    assert nms_numpy(boxes, scores, 0.5).tolist() == [0, 2]          # tie -> lower index first, duplicates suppressed
+    assert nms_numpy(boxes, scores, 0.99).tolist() == [0, 1, 2]      # identical box still suppressed (IoU 1 > .99)
+    assert nms_numpy(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5).shape == (0,)

@@ -15,7 +15,7 @@ def _state_dict_for(cfg, winit):
     return syn.seeded_state_dict(m.state_dict(), **winit)
 
 
-@pytest.mark.parametrize('name', ['stereo3d_r34_96x320', 'stereo3d_r34_384x1280', 'stereo3d_r34_384x1280_thr06'])
+@pytest.mark.parametrize('name', ['stereo3d_r34_96x320', 'stereo3d_r34_384x1280', 'stereo3d_r34_384x1280_thr06', 'stereo3d_r50_96x320'])
 def test_oracle_matches_reference_golden(name):
     g = load_golden(name)
     cfg, (L, R, P2, P3), winit = stereo_case_from_golden(g)

@@ -25,7 +25,7 @@ def _model(cfg, winit, dtype):
     return m, sd
 
 
-@pytest.mark.parametrize('name', ['stereo3d_r34_96x320', 'stereo3d_r34_384x1280', 'stereo3d_r34_384x1280_thr06'])
+@pytest.mark.parametrize('name', ['stereo3d_r34_96x320', 'stereo3d_r34_384x1280', 'stereo3d_r34_384x1280_thr06', 'stereo3d_r50_96x320'])
 def test_fp32_mode_matches_reference_golden(name):
     g = load_golden(name)
     cfg, (L, R, P2, P3), winit = stereo_case_from_golden(g)
@@ -84,3 +84,35 @@ def test_state_dict_keys_match_reference_layout():
               'bbox_head.loss_cls.balance_weights', 'bbox_head.regression_weight',
               'core.neck.depth_reasoning.depth_output.8.bias'):
         assert k in keys, k
+
+
+def test_config3_stereo_core_with_dcn_head_r50():
+    """BASELINE config 3: YOLOStereo3D ResNet-50 core + the base (DCNv2) head, expressed exactly as SURVEY.md 0.8 says:
+    override ``Stereo3D.build_head``.  Logits vs the oracle (stereo_core + dcn_head), fp32 mode."""
+    import tempfile
+    from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3D
+    from visualdet3d_amd.networks.heads.detection_3d_head import AnchorBasedDetection3DHead
+
+    class Stereo3DDCN(Stereo3D):
+        def build_head(self, network_cfg):
+            self.bbox_head = AnchorBasedDetection3DHead(**(network_cfg.head))
+
+    tmp = tempfile.mkdtemp()
+    cfg = syn.stereo3d_cfg(tmp, depth=50, score_thr=0.5)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    m = Stereo3DDCN(cfg)
+    sd = syn.seeded_state_dict(m.state_dict(), seed=6, head_std=0.006)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.compute_dtype = torch.float32
+    L, R = syn.stereo_pair(2, 96, 320, seed=9)
+    P2, P3 = syn.kitti_calib(320, batch=2)
+    outs = m.test_forward_batched(L.cuda(), R.cuda(), P2.cuda(), P3.cuda())
+    cls, reg = m._last_raw
+    with torch.no_grad():
+        c = orc.Ctx(sd)
+        feats, _ = orc.stereo_core(c, L, R, 50)
+        want_cls, want_reg = orc.dcn_head(c, feats, 3)
+    assert rel_err(cls.cpu(), want_cls) < 1e-3
+    assert rel_err(reg.cpu(), want_reg) < 1e-3
+    assert len(outs) == 2
