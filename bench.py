@@ -75,6 +75,8 @@ def profile_convs(model, inputs, reps=3):
         return o
 
     ops.conv2d = timed
+    overlap = model.bbox_head.overlap_towers
+    model.bbox_head.overlap_towers = False     # serial launches: per-kernel event times must not overlap
     try:
         with torch.no_grad():
             for _ in range(reps):
@@ -82,6 +84,7 @@ def profile_convs(model, inputs, reps=3):
         torch.cuda.synchronize()
     finally:
         ops.conv2d = orig
+        model.bbox_head.overlap_towers = overlap
     if os.environ.get('VD3D_BENCH_LAYERS'):
         per = len(records) // reps
         for i in range(per):

@@ -21,6 +21,8 @@
 //   * the 1-D grid is remapped so each XCD (private 4 MiB L2) walks a contiguous run of pixel tiles that
 //     share one weight panel.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -296,9 +298,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     constexpr int BKE = 128 / ES;
     constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int A_PIECES = BM / 8 / NW, W_PIECES = BN / 8 / NW;  // per wave
+    constexpr int A_PIECES = BM / 8 / NW, W_PIECES = (BN / 8 + NW - 1) / NW;  // per wave (last W round may be partial)
     constexpr int A_STAGE = BM * 128, STAGE = (BM + BN) * 128;
-    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "tile rows must split evenly into 8-row pieces per wave");
+    static_assert((BM / 8) % NW == 0 && BN % 32 == 0, "pixel rows must split evenly into 8-row pieces per wave");
     static_assert((8 * NW) % 16 == 0, "piece stride must keep the swizzle phase constant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -357,9 +359,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + it * NW * 1024), 16, off, 0, 0, 0);
         }
 #pragma unroll
-        for (int it = 0; it < W_PIECES; ++it)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + A_STAGE + it * NW * 1024), 16,
-                                                     w_off + (uint32_t)(it * NW * 8 * p.Kpad * ES), 0, 0, 0);
+        for (int it = 0; it < W_PIECES; ++it) {
+            if ((BN / 8) % NW == 0 || wave + it * NW < BN / 8)   // wave-uniform guard for a partial last round
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + A_STAGE + it * NW * 1024), 16,
+                                                         w_off + (uint32_t)(it * NW * 8 * p.Kpad * ES), 0, 0, 0);
+        }
         w_off += BKE * ES;
         kc += BKE;
         while (kc >= p.Cin) {
@@ -447,21 +451,50 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 6: return launch<T, 256, 64, 4, 1>(a, stream);
         case 7: return launch<T, 128, 256, 2, 2, true>(a, stream);
         case 8: return launch<T, 256, 256, 2, 4, true>(a, stream);
+        case 9: return launch<T, 256, 352, 8, 1, true>(a, stream);
+        case 10: return launch<T, 256, 288, 8, 1, true>(a, stream);
+        case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
+        case 12: return launch<T, 256, 256, 8, 1, true>(a, stream);
+        case 13: return launch<T, 128, 352, 4, 1, true>(a, stream);
         default: break;
     }
     if (a.Cout <= 32) return launch<T, 256, 32, 4, 1, true>(a, stream);
     if (a.Cout <= 64) return launch<T, 256, 64, 4, 1, true>(a, stream);
-    // 128x128 (2 workgroups / CU) vs 256x256 (1 / CU): pick by modelled throughput = full-occupancy rate of the
-    // tile shape (measured on MI355X: ~970 vs ~1350 TFLOP/s bf16) x tile-edge waste x last-round occupancy.
+    // Tile choice by modelled throughput = full-occupancy rate of the tile shape (measured on MI355X, bf16 TFLOP/s)
+    // x tile-edge waste x last-round occupancy.  Candidates: 128x128 (2 workgroups/CU), 256x256 (8 waves of 128x64,
+    // 1/CU), and "column strips" 256xBN / 128xBN with BN = 288 | 352 (= 1152/4, 1408/4: every wave owns 32 pixels x
+    // the whole strip) which put the 1152- and 1408-channel layers at B = 8 on the chip in ONE ~94 %-full round.
     auto util = [&](int bm, int bn, int slots) {
         const double tm = (a.M + bm - 1) / bm, tn = (a.Cout + bn - 1) / bn;
         const double tiles = tm * tn;
         const double rounds = (double)((int64_t)((tiles + slots - 1) / slots));
         return ((double)a.M * a.Cout) / (tm * bm * tn * bn) * tiles / (rounds * slots);
     };
-    const double r128 = 970.0 * util(128, 128, 512), r256 = 1350.0 * util(256, 256, 256);
-    if (r256 > r128) return launch<T, 256, 256, 2, 4, true>(a, stream);
-    return launch<T, 128, 128, 2, 2, true>(a, stream);
+    double best = 970.0 * util(128, 128, 512);
+    int pick = 0;
+    const double r256 = 1350.0 * util(256, 256, 256);
+    if (r256 > best) { best = r256; pick = 1; }
+    if (a.Cout % 352 == 0) {
+        const double r = 1120.0 * util(256, 352, 256);
+        if (r > best) { best = r; pick = 2; }
+        const double r2 = 900.0 * util(128, 352, 256);
+        if (r2 > best) { best = r2; pick = 4; }
+    }
+    if (a.Cout % 288 == 0) {
+        const double r = 1100.0 * util(256, 288, 256);
+        if (r > best) { best = r; pick = 3; }
+        const double r2 = 850.0 * util(128, 288, 256);
+        if (r2 > best) { best = r2; pick = 5; }
+    }
+    if (getenv("VD3D_CONV_DEBUG")) fprintf(stderr, "[vd3d conv] M=%d N=%d pick=%d best=%.0f\n", a.M, a.Cout, pick, best);
+    switch (pick) {
+        case 1: return launch<T, 256, 256, 2, 4, true>(a, stream);
+        case 2: return launch<T, 256, 352, 8, 1, true>(a, stream);
+        case 3: return launch<T, 256, 288, 8, 1, true>(a, stream);
+        case 4: return launch<T, 128, 352, 4, 1, true>(a, stream);
+        case 5: return launch<T, 128, 288, 4, 1, true>(a, stream);
+        default: return launch<T, 128, 128, 2, 2, true>(a, stream);
+    }
 }
 
 }  // namespace

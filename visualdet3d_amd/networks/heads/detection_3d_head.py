@@ -58,6 +58,8 @@ class AnchorBasedDetection3DHead(nn.Module):
             layer_cfg['num_anchors'] = self.anchors.num_anchors
         self.init_layers(**layer_cfg)
         self._cache = fused.PackCache()
+        self._side_streams = {}
+        self.overlap_towers = True   # False: run the towers back to back on one stream (per-kernel profiling)
         self.max_candidates = 4096   # per-sample capacity of the device candidate list (power of two <= 8192)
         self._workspace = None
 
@@ -118,8 +120,23 @@ class AnchorBasedDetection3DHead(nn.Module):
         return t[7].forward_nhwc(x)
 
     def forward_nhwc(self, inputs):
+        """The two towers are independent: the (small) cls tower runs on a side HIP stream so its workgroups fill the
+        CUs the reg tower's partially-filled last tile rounds leave idle (fork/join is captured into the hipGraph)."""
         feat = inputs['features']
-        return self._cls_forward_nhwc(feat), self._reg_forward_nhwc(feat, inputs)
+        if not self.overlap_towers:
+            return self._cls_forward_nhwc(feat), self._reg_forward_nhwc(feat, inputs)
+        main = torch.cuda.current_stream()
+        side = self._side_streams.get(feat.device)
+        if side is None:
+            side = self._side_streams[feat.device] = torch.cuda.Stream(device=feat.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            cls_preds = self._cls_forward_nhwc(feat)
+        reg_preds = self._reg_forward_nhwc(feat, inputs)
+        main.wait_stream(side)
+        cls_preds.record_stream(main)
+        feat.record_stream(side)
+        return cls_preds, reg_preds
 
     def forward(self, inputs):
         """Reference signature: ``inputs['features']`` is NCHW fp32."""
