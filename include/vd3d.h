@@ -79,6 +79,20 @@ int vd3d_conv2d_set_tuning(int cfg);
 int vd3d_pack_image_nhwc4(const float* in_nchw, void* out, int B, int H, int W,
                           int pad_y, int pad_l, int pad_r, int dtype, void* stream);
 
+/* General form of the image packer: `cpad` = 4 or 8 channels per pixel (3 real + zeros), independent borders.
+ * Used by DLA's 7x7 stride-1 base layer (backbones/dla.py:247-251): with 8-channel bf16 pixels every pixel is 16 bytes,
+ * so a kernel row (8 px x 8 ch = 64 elements) is a 16-byte aligned run for any output column. */
+int vd3d_pack_image_nhwc(const float* in_nchw, void* out, int B, int H, int W, int pad_y0, int pad_y1, int pad_l, int pad_r,
+                         int cpad, int dtype, void* stream);
+
+/* nn.MaxPool2d(2, stride 2) on NHWC (backbones/dla.py:213, Tree.downsample). */
+int vd3d_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int in_pix_stride, int out_pix_stride,
+                    int dtype, void* stream);
+/* Depth-wise nn.ConvTranspose2d(C, C, 2f, stride f, padding f/2, groups C, bias False) on NHWC (backbones/dla_utils.py:69-71)
+ * fused with the `+ layers[i-1]` that follows it (:83); weight [(2f)^2][C] fp32; add may be NULL. */
+int vd3d_dwconv_transpose(const void* in, const float* weight, const void* add, void* out, int B, int H, int W, int C,
+                          int f, int in_pix_stride, int add_pix_stride, int out_pix_stride, int dtype, void* stream);
+
 /* nn.MaxPool2d(3, stride 2, pad 1) on NHWC (backbones/resnet.py:121,193). */
 int vd3d_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C,
                       int in_pix_stride, int out_pix_stride, int dtype, void* stream);
@@ -202,6 +216,23 @@ int vd3d_deform_conv(const vd3d_dcn_params* p, void* stream);
 int vd3d_look_ground_sample(const void* x, const float* disp, const float* P2s, void* out, int B, int H, int W,
                             int C, int in_pix_stride, int out_pix_stride, float baseline, float elevation,
                             int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * KM3D / RTM3D keypoint-head decoding (heads/km3d_head.py:155-314 _decode + get_bboxes; networks/utils/rtm3d_utils.py
+ * _nms :122-127, _topk :201-216, _topk_channel :219-228, gen_position :314-455; torchvision nms) for a whole batch.
+ * All maps are fp32 NHWC logits / regressions [B][H][W][n] (n: hm n_cls, wh 2, hps 18, rot 8, dim 3, prob 1, reg 2,
+ * hm_hp 9, hp_offset 2); P2 [B][3][4]; kconst = the head's `const` buffer, 32 floats ([16][2]).
+ * Outputs padded to K per sample in decreasing-score order: scores [B][K], boxes [B][K][11]
+ * (x1,y1,x2,y2,cx,cy,z,w,h,l,alpha), cls [B][K] int32, count [B] int32 (-1: more peaks than max_peaks). */
+typedef struct vd3d_km3d_params {
+    const float *hm, *wh, *hps, *rot, *dim, *prob, *reg, *hm_hp, *hp_offset, *P2, *kconst;
+    int32_t B, H, W, n_cls, n_joints, K, max_peaks, img_h, img_w;
+    float score_thr, nms_iou_thr;
+    void* workspace;
+    float* out_scores; float* out_boxes; int32_t* out_cls; int32_t* out_count;
+} vd3d_km3d_params;
+int64_t vd3d_km3d_workspace_bytes(int B, int n_cls, int n_joints, int max_peaks, int K);
+int vd3d_km3d_decode(const vd3d_km3d_params* p, void* stream);
 
 #ifdef __cplusplus
 }

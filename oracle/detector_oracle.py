@@ -393,6 +393,231 @@ def mono3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False):
     return outs
 
 
+# ------------------------------------------------------------------------------------------- KM3D (DLA-34)
+def dla_block(c, p, x, residual=None, stride=1):
+    """backbones/dla.py:37-61 (BasicBlock with external residual)."""
+    if residual is None:
+        residual = x
+    out = conv_bn_act(c, x, p + '.conv1', p + '.bn1', True, stride=stride, padding=1)
+    return conv_bn_act(c, out, p + '.conv2', p + '.bn2', True, padding=1, residual=residual)
+
+
+def dla_tree(c, p, x, levels, in_ch, out_ch, stride, level_root, residual=None, children=None):
+    """backbones/dla.py:177-230."""
+    children = [] if children is None else children
+    bottom = F.max_pool2d(x, stride, stride) if stride > 1 else x
+    if in_ch != out_ch:
+        residual = conv_bn_act(c, bottom, p + '.project.0', p + '.project.1', False, padding=0)
+    else:
+        residual = bottom
+    if level_root:
+        children.append(bottom)
+    if levels == 1:
+        x1 = dla_block(c, p + '.tree1', x, residual, stride)
+        x2 = dla_block(c, p + '.tree2', x1)
+        cat = torch.cat([x2, x1] + children, dim=1)
+        return conv_bn_act(c, cat, p + '.root.conv', p + '.root.bn', True, padding=0)
+    x1 = dla_tree(c, p + '.tree1', x, levels - 1, in_ch, out_ch, stride, False, residual)
+    children.append(x1)
+    return dla_tree(c, p + '.tree2', x1, levels - 1, out_ch, out_ch, 1, False, children=children)
+
+
+def dla34(c, p, img):
+    """backbones/dla.py:317-326, DLA-34: levels [1,1,1,2,2,1], channels [16,32,64,128,256,512]; returns levels 0..5."""
+    ch = [16, 32, 64, 128, 256, 512]
+    lv = [1, 1, 1, 2, 2, 1]
+    x = conv_bn_act(c, c.rnd(img), p + '.base_layer.0', p + '.base_layer.1', True, padding=3)
+    y = []
+    x = conv_bn_act(c, x, p + '.level0.0', p + '.level0.1', True, padding=1)
+    y.append(x)
+    x = conv_bn_act(c, x, p + '.level1.0', p + '.level1.1', True, stride=2, padding=1)
+    y.append(x)
+    for i in range(2, 6):
+        x = dla_tree(c, '%s.level%d' % (p, i), x, lv[i], ch[i - 1], ch[i], 2, i > 2)
+        y.append(x)
+    return y
+
+
+def dcn_bn_relu(c, p, x):
+    """backbones/dla_utils.py:42-56: ModulatedDeformConvPack 3x3 + BN + ReLU."""
+    from . import dcn_ref
+    q = p + '.conv'
+    logits = F.conv2d(x, c.w(q + '.conv_offset.weight'), c.sd[q + '.conv_offset.bias'], padding=1)
+    o1, o2, mask = torch.chunk(logits, 3, dim=1)
+    y = dcn_ref.deform_conv_forward(x, torch.cat((o1, o2), 1), torch.sigmoid(mask), c.sd[q + '.weight'], c.sd[q + '.bias'],
+                                    1, 1, 1, 1, 1, rnd=(c.rnd if c.rnd is not identity else None))
+    s, t = c.bn(p + '.actf.0')
+    return c.rnd(F.relu(_affine(y, s, t)))
+
+
+def ida_up(c, p, layers, startp, endp, up_f):
+    """backbones/dla_utils.py:76-85."""
+    for i in range(startp + 1, endp):
+        k = i - startp
+        f = int(up_f[k])
+        w = c.sd['%s.up_%d.weight' % (p, k)]
+        up = c.rnd(F.conv_transpose2d(dcn_bn_relu(c, '%s.proj_%d' % (p, k), layers[i]), w, None, stride=f, padding=f // 2, groups=w.shape[0]))
+        layers[i] = dcn_bn_relu(c, '%s.node_%d' % (p, k), c.rnd(up + layers[i - 1]))
+
+
+def dla_seg_upsample(c, p, tensors, first_level=2, last_level=5):
+    """backbones/dla_utils.py:126-155 (+ DLAUp :89-112)."""
+    layers = list(tensors)
+    channels = [64, 128, 256, 512]
+    scales = np.array([1, 2, 4, 8])
+    out = [layers[-1]]
+    for i in range(len(channels) - 1):
+        j = -i - 2
+        ida_up(c, '%s.dla_up.ida_%d' % (p, i), layers, len(layers) - i - 2, len(layers), scales[j:] // scales[j])
+        scales[j + 1:] = scales[j]
+        out.insert(0, layers[-1])
+    y = [out[i].clone() for i in range(last_level - first_level)]
+    ida_up(c, p + '.ida_up', y, 0, len(y), [2 ** i for i in range(last_level - first_level)])
+    return y[-1]
+
+
+KM3D_HEADS = ('hm', 'wh', 'hps', 'rot', 'dim', 'prob', 'reg', 'hm_hp', 'hp_offset')
+
+
+def km3d_heads(c, feat, heads, p='bbox_head.head_layers'):
+    """heads/km3d_head.py:353-357: nine (conv3x3 + ReLU, conv1x1) heads; final maps stay fp32."""
+    out = {}
+    for h in heads:
+        x = conv_bn_act(c, feat, '%s.%s.0' % (p, h), None, True)
+        out[h] = conv_bn_act(c, x, '%s.%s.2' % (p, h), None, False, padding=0, out_round=False)
+    return out
+
+
+def _gather_map(m, ind):
+    """_transpose_and_gather_feat (rtm3d_utils.py:195-199): m [B,C,H,W], ind [B,K] -> [B,K,C]."""
+    B, C, H, W = m.shape
+    f = m.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    return f.gather(1, ind.unsqueeze(2).expand(B, ind.shape[1], C))
+
+
+def _heat_nms(heat):
+    hmax = F.max_pool2d(heat, 3, 1, 1)
+    return heat * (hmax == heat).float()
+
+
+def km3d_gen_position(kps, dim, rot, calib, const):
+    """networks/utils/rtm3d_utils.py:314-455 (without the random 1e-8 jitter before the 3x3 inverse)."""
+    b, cn = kps.shape[:2]
+    off_set = calib[:, 0, 3] / calib[:, 0, 0]
+    si = torch.zeros_like(kps[:, :, 0:1]) + calib[:, 0:1, 0:1]
+    alpha_idx = (rot[:, :, 1] > rot[:, :, 5]).float()
+    alpha1 = torch.atan(rot[:, :, 2] / rot[:, :, 3]) + (-0.5 * np.pi)
+    alpha2 = torch.atan(rot[:, :, 6] / rot[:, :, 7]) + (0.5 * np.pi)
+    alpha = (alpha1 * alpha_idx + alpha2 * (1 - alpha_idx)).unsqueeze(2)
+    rot_y = alpha + torch.atan2(kps[:, :, 16:17] - calib[:, 0:1, 2:3], si)
+    rot_y = torch.where(rot_y > np.pi, rot_y - 2 * np.pi, rot_y)
+    rot_y = torch.where(rot_y < -np.pi, rot_y + 2 * np.pi, rot_y)
+    kpoint = kps[:, :, :16]
+    f = calib[:, 0, 0].view(b, 1, 1)
+    cxy = torch.stack([calib[:, 0, 2], calib[:, 1, 2]], dim=1).view(b, 1, 2).repeat(1, 1, 8)
+    kp_norm = (kpoint - cxy) / f
+    l, h, w = dim[:, :, 2:3], dim[:, :, 1:2], dim[:, :, 0:1]
+    co, sn = torch.cos(rot_y), torch.sin(rot_y)
+    lc, ls, wc, ws_, hh = l * 0.5 * co, l * 0.5 * sn, w * 0.5 * co, w * 0.5 * sn, h * 0.5
+    Bx = [-lc - ws_, -lc + ws_, -lc + ws_, lc + ws_, lc + ws_, lc - ws_, lc - ws_, -lc - ws_]
+    By = [-hh, -hh, hh, hh, -hh, -hh, hh, hh]
+    Cz = [ls - wc, ls + wc, ls + wc, -ls + wc, -ls + wc, -ls - wc, -ls - wc, ls - wc]
+    Bm = torch.cat([t for pair in zip(Bx, By) for t in pair], dim=2)
+    Cm = torch.cat([t for z in Cz for t in (z, z)], dim=2)
+    Bm = Bm - kp_norm * Cm
+    A = torch.cat([const.expand(b, cn, -1, -1), kp_norm.unsqueeze(3)], dim=3).double().view(b * cn, 16, 3)
+    AT = A.transpose(1, 2)
+    pinv = torch.inverse(torch.bmm(AT, A))
+    pinv = torch.bmm(pinv, AT).float()
+    pos = torch.bmm(pinv, Bm.reshape(b * cn, 16, 1).float()).view(b, cn, 3)
+    pos = pos.clone()
+    pos[:, :, 0] -= off_set.unsqueeze(1)
+    return pos, rot_y, alpha
+
+
+def km3d_get_bboxes(out, P2, img_hw, score_thr=0.3, nms_iou_thr=0.5, K=100, const=None):
+    """heads/km3d_head.py:255-314 get_bboxes + :155-252 _decode, for every sample of the batch (the reference takes
+    sample 0 only).  Returns a list of (scores[N], bbox[N,11], cls[N,1] int64)."""
+    heat = _heat_nms(torch.sigmoid(out['hm']))
+    hm_hp = _heat_nms(torch.sigmoid(out['hm_hp']))
+    B, ncls, H, W = heat.shape
+    J = 9
+    ts, ti = torch.topk(heat.view(B, ncls, -1), K)
+    ti = ti % (H * W)
+    tys, txs = (ti // W).float(), (ti % W).float()
+    sc, tk = torch.topk(ts.view(B, -1), K)
+    clses = (tk // K).float()
+    inds = ti.view(B, -1).gather(1, tk)
+    ys, xs = tys.view(B, -1).gather(1, tk), txs.view(B, -1).gather(1, tk)
+    kps = _gather_map(out['hps'], inds).clone()
+    kps[..., ::2] += xs.unsqueeze(2)
+    kps[..., 1::2] += ys.unsqueeze(2)
+    reg = _gather_map(out['reg'], inds)
+    xs_, ys_ = xs.unsqueeze(2) + reg[:, :, 0:1], ys.unsqueeze(2) + reg[:, :, 1:2]
+    wh = _gather_map(out['wh'], inds)
+    bboxes = torch.cat([xs_ - wh[..., 0:1] / 2, ys_ - wh[..., 1:2] / 2, xs_ + wh[..., 0:1] / 2, ys_ + wh[..., 1:2] / 2], dim=2)
+    dim = _gather_map(out['dim'], inds)
+    rot = _gather_map(out['rot'], inds)
+    # keypoint <-> heat-map association (:205-244)
+    kps = kps.view(B, K, J, 2).permute(0, 2, 1, 3).contiguous()
+    hs, hi = torch.topk(hm_hp.view(B, J, -1), K)
+    hi = hi % (H * W)
+    hys, hxs = (hi // W).float(), (hi % W).float()
+    hpo = _gather_map(out['hp_offset'], hi.view(B, -1)).view(B, J, K, 2)
+    hxs, hys = hxs + hpo[..., 0], hys + hpo[..., 1]
+    m = (hs > 0.1).float()
+    hs = (1 - m) * -1 + m * hs
+    hys = (1 - m) * (-10000) + m * hys
+    hxs = (1 - m) * (-10000) + m * hxs
+    hm_kps = torch.stack([hxs, hys], dim=-1).unsqueeze(2).expand(B, J, K, K, 2)
+    dist = ((kps.unsqueeze(3).expand(B, J, K, K, 2) - hm_kps) ** 2).sum(dim=4) ** 0.5
+    min_dist, min_ind = dist.min(dim=3)
+    hsc = hs.gather(2, min_ind).unsqueeze(-1)
+    sel = hm_kps.gather(3, min_ind.view(B, J, K, 1, 1).expand(B, J, K, 1, 2)).view(B, J, K, 2)
+    l_, t_, r_, b_ = [bboxes[:, :, i].view(B, 1, K, 1).expand(B, J, K, 1) for i in range(4)]
+    bad = (sel[..., 0:1] < l_) | (sel[..., 0:1] > r_) | (sel[..., 1:2] < t_) | (sel[..., 1:2] > b_) | (hsc < 0.1) | \
+          (min_dist.unsqueeze(-1) > (torch.max(b_ - t_, r_ - l_) * 0.3))
+    bad = bad.float().expand(B, J, K, 2)
+    kps = ((1 - bad) * sel + bad * kps).permute(0, 2, 1, 3).contiguous().view(B, K, J * 2)
+    kps = kps * 4
+    bboxes = bboxes * 4
+    if const is None:
+        const = torch.tensor([[-1, 0], [0, -1]] * 8, dtype=torch.float32).view(1, 1, 16, 2)
+    pos, rot_y, alpha = km3d_gen_position(kps, dim, rot, P2.float(), const)
+    res = []
+    Hh, Ww = img_hw
+    for b in range(B):
+        keep = sc[b] > score_thr
+        p2 = P2[b].float()
+        fx, fy, cx, cy, tx, ty = p2[0, 0], p2[1, 1], p2[0, 2], p2[1, 2], p2[0, 3], p2[1, 3]
+        position = pos[b][keep]
+        z3d = position[:, 2:3]
+        cx3d = (position[:, 0:1] * fx + tx + cx * z3d) / z3d
+        cy3d = (position[:, 1:2] * fy + ty + cy * z3d) / z3d
+        bb = bboxes[b][keep].clone()
+        bb[:, 0].clamp_(min=0); bb[:, 1].clamp_(min=0); bb[:, 2].clamp_(max=Ww); bb[:, 3].clamp_(max=Hh)
+        box = torch.cat([bb, cx3d, cy3d, z3d, dim[b][keep], alpha[b][keep]], dim=1)
+        s = sc[b][keep]
+        k = torch.from_numpy(nms_numpy(box[:, :4].numpy(), s.numpy(), nms_iou_thr))
+        res.append((s[k], box[k], clses[b][keep][k].long().unsqueeze(1)))
+    return res
+
+
+def km3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False):
+    """KM3D.test_forward (detectors/KM3D.py:61-79) with the DLA-34 + DLA-Up core, B >= 1."""
+    c = Ctx(sd, rnd)
+    levels = dla34(c, 'core.backbone', img.float())
+    feat = dla_seg_upsample(c, 'core.deconv_layers', levels)
+    heads = list(cfg.head.layer_cfg.head_dict.keys())
+    out = km3d_heads(c, feat, heads)
+    tc = cfg.head.test_cfg
+    dets = km3d_get_bboxes(out, P2, img.shape[2:], getattr(tc, 'score_thr', 0.1), getattr(tc, 'nms_iou_thr', 0.5),
+                           const=c.sd.get('bbox_head.const'))
+    if return_stages:
+        return dets, dict(features=feat, **out)
+    return dets
+
+
 # ------------------------------------------------------------------------------------------- detectors
 def load_priors(preprocessed_path, obj_types):
     import os

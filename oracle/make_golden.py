@@ -128,8 +128,59 @@ def run_mono_case(name, case):
     np.savez_compressed(os.path.join(GOLDEN_DIR, name + '.npz'), **out)
 
 
+KM3D_CASES = {
+    'km3d_dla34_96x320': dict(H=96, W=320, frames=2, wseed=7, iseed=11, score_thr=0.3),
+    'km3d_dla34_192x640': dict(H=192, W=640, frames=1, wseed=7, iseed=12, score_thr=0.3),
+}
+
+
+def build_reference_km3d(case, tmp):
+    DD = ref_shim.detector_dict()
+    import visualDet3D.networks.lib.ops.dcn.deform_conv as ref_dcn
+    import visualDet3D.networks.backbones.dla as ref_dla
+    from oracle import dcn_ref
+    ref_dcn.modulated_deform_conv = lambda x, off, m, w, b, s, p, d, g, dg: dcn_ref.deform_conv_forward(x, off, m, w, b, s, p, d, g, dg)
+    ref_dla.DLA.load_pretrained_model = lambda self, *a, **k: None
+    cfg = syn.km3d_cfg(score_thr=case['score_thr'], output_w=case['W'] // 4)
+    model = DD['KM3D'](cfg).eval()
+    sd = syn.seeded_state_dict(model.state_dict(), seed=case['wseed'])
+    model.load_state_dict(sd)
+    return model, cfg, sd
+
+
+def run_km3d_case(name, case):
+    tmp = tempfile.mkdtemp()
+    model, cfg, sd = build_reference_km3d(case, tmp)
+    print(name, 'state_dict entries', len(sd), sum(v.numel() for v in sd.values()))
+    img = syn.mono_image(case['frames'], case['H'], case['W'], seed=case['iseed'])
+    P2, _ = syn.kitti_calib(case['W'], batch=case['frames'])
+    out = {}
+    torch.manual_seed(0)   # gen_position adds randn * 1e-8 before the 3x3 inverse (rtm3d_utils.py:447)
+    with torch.no_grad():
+        for f in range(case['frames']):
+            im, p2 = img[f:f + 1], P2[f:f + 1].clone()
+            feats = model.core(dict(image=im, P2=p2))
+            maps = model.bbox_head(feats)
+            for h, v in maps.items():
+                out['f%d_%s_sub' % (f, h)] = subsample(v).numpy()
+            scores, boxes, labels = model([im, p2])
+            out['f%d_scores' % f] = scores.numpy()
+            out['f%d_boxes' % f] = boxes.numpy()
+            out['f%d_labels' % f] = labels.numpy()
+            out['f%d_features_sub' % f] = subsample(feats).numpy()
+            print(name, 'frame', f, 'detections', len(scores), 'hm max', float(torch.sigmoid(maps['hm']).max()), 'feat std', float(feats.std()))
+    out['meta'] = np.array([34, case['H'], case['W'], case['frames'], case['wseed'], case['iseed']])
+    out['score_thr'] = np.float32(case['score_thr'])
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + '.npz'), **out)
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    only__ = sys.argv[1:] or None
+    for name, case in KM3D_CASES.items():
+        if only__ and name not in only__:
+            continue
+        run_km3d_case(name, case)
     only_ = sys.argv[1:] or None
     for name, case in MONO_CASES.items():
         if only_ and name not in only_:

@@ -43,6 +43,13 @@ class DcnParams(C.Structure):
     ]
 
 
+class Km3dParams(C.Structure):
+    _fields_ = [(n, c_void_p) for n in ('hm', 'wh', 'hps', 'rot', 'dim', 'prob', 'reg', 'hm_hp', 'hp_offset', 'P2', 'kconst')] + [
+        ('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('n_cls', C.c_int32), ('n_joints', C.c_int32), ('K', C.c_int32),
+        ('max_peaks', C.c_int32), ('img_h', C.c_int32), ('img_w', C.c_int32), ('score_thr', c_float), ('nms_iou_thr', c_float),
+        ('workspace', c_void_p), ('out_scores', c_void_p), ('out_boxes', c_void_p), ('out_cls', c_void_p), ('out_count', c_void_p)]
+
+
 class HeadParams(C.Structure):
     _fields_ = [
         ('cls', c_void_p), ('reg', c_void_p), ('anchors', c_void_p), ('prior_mean_std', c_void_p), ('P2', c_void_p),
@@ -85,6 +92,11 @@ SIGNATURES = {
     'vd3d_dcn_pack_weight': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'vd3d_deform_conv': (c_int, [C.POINTER(DcnParams), c_void_p]),
     'vd3d_look_ground_sample': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_int, c_void_p]),
+    'vd3d_pack_image_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'vd3d_maxpool2x2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
+    'vd3d_dwconv_transpose': (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
+    'vd3d_km3d_workspace_bytes': (c_int64, [c_int] * 5),
+    'vd3d_km3d_decode': (c_int, [C.POINTER(Km3dParams), c_void_p]),
 }
 # declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)
 PENDING = {

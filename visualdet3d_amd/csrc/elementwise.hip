@@ -338,3 +338,148 @@ extern "C" int vd3d_look_ground_sample(const void* x, const float* disp, const f
                                              (const T*)x, disp, P2s, (T*)out, B, H, W, C, Cpad, ips, ops, baseline, elevation));
     return vd3d_check_launch("look_ground_sample");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// DLA helpers (backbones/dla.py, dla_utils.py): 2x2/s2 max-pool (Tree.downsample), depth-wise ConvTranspose2d
+// (IDAUp.up_i: kernel 2f, stride f, pad f/2, groups = C, no bias) fused with the following `+ layers[i-1]`.
+namespace {
+template <typename T>
+__global__ void maxpool2x2_kernel(const T* __restrict__ in, T* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int ips, int ops) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int cv = C / VE;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t pix = i / cv;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        float m[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) m[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                Vec16<T> v;
+                v.raw = *(const i32x4*)(in + (((int64_t)b * H + oy * 2 + dy) * W + ox * 2 + dx) * ips + c);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) m[e] = fmaxf(m[e], v.get(e));
+            }
+        Vec16<T> o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, m[2 * e], m[2 * e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, m[e]);
+        }
+        *(i32x4*)(out + pix * ops + c) = o.raw;
+    }
+}
+
+// out[b,y,x,c] = sum_{ky,kx} in[b,(y+pad-ky)/f,(x+pad-kx)/f,c] * w[ky*K+kx][c]  (terms with exact division, in range)
+//                (+ add[b,y,x,c]);  weight layout [K*K][C] fp32
+template <typename T>
+__global__ void dwconvT_kernel(const T* __restrict__ in, const float* __restrict__ w, const T* __restrict__ add, T* __restrict__ out,
+                               int B, int H, int W, int C, int f, int K, int pad, int Ho, int Wo, int ips, int aps, int ops) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    const int cv = C / VE;
+    const int64_t total = (int64_t)B * Ho * Wo * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t pix = i / cv;
+        const int x = (int)(pix % Wo), y = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+        float s[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s[e] = 0.f;
+        // torch's conv_transpose accumulates input-major; the order of the (at most ceil(K/f)^2) terms differs only in
+        // fp32 round-off
+        for (int ky = (y + pad) % f; ky < K; ky += f) {
+            const int iy = (y + pad - ky) / f;
+            if (y + pad - ky < 0 || iy >= H) continue;
+            for (int kx = (x + pad) % f; kx < K; kx += f) {
+                const int ix = (x + pad - kx) / f;
+                if (x + pad - kx < 0 || ix >= W) continue;
+                Vec16<T> v;
+                v.raw = *(const i32x4*)(in + (((int64_t)b * H + iy) * W + ix) * ips + c);
+                const float* wt = w + (ky * K + kx) * C + c;
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] = fmaf(v.get(e), wt[e], s[e]);
+            }
+        }
+        Vec16<T> o;
+        if constexpr (sizeof(T) == 2) {
+            // the reference rounds the up-sampled map (a tensor) before adding: mimic (bf16 path) so rounding points match
+            if (add) {
+                Vec16<T> a; a.raw = *(const i32x4*)(add + pix * aps + c);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] = bf2f(f2bf(s[e])) + a.get(e);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, s[2 * e], s[2 * e + 1]);
+        } else {
+            if (add) {
+                Vec16<T> a; a.raw = *(const i32x4*)(add + pix * aps + c);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) s[e] += a.get(e);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, s[e]);
+        }
+        *(i32x4*)(out + pix * ops + c) = o.raw;
+    }
+}
+
+// NCHW fp32 image -> zero-bordered NHWC with `cpad` channels (3 real + zeros), general borders
+template <typename T, int CPAD>
+__global__ void pack_image_c_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int H, int W, int pad_y, int pad_l, int Hp, int Wp) {
+    const int64_t total = (int64_t)B * Hp * Wp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp), yp = (int)((i / Wp) % Hp), b = (int)(i / ((int64_t)Wp * Hp));
+        const int x = xp - pad_l, y = yp - pad_y;
+        float v[3] = {0.f, 0.f, 0.f};
+        if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+            const int64_t base = ((int64_t)b * 3 * H + y) * W + x;
+            v[0] = in[base]; v[1] = in[base + (int64_t)H * W]; v[2] = in[base + 2 * (int64_t)H * W];
+        }
+        T* o = out + i * CPAD;
+#pragma unroll
+        for (int c = 0; c < CPAD; ++c) o[c] = ElemTraits<T>::from_f(c < 3 ? v[c] : 0.f);
+    }
+}
+}  // namespace
+
+extern "C" int vd3d_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int ips, int ops, int dtype, void* stream) {
+    if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("maxpool2x2: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(maxpool2x2_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)in, (T*)out, B, H, W, C, Ho, Wo, ips, ops));
+    return vd3d_check_launch("maxpool2x2");
+}
+
+extern "C" int vd3d_dwconv_transpose(const void* in, const float* weight, const void* add, void* out, int B, int H, int W, int C,
+                                     int f, int ips, int aps, int ops, int dtype, void* stream) {
+    if (!vec_ok(dtype, C, ips, ops, in, out) || !weight || f < 1 || (add && (((uintptr_t)add & 15) || aps % (dtype == VD3D_BF16 ? 8 : 4)))) {
+        vd3d_set_error("dwconv_transpose: bad args"); return VD3D_EINVAL;
+    }
+    const int K = 2 * f, pad = f / 2;
+    const int Ho = (H - 1) * f - 2 * pad + K, Wo = (W - 1) * f - 2 * pad + K;
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    VD3D_DISPATCH(dtype, hipLaunchKernelGGL(dwconvT_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                                             (const T*)in, weight, (const T*)add, (T*)out, B, H, W, C, f, K, pad, Ho, Wo, ips, aps, ops));
+    return vd3d_check_launch("dwconv_transpose");
+}
+
+extern "C" int vd3d_pack_image_nhwc(const float* in, void* out, int B, int H, int W, int pad_y0, int pad_y1, int pad_l, int pad_r,
+                                    int cpad, int dtype, void* stream) {
+    if (!in || !out || (cpad != 4 && cpad != 8)) { vd3d_set_error("pack_image_nhwc: cpad must be 4 or 8"); return VD3D_EINVAL; }
+    const int Hp = H + pad_y0 + pad_y1, Wp = W + pad_l + pad_r;
+    const int64_t total = (int64_t)B * Hp * Wp;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == VD3D_BF16 && cpad == 8) hipLaunchKernelGGL((pack_image_c_kernel<short, 8>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (short*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
+    else if (dtype == VD3D_BF16) hipLaunchKernelGGL((pack_image_c_kernel<short, 4>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (short*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
+    else if (dtype == VD3D_F32 && cpad == 8) hipLaunchKernelGGL((pack_image_c_kernel<float, 8>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (float*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
+    else if (dtype == VD3D_F32) hipLaunchKernelGGL((pack_image_c_kernel<float, 4>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (float*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
+    else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }
+    return vd3d_check_launch("pack_image_nhwc");
+}

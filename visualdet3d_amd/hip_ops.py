@@ -433,3 +433,88 @@ def deform_conv_forward_nchw(x, weight, bias, offset, mask, stride, padding, dil
                                               stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
                                               groups, deformable_groups, _stream()), 'vd3d_deform_conv_forward')
     return out
+
+
+# --------------------------------------------------------------------------------------------- 3-channel image convs
+def pack_image_conv(weight, bn, dtype, stride, pad):
+    """k x k conv on a 3-channel image (ResNet stem 7x7/s2, DLA base layer 7x7/s1) as a (k x 1)-tap implicit GEMM over
+    rows of 8 px x cpad channels of a zero-bordered NHWC-cpad image (vd3d_pack_image_nhwc).  cpad is chosen so that every
+    output column starts a 16-byte aligned run: 4 for fp32 or stride 2, 8 for bf16 at stride 1."""
+    O, I, kh, kw = weight.shape
+    assert I == 3 and kh == kw and kw <= 8
+    cpad = 4 if (dtype == torch.float32 or stride % 2 == 0) else 8
+    dev = weight.device
+    w = torch.zeros((O, kh, 8, cpad), dtype=torch.float32, device=dev)
+    w[:, :, :kw, :3] = weight.detach().float().permute(0, 2, 3, 1)
+    row = 8 * cpad
+    K = kh * row
+    bke = 64 if dtype == torch.bfloat16 else 32
+    Kpad = (K + bke - 1) // bke * bke
+    CoutPad = (O + 127) // 128 * 128
+    packed = torch.zeros((CoutPad, Kpad), dtype=dtype, device=dev)
+    packed[:O, :K] = w.reshape(O, K).to(dtype)
+    scale, shift = fold_bn(None, bn, O, dev)
+    pc = PackedConv(packed, scale, shift, row, O, kh, 1, stride, 0, 1, Kpad, CoutPad, dtype)
+    pc.cpad, pc.k, pc.img_pad = cpad, kh, pad
+    return pc
+
+
+def image_conv(img_nchw, pc, relu=True):
+    _require_cuda(img_nchw)
+    B, Cc, H, W = img_nchw.shape
+    assert Cc == 3 and img_nchw.dtype == torch.float32 and img_nchw.is_contiguous()
+    dtype, k, s, p, cpad = pc.dtype, pc.k, pc.stride, pc.img_pad, pc.cpad
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    pad_r = max(p, (Wo - 1) * s + 8 - W - p)
+    Wp = W + p + pad_r
+    if (Wp * cpad * packed_elem_size(dtype)) % 16:
+        pad_r += 1
+        Wp += 1
+    pad_b = max(p, (Ho - 1) * s + k - H - p)
+    Hp = H + p + pad_b
+    packed = torch.empty((B, Hp, Wp, cpad), dtype=dtype, device=img_nchw.device)
+    check(_lib.lib().vd3d_pack_image_nhwc(_p(img_nchw), _p(packed), B, H, W, p, pad_b, p, pad_r, cpad, dtype_code(dtype), _stream()),
+          'vd3d_pack_image_nhwc')
+    out = torch.empty((B, Ho, Wo, pc.Cout), dtype=dtype, device=img_nchw.device)
+    q = ConvParams()
+    q.in_, q.weight, q.out = packed.data_ptr(), pc.w.data_ptr(), out.data_ptr()
+    q.scale = pc.scale.data_ptr() if pc.scale is not None else None
+    q.shift = pc.shift.data_ptr()
+    q.B, q.H, q.W, q.Cin = B, Hp, Wp, 8 * cpad
+    q.in_pix_stride, q.in_row_stride, q.in_batch_stride = cpad, Wp * cpad, Hp * Wp * cpad
+    q.in_bytes = _bytes_from(packed)
+    q.Ho, q.Wo, q.Cout = Ho, Wo, pc.Cout
+    q.out_pix_stride = pc.Cout
+    q.kh, q.kw, q.stride, q.pad, q.dil = k, 1, s, 0, 1
+    q.Kpad, q.CoutPad, q.relu = pc.Kpad, pc.CoutPad, int(relu)
+    q.dtype, q.out_f32 = dtype_code(dtype), 0
+    check(_lib.lib().vd3d_conv2d_igemm(C.byref(q), _stream()), 'vd3d_conv2d_igemm(image)')
+    return out
+
+
+def packed_elem_size(dtype):
+    return 2 if dtype == torch.bfloat16 else 4
+
+
+def maxpool2x2(x):
+    _require_cuda(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+    assert _dense_pixels(x)
+    check(_lib.lib().vd3d_maxpool2x2(_p(x), _p(out), B, H, W, Cc, x.stride(2), out.stride(2), dtype_code(x.dtype), _stream()),
+          'vd3d_maxpool2x2')
+    return out
+
+
+def dwconv_transpose(x, weight_kk_c, f, add=None):
+    """Depth-wise ConvTranspose2d(kernel 2f, stride f, pad f//2) (+ add).  weight_kk_c: [(2f)^2][C] fp32."""
+    _require_cuda(x, weight_kk_c, add)
+    B, H, W, Cc = x.shape
+    K, pad = 2 * f, f // 2
+    Ho, Wo = (H - 1) * f - 2 * pad + K, (W - 1) * f - 2 * pad + K
+    out = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    assert _dense_pixels(x) and (add is None or (add.shape == out.shape and _dense_pixels(add)))
+    check(_lib.lib().vd3d_dwconv_transpose(_p(x), _p(weight_kk_c), _p(add), _p(out), B, H, W, Cc, f, x.stride(2),
+                                           add.stride(2) if add is not None else 0, out.stride(2), dtype_code(x.dtype), _stream()),
+          'vd3d_dwconv_transpose')
+    return out

@@ -1,0 +1,140 @@
+"""``KM3DHead`` (heads/km3d_head.py:22-357) -- inference path -- with the reference's parameter names.
+
+Forward: the nine heads' 3x3 convs share one input, so they run as ONE implicit GEMM 64 -> 9*256 (+bias, ReLU); the nine
+1x1 output convs read their 256-channel slice of that buffer and write fp32 maps ``[B,H,W,n]`` (NHWC).
+Decode (``_decode`` :155-252, ``get_bboxes`` :255-314, rtm3d_utils ``_nms/_topk/_topk_channel/gen_position``): three
+kernels (csrc/km3d_decode.hip) -- peak extraction (sigmoid + 3x3 max test), per-channel top-K, and one workgroup per sample
+doing class merge, gathers, keypoint association, the fp64 16x3 least squares, re-projection, clip, score mask and NMS.
+The only host sync is reading the detection counts."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from ... import _lib
+from ... import hip_ops as ops
+from ...utils.config import EasyDict
+from ..lib import fused
+from ..utils.utils import ClipBoxes
+
+
+class _PositionLossStub(nn.Module):
+    """Holds the ``const`` buffer the reference's Position_loss registers (rtm3d_utils.py:234-237): checkpoint-key parity."""
+
+    def __init__(self):
+        super(_PositionLossStub, self).__init__()
+        self.register_buffer('const', torch.Tensor([[-1, 0], [0, -1]] * 8).unsqueeze(0).unsqueeze(0))
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('training losses are out of scope of the inference path')
+
+
+class KM3DHead(nn.Module):
+    TOPK = 100
+
+    def __init__(self, num_classes: int = 3, num_joints: int = 9, max_objects: int = 32, layer_cfg=EasyDict(),
+                 loss_cfg=EasyDict(), test_cfg=EasyDict()):
+        super(KM3DHead, self).__init__()
+        self._init_layers(**layer_cfg)
+        self.position_loss = _PositionLossStub()
+        self.rampup_length = getattr(loss_cfg, 'rampup_length', 100)
+        self.test_cfg = test_cfg
+        const = torch.Tensor([[-1, 0], [0, -1]] * 8).unsqueeze(0).unsqueeze(0)
+        self.register_buffer('const', const)
+        self.num_classes, self.num_joints, self.max_objects = num_classes, num_joints, max_objects
+        self.clipper = ClipBoxes()
+        self._cache = fused.PackCache()
+        self.max_peaks = 8192      # per (sample, heat-map channel) capacity of the peak list (LDS sort size)
+        self._workspace = None
+
+    def _init_layers(self, input_features=256, head_features=64, head_dict=dict(), **kwargs):
+        self.head_layers = nn.ModuleDict()
+        for head_name, num_output in head_dict.items():
+            self.head_layers[head_name] = nn.Sequential(
+                nn.Conv2d(input_features, head_features, 3, padding=1, bias=True),
+                nn.ReLU(inplace=True),
+                nn.Conv2d(head_features, num_output, 1))
+            out = self.head_layers[head_name][-1]
+            if 'hm' in head_name:
+                nn.init.constant_(out.bias, -2.19)
+            else:
+                nn.init.normal_(out.weight, std=0.001)
+                nn.init.constant_(out.bias, 0)
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def forward_nhwc(self, x):
+        dt = x.dtype
+        names = list(self.head_layers.keys())
+        firsts = [self.head_layers[n][0] for n in names]
+
+        def build_first():
+            w = torch.cat([c.weight.detach().float() for c in firsts], dim=0)
+            b = torch.cat([c.bias.detach().float() for c in firsts], dim=0)
+            return ops.pack_conv(w, b, None, dt, 1, 1, 1)
+
+        srcs = [t for c in firsts for t in (c.weight, c.bias)]
+        pc = self._cache.get(('first', dt), srcs, build_first)
+        mid = ops.conv2d(x, pc, relu=True)                    # [B,H,W,9*F]
+        F_ = firsts[0].out_channels
+        ret = {}
+        for i, n in enumerate(names):
+            conv = self.head_layers[n][2]
+            pco = self._cache.get((n, dt), [conv.weight, conv.bias], lambda conv=conv: ops.pack_conv(conv.weight, conv.bias, None, dt, 1, 0, 1))
+            ret[n] = ops.conv2d(mid[..., i * F_:(i + 1) * F_], pco, relu=False, out_f32=True)   # fp32 [B,H,W,n]
+        return ret
+
+    def forward(self, x):
+        """Reference signature: NCHW fp32 features -> dict of NCHW fp32 maps."""
+        return {k: v.permute(0, 3, 1, 2).contiguous() for k, v in self.forward_nhwc(fused.to_nhwc(x)).items()}
+
+    # ---- decode --------------------------------------------------------------------------------------------------
+    def get_bboxes_batched(self, maps, P2, img_hw):
+        """maps: dict of fp32 NHWC tensors.  Returns padded device tensors (scores [B,K], boxes [B,K,11], cls [B,K] i32,
+        count [B] i32) -- no host sync."""
+        from ..._lib import Km3dParams
+        hm = maps['hm']
+        B, H, W, ncls = hm.shape
+        dev = hm.device
+        K = self.TOPK
+        J = self.num_joints
+        need = _lib.lib().vd3d_km3d_workspace_bytes(B, ncls, J, self.max_peaks, K)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        scores = torch.empty((B, K), dtype=torch.float32, device=dev)
+        boxes = torch.empty((B, K, 11), dtype=torch.float32, device=dev)
+        cls = torch.empty((B, K), dtype=torch.int32, device=dev)
+        count = torch.empty((B,), dtype=torch.int32, device=dev)
+        P2 = P2.to(device=dev, dtype=torch.float32).contiguous()
+        p = Km3dParams()
+        for name in ('hm', 'wh', 'hps', 'rot', 'dim', 'prob', 'reg', 'hm_hp', 'hp_offset'):
+            t = maps[name]
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.shape[:3] == (B, H, W)
+            setattr(p, name, t.data_ptr())
+        assert maps['hps'].shape[3] == 2 * J and maps['hm_hp'].shape[3] == J and maps['rot'].shape[3] == 8
+        p.P2 = P2.data_ptr()
+        kconst = self.const.detach().to(device=dev, dtype=torch.float32).contiguous()
+        p.kconst = kconst.data_ptr()
+        p.B, p.H, p.W, p.n_cls, p.n_joints, p.K, p.max_peaks = B, H, W, ncls, J, K, self.max_peaks
+        p.img_h, p.img_w = int(img_hw[0]), int(img_hw[1])
+        p.score_thr = float(getattr(self.test_cfg, 'score_thr', 0.1))
+        p.nms_iou_thr = float(getattr(self.test_cfg, 'nms_iou_thr', 0.5))
+        p.workspace = self._workspace.data_ptr()
+        p.out_scores, p.out_boxes, p.out_cls, p.out_count = scores.data_ptr(), boxes.data_ptr(), cls.data_ptr(), count.data_ptr()
+        _lib.check(_lib.lib().vd3d_km3d_decode(C.byref(p), ops._stream()), 'vd3d_km3d_decode')
+        return scores, boxes, cls, count
+
+    @staticmethod
+    def unpad(padded):
+        scores, boxes, cls, count = padded
+        outs = []
+        for b, k in enumerate(count.tolist()):
+            if k < 0:
+                raise RuntimeError('sample %d: more heat-map peaks than KM3DHead.max_peaks' % b)
+            outs.append((scores[b, :k], boxes[b, :k], cls[b, :k].long().unsqueeze(1)))
+        return outs
+
+    def get_bboxes(self, output: dict, P2, img_batch=None):
+        """Reference signature: ``output`` = dict of NCHW fp32 maps (as returned by ``forward``), batch 1."""
+        maps = {k: v.permute(0, 2, 3, 1).contiguous().float() for k, v in output.items()}
+        assert img_batch is not None
+        return self.unpad(self.get_bboxes_batched(maps, P2, img_batch.shape[2:]))[0]

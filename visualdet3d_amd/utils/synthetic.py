@@ -81,6 +81,25 @@ def mono3d_cfg(preprocessed_path, depth=34, obj_types=('Car',), score_thr=0.75, 
     return det
 
 
+def km3d_cfg(obj_types=('Car', 'Pedestrian', 'Cyclist'), score_thr=0.3, output_w=320):
+    """``cfg.detector`` for KM3D with the DLA-34 + DLA-Up core (config/KM3D_example:126-167 head; backbone as in
+    config/Monoflex_example:129-131 -- KM3DCore needs ``backbone.name``)."""
+    obj_types = list(obj_types)
+    det = EasyDict()
+    det.obj_types = obj_types
+    det.name = 'KM3D'
+    det.backbone = EasyDict(name='dlanet', depth=34, pretrained=None, out_indices=(0, 1, 2, 3, 4, 5))
+    head_loss = EasyDict(gamma=2.0, rampup_length=100, output_w=output_w)
+    head_test = EasyDict(score_thr=score_thr)
+    head_layer = EasyDict(input_features=64, head_features=256,
+                          head_dict={'hm': len(obj_types), 'wh': 2, 'hps': 18, 'rot': 8, 'dim': 3, 'prob': 1, 'reg': 2,
+                                     'hm_hp': 9, 'hp_offset': 2})
+    det.head = EasyDict(num_classes=len(obj_types), num_joints=9, max_objects=32, layer_cfg=head_layer, loss_cfg=head_loss,
+                        test_cfg=head_test)
+    det.loss = head_loss
+    return det
+
+
 # --------------------------------------------------------------------------------------------- priors
 def write_synthetic_priors(preprocessed_path, obj_types, n_ratios, n_scales=16):
     """Write ``anchor_{mean,std}_{type}.npy`` under ``<preprocessed_path>/training``.
@@ -160,15 +179,18 @@ def seeded_state_dict(state_dict, seed=1, head_bias=-1.0, head_std=0.006):
                 a = rng.normal(0.0, head_std, shape)
             else:
                 fan = int(np.prod(shape[2:])) * shape[0]
-                a = rng.normal(0.0, np.sqrt(2.0 / fan), shape)
+                gain = 6.0 if ('head_layers.' in k and k.endswith('.2.weight')) else 1.0   # KM3D 1x1 output convs
+                a = rng.normal(0.0, gain * np.sqrt(2.0 / fan), shape)
         elif leaf == 'bias' and len(shape) == 1:
             if k.endswith('cls_feature_extraction.6.bias'):
                 a = np.full(shape, head_bias)
+            elif k.endswith('head_layers.hm.2.bias') or k.endswith('head_layers.hm_hp.2.bias'):
+                a = np.full(shape, -2.19)      # CenterNet-style heat-map prior (heads/km3d_head.py:146-148)
             else:
                 a = rng.normal(0.0, 0.01, shape)
         elif leaf == 'alpha':  # LookGround.alpha is 0-initialised (look_ground.py:22) -> module is a no-op
             a = np.full(shape, 0.5)
-        elif leaf in ('balance_weights', 'regression_weight'):
+        elif leaf in ('balance_weights', 'regression_weight', 'const'):
             out[k] = v.detach().clone().cpu().float()
             continue
         else:
