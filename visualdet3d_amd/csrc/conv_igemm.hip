@@ -67,11 +67,11 @@ template <> struct Mma<float> {
 
 // ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store ------------------------------------------------
 template <typename T, int TM, int TN, int WTM, int WTN>
-VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], int m0, int n0, int wm, int wn, int lr, int half) {
+VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int half) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * WTM + j * 32 + lr;
-        if (m >= p.M) continue;
+        const int m = mrow[j];      // flat output pixel index of this lane for accumulator column j, or -1
+        if (m < 0) continue;
         const int64_t obase = (int64_t)m * p.out_pix_stride;
         const int64_t rbase = (int64_t)m * p.res_pix_stride;
 #pragma unroll
@@ -279,7 +279,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
         __syncthreads();
     }
 
-    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lr, half);
+    int mrow[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WTM + j * 32 + lr;
+        mrow[j] = m < p.M ? m : -1;
+    }
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
 }
 
 // =====================================================================================================
@@ -415,7 +421,189 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, m0, n0, wm, wn, lr, half);
+    int mrow[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * WTM + j * 32 + lr;
+        mrow[j] = m < p.M ? m : -1;
+    }
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
+}
+
+// =====================================================================================================
+// v3 "halo" kernel for 3x3 / stride 1 / pad 1 convolutions (95 % of the FLOPs of every detector here).
+// In the implicit-GEMM view the pixel operand of tap (ky,kx) is the same activation shifted by one pixel, so the v2
+// kernel re-fetches every input pixel 9 times into LDS (once per tap).  LDS fill bandwidth (L2 -> LDS DMA) is what bounds
+// the small-channel layers (layer1: ~52 flop per filled byte).  Here the workgroup owns a TH x TW patch of output pixels
+// of one image and stages, per 64-channel chunk, the (TH+2) x (TW+2) input halo ONCE; the nine taps read their pixel
+// fragments from the halo at shifted rows.  K is walked chunk-outer / tap-inner (the packed weight layout
+// K = tap*Cin + c already makes every (chunk, tap) slice a contiguous 128-byte run).  Fill traffic per 64-channel
+// chunk drops from 9*(BM + BN) rows to ~1.3*BM + 9*BN rows.
+template <int N> VD3D_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int TH, int TW, int BN, int WARPS_M, int WARPS_N, int STAGES>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const ConvArgs p) {
+    constexpr int NW = WARPS_M * WARPS_N;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VE = 16 / ES;
+    constexpr int BKE = 128 / ES;
+    constexpr int BM = TH * TW;
+    constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int HW2 = TW + 2;
+    constexpr int HR = (TH + 2) * HW2;                 // halo pixels
+    constexpr int H_PIECES_TOT = (HR + 7) / 8;
+    constexpr int H_PIECES = (H_PIECES_TOT + NW - 1) / NW;
+    constexpr int W_PIECES = BN / 8 / NW;               // identical for every wave: the counted vmcnt below relies on it
+    constexpr int H_STAGE = H_PIECES_TOT * 1024, W_STAGE = BN * 128;
+    static_assert(BM % (32 * WARPS_M) == 0 && BN % (32 * WARPS_N) == 0 && (8 * NW) % 16 == 0, "tile shape");
+    static_assert((BN / 8) % NW == 0 && STAGES >= 2 && (STAGES - 2) * W_PIECES <= 63, "weight pieces per wave / vmcnt range");
+    static_assert((TW & (TW - 1)) == 0, "TW must be a power of two");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Hs = smem;                       // 2 halo stages
+    char* Ws = smem + 2 * H_STAGE;         // STAGES weight stages (ring)
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int b = tile_m / (tiles_x * tiles_y), trem = tile_m - b * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+    const int n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+
+    // ---- DMA lane state ---------------------------------------------------------------------------------
+    const int prow = lane >> 3;
+    const int slot = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    uint32_t h_off[H_PIECES];   // byte offset of this lane's halo pixel (channel 0 of the slice, logical slot), or OOB
+#pragma unroll
+    for (int it = 0; it < H_PIECES; ++it) {
+        const int hr = 8 * (wave + it * NW) + prow;
+        const int hy = hr / HW2, hx = hr - hy * HW2;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        const bool v = hr < HR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        h_off[it] = v ? (uint32_t)((int)(b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + slot * VE) * ES : kOOB;
+    }
+    const uint32_t w_base = (uint32_t)(((n0 + 8 * wave + prow) * p.Kpad + slot * VE) * ES);
+
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.weight, 0, p.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    auto issue_halo = [&](int chunk) {
+        char* base = Hs + (chunk & 1) * H_STAGE + wave * 1024;
+        const uint32_t coff = (uint32_t)(chunk * BKE * ES);
+#pragma unroll
+        for (int it = 0; it < H_PIECES; ++it) {
+            if (H_PIECES_TOT % NW == 0 || wave + it * NW < H_PIECES_TOT) {
+                const uint32_t off = h_off[it] == kOOB ? kOOB : h_off[it] + coff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + it * NW * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int step) {     // step = chunk * 9 + tap
+        const int chunk = step / 9, tap = step - chunk * 9;
+        char* base = Ws + (step % STAGES) * W_STAGE + wave * 1024;
+        const uint32_t koff = (uint32_t)((tap * p.Cin + chunk * BKE) * ES);
+#pragma unroll
+        for (int it = 0; it < W_PIECES; ++it)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + it * NW * 1024), 16,
+                                                     w_base + koff + (uint32_t)(it * NW * 8 * p.Kpad * ES), 0, 0, 0);
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int lr = lane & 31, half = lane >> 5;
+    int hrow0[TM];   // halo row of this lane's pixel for tap (0,0)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int pp = wm * WTM + j * 32 + lr;
+        hrow0[j] = (pp / TW) * HW2 + (pp & (TW - 1));
+    }
+    auto compute = [&](int hst, int wst, int tap) {
+        const char* Hb = Hs + hst * H_STAGE;
+        const char* Wb = Ws + wst * W_STAGE;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int shift = dy * HW2 + dx;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int sk = 2 * ks + half;
+            i32x4 fa[TN], fb[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int row = wn * WTN + i * 32 + lr;
+                fa[i] = *(const i32x4*)(Wb + row * 128 + ((sk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int row = hrow0[j] + shift;
+                fb[j] = *(const i32x4*)(Hb + row * 128 + ((sk ^ ((row >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+    };
+
+    // ---- STAGES-deep weight ring with a COUNTED vmcnt: at step t only W(t) (and everything older, incl. the halo issued
+    // nine steps earlier) must have landed; the DMAs of steps t+1 .. t+STAGES-2 stay in flight across the barrier, so the
+    // L2 -> LDS latency (several hundred cycles) is covered by STAGES-2 slices of MFMA work instead of one.
+    const int nchunk = p.Cin / BKE;
+    const int nsteps = nchunk * 9;
+    issue_halo(0);
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0)
+        if (s0 < nsteps) issue_w(s0);
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + STAGES - 2 < nsteps) wait_vmcnt<(STAGES - 2) * W_PIECES>();
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int chunk = step / 9, tap = step - chunk * 9;
+        if (tap == 0 && chunk + 1 < nchunk) issue_halo(chunk + 1);
+        if (step + STAGES - 1 < nsteps) issue_w(step + STAGES - 1);
+        compute(chunk & 1, step % STAGES, tap);
+    }
+    int mrow[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int pp = wm * WTM + j * 32 + lr;
+        const int y = ty0 + pp / TW, x = tx0 + (pp & (TW - 1));
+        mrow[j] = (y < p.H && x < p.W) ? (b * p.H + y) * p.W + x : -1;
+    }
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
+}
+
+template <typename T, int TH, int TW, int BN, int WARPS_M, int WARPS_N, int STAGES = 4>
+int launch_halo(ConvArgs& a, hipStream_t stream) {
+    constexpr int NT = WARPS_M * WARPS_N * 64;
+    constexpr int HR = (TH + 2) * (TW + 2);
+    constexpr int LDS = 2 * ((HR + 7) / 8) * 1024 + STAGES * BN * 128;
+    static_assert(LDS <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
+    a.tiles_m = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    static bool attr_done = false;
+    auto kern = conv_halo_kernel<T, TH, TW, BN, WARPS_M, WARPS_N, STAGES>;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return vd3d_check_launch("hipFuncSetAttribute(conv_halo)");
+        attr_done = true;
+    }
+    const int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
+    if (grid <= 0 || grid > 0x7fffffff) return VD3D_EINVAL;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS, stream, a);
+    return vd3d_check_launch("conv_halo");
 }
 
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false>
@@ -456,10 +644,32 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 12: return launch<T, 256, 256, 8, 1, true>(a, stream);
         case 13: return launch<T, 128, 352, 4, 1, true>(a, stream);
+        case 20: return launch_halo<T, 8, 32, 64, 8, 1, 4>(a, stream);
+        case 21: return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
+        case 22: return launch_halo<T, 8, 32, 128, 8, 1, 4>(a, stream);
+        case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
+        case 24: return launch_halo<T, 8, 16, 256, 4, 2, 3>(a, stream);
+        case 25: return launch_halo<T, 8, 16, 128, 4, 1, 4>(a, stream);
+        case 26: return launch_halo<T, 8, 16, 64, 4, 1, 6>(a, stream);
+        case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
+        case 28: return launch_halo<T, 8, 32, 64, 8, 1, 6>(a, stream);
+        case 29: return launch_halo<T, 8, 16, 128, 4, 1, 6>(a, stream);
         default: break;
     }
     if (a.Cout <= 32) return launch<T, 256, 32, 4, 1, true>(a, stream);
     if (a.Cout <= 64) return launch<T, 256, 64, 4, 1, true>(a, stream);
+    // 3x3 / stride 1 / pad 1 with 64-channel-aligned input: the halo kernel (each input pixel staged once per channel
+    // chunk instead of once per tap) wins on the mid-size layers (measured on MI355X, bf16):
+    //   Cout <= 128 (layer2-like): 8x32 patch x 128 channels          +6 %
+    //   Cout == 256, short K (layer3-like): 8x16 patch x 256 channels +10 %
+    //   Cout == 256, long K (1408 -> 256 cls conv): 8x16 patch x 128  +60 %
+    const bool halo_ok = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W &&
+                         a.Cin % (128 / (int)sizeof(T)) == 0 && a.H % 8 == 0 && a.W % 16 == 0;
+    if (halo_ok && a.Cout <= 128 && a.Cout % 128 == 0 && a.W % 32 == 0) return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
+    if (halo_ok && a.Cout == 256) {
+        if (a.Cin >= 1024) return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
+        return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
+    }
     // Tile choice by modelled throughput = full-occupancy rate of the tile shape (measured on MI355X, bf16 TFLOP/s)
     // x tile-edge waste x last-round occupancy.  Candidates: 128x128 (2 workgroups/CU), 256x256 (8 waves of 128x64,
     // 1/CU), and "column strips" 256xBN / 128xBN with BN = 288 | 352 (= 1152/4, 1408/4: every wave owns 32 pixels x
