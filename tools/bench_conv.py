@@ -25,7 +25,7 @@ for name, B, H, W, Cin, Cout in SHAPES:
     ref = None
     line = '%-18s' % name
     for c in cfgs:
-        if (Cout <= 64 and c in (1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 21, 22, 23, 24, 25, 27)) or (Cout > 64 and c in (20, 26, 28)) or (Cout <= 64 and c == 29) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and c >= 20):
+        if (Cout <= 64 and c in (1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 21, 22, 23, 24, 25, 27)) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 128 and c == 33) or (Cout <= 64 and c == 29) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and c >= 20):
             line += '  cfg%d    --   ' % c
             continue
         _lib.lib().vd3d_conv2d_set_tuning(c)

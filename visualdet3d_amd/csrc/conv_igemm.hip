@@ -42,7 +42,7 @@ struct ConvArgs {
     int kh, kw, stride, pad, dil;
     int Kpad, relu, out_f32;
     int M, tiles_m, tiles_n, ntaps, nk;
-    int vec_epilogue;
+    int vec_epilogue, wide_store;
 };
 
 constexpr uint32_t kOOB = 0x80000000u;  // byte offset guaranteed >= num_records (host enforces in_bytes < 2^31)
@@ -66,75 +66,108 @@ template <> struct Mma<float> {
 };
 
 // ---- epilogue: scale/shift (+residual) (+ReLU), NHWC store ------------------------------------------------
+// Accumulator layout (32x32 MFMA, weights = A operand): lane (lr, half) holds, for accumulator quad g, the 4 consecutive
+// output channels 8g + 4*half .. +3 of pixel lr.  bf16 output: the two half-waves of a pixel hold adjacent 8-byte runs;
+// one v_permlane32_swap per dword pairs quads (g, g+1) so that every lane stores 16 contiguous bytes (half the store
+// instructions -- the store tail of short-K layers is issue-bound, cf. guide T21).
 template <typename T, int TM, int TN, int WTM, int WTN>
 VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int half) {
+    const bool f32_out = sizeof(T) == 4 || p.out_f32;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = mrow[j];      // flat output pixel index of this lane for accumulator column j, or -1
-        if (m < 0) continue;
-        const int64_t obase = (int64_t)m * p.out_pix_stride;
-        const int64_t rbase = (int64_t)m * p.res_pix_stride;
+        const bool mvalid = m >= 0;
+        const int64_t obase = (int64_t)(mvalid ? m : 0) * p.out_pix_stride;
+        const int64_t rbase = (int64_t)(mvalid ? m : 0) * p.res_pix_stride;
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
+            const int nt = n0 + wn * WTN + i * 32;     // wave-uniform
+            if (nt >= p.Cout) continue;
+            if (p.vec_epilogue) {
+                i32x2 packed[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nb = n0 + wn * WTN + i * 32 + 8 * g + 4 * half;
-                if (nb >= p.Cout) continue;
-                float v[4];
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = nt + 8 * g + 4 * half;
+                    const bool ok = mvalid && nb < p.Cout;
+                    float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (p.vec_epilogue) {
-                    if (p.scale) {
-                        const f32x4 s = *(const f32x4*)(p.scale + nb);
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    if (ok) {
+                        if (p.scale) {
+                            const f32x4 s = *(const f32x4*)(p.scale + nb);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= s[e];
-                    }
-                    if (p.shift) {
-                        const f32x4 s = *(const f32x4*)(p.shift + nb);
+                            for (int e = 0; e < 4; ++e) v[e] *= s[e];
+                        }
+                        if (p.shift) {
+                            const f32x4 s = *(const f32x4*)(p.shift + nb);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += s[e];
-                    }
-                    if (p.residual) {
-                        if constexpr (sizeof(T) == 2) {
-                            const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
-                            const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
-                            v[0] += i2f((int)(r0 << 16));
-                            v[1] += i2f((int)(r0 & 0xffff0000u));
-                            v[2] += i2f((int)(r1 << 16));
-                            v[3] += i2f((int)(r1 & 0xffff0000u));
-                        } else {
-                            const f32x4 rr = *(const f32x4*)(p.residual + (rbase + nb) * 4);
+                            for (int e = 0; e < 4; ++e) v[e] += s[e];
+                        }
+                        if (p.residual) {
+                            if constexpr (sizeof(T) == 2) {
+                                const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
+                                const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
+                                v[0] += i2f((int)(r0 << 16));
+                                v[1] += i2f((int)(r0 & 0xffff0000u));
+                                v[2] += i2f((int)(r1 << 16));
+                                v[3] += i2f((int)(r1 & 0xffff0000u));
+                            } else {
+                                const f32x4 rr = *(const f32x4*)(p.residual + (rbase + nb) * 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                                for (int e = 0; e < 4; ++e) v[e] += rr[e];
+                            }
+                        }
+                        if (p.relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                        }
+                        if (f32_out) {
+                            f32x4 o = {v[0], v[1], v[2], v[3]};
+                            *(f32x4*)(p.out + (obase + nb) * 4) = o;
                         }
                     }
-                    if (p.relu) {
+                    packed[g][0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+                    packed[g][1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                }
+                if (!f32_out) {
+                    if (p.wide_store) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (sizeof(T) == 4 || p.out_f32) {
-                        f32x4 o = {v[0], v[1], v[2], v[3]};
-                        *(f32x4*)(p.out + (obase + nb) * 4) = o;
+                        for (int g = 0; g < 4; g += 2) {
+                            // x = quad g, y = quad g+1: after the swap the lower half-wave holds [own g | upper's g] and the
+                            // upper half-wave [lower's g+1 | own g+1]: 16 contiguous bytes each
+                            int x0 = packed[g][0], x1 = packed[g][1], y0 = packed[g + 1][0], y1 = packed[g + 1][1];
+                            auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                            auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                            const int nb16 = nt + 8 * (g + half);
+                            if (mvalid && nb16 < p.Cout) {
+                                i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
+                                *(i32x4*)(p.out + (obase + nb16) * 2) = o;
+                            }
+                        }
                     } else {
-                        i32x2 o;
-                        o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-                        o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
-                        *(i32x2*)(p.out + (obase + nb) * 2) = o;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int nb = nt + 8 * g + 4 * half;
+                            if (mvalid && nb < p.Cout) *(i32x2*)(p.out + (obase + nb) * 2) = packed[g];
+                        }
                     }
-                } else {
+                }
+            } else {
+                if (!mvalid) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int n = nb + e;
-                        if (n >= p.Cout) break;
-                        float x = v[e];
+                        const int n = nt + 8 * g + 4 * half + e;
+                        if (n >= p.Cout) continue;
+                        float x = acc[i][j][4 * g + e];
                         if (p.scale) x *= p.scale[n];
                         if (p.shift) x += p.shift[n];
                         if (p.residual) x += ElemTraits<T>::to_f(((const T*)p.residual)[rbase + n]);
                         if (p.relu) x = fmaxf(x, 0.f);
-                        if (sizeof(T) == 4 || p.out_f32) ((float*)p.out)[obase + n] = x;
+                        if (f32_out) ((float*)p.out)[obase + n] = x;
                         else ((short*)p.out)[obase + n] = f2bf(x);
                     }
-                }
             }
         }
     }
@@ -644,6 +677,12 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 12: return launch<T, 256, 256, 8, 1, true>(a, stream);
         case 13: return launch<T, 128, 352, 4, 1, true>(a, stream);
+        case 30: return launch<T, 128, 64, 4, 1, true>(a, stream);
+        case 31: return launch<T, 128, 64, 2, 2, true>(a, stream);
+        case 32: return launch<T, 64, 64, 2, 1, true>(a, stream);
+        case 33: return launch<T, 128, 128, 4, 1, true>(a, stream);
+        case 34: return launch_halo<T, 4, 32, 64, 4, 1, 4>(a, stream);
+        case 35: return launch_halo<T, 8, 16, 64, 2, 2, 4>(a, stream);
         case 20: return launch_halo<T, 8, 32, 64, 8, 1, 4>(a, stream);
         case 21: return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
         case 22: return launch_halo<T, 8, 32, 128, 8, 1, 4>(a, stream);
@@ -657,7 +696,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         default: break;
     }
     if (a.Cout <= 32) return launch<T, 256, 32, 4, 1, true>(a, stream);
-    if (a.Cout <= 64) return launch<T, 256, 64, 4, 1, true>(a, stream);
+    if (a.Cout <= 64) return launch<T, 128, 64, 4, 1, true>(a, stream);   // 48 KiB LDS -> 3 workgroups / CU (short K: latency bound)
     // 3x3 / stride 1 / pad 1 with 64-channel-aligned input: the halo kernel (each input pixel staged once per channel
     // chunk instead of once per tap) wins on the mid-size layers (measured on MI355X, bf16):
     //   Cout <= 128 (layer2-like): 8x32 patch x 128 channels          +6 %
@@ -756,6 +795,8 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
     a.vec_epilogue = (p->Cout % 4 == 0) && (p->out_pix_stride % 4 == 0) && (((uintptr_t)p->out % (4 * oes)) == 0) &&
                      (!p->residual || (p->res_pix_stride % 4 == 0 && ((uintptr_t)p->residual % (4 * es)) == 0)) &&
                      (!p->scale || ((uintptr_t)p->scale % 16) == 0) && (!p->shift || ((uintptr_t)p->shift % 16) == 0);
+    // 16-byte bf16 stores (half-wave pairing) need 16-channel groups inside Cout and 16-byte aligned rows
+    a.wide_store = a.vec_epilogue && oes == 2 && (p->Cout % 16 == 0) && (p->out_pix_stride % 8 == 0) && (((uintptr_t)p->out & 15) == 0);
     hipStream_t s = (hipStream_t)stream;
     return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : dispatch<float>(a, s);
 }
