@@ -42,7 +42,7 @@ struct ConvArgs {
     int kh, kw, stride, pad, dil;
     int Kpad, relu, out_f32;
     int M, tiles_m, tiles_n, ntaps, nk;
-    int vec_epilogue, wide_store;
+    int vec_epilogue, wide_store, chunk_major;
 };
 
 constexpr uint32_t kOOB = 0x80000000u;  // byte offset guaranteed >= num_records (host enforces in_bytes < 2^31)
@@ -374,13 +374,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             a_off[it] = 0;
         }
     }
+    // K walk.  Generic: tap-major (k = tap*Cin + c), works for any Cin.  When Cin is a multiple of the 128-byte slice
+    // (p.chunk_major) the slices are visited chunk-major / tap-minor instead: the kh*kw taps of one 64-channel chunk
+    // run back to back, so the shifted re-reads of the same input pixels hit L2 instead of going back to the fabric /
+    // Infinity Cache once per tap (measured on the 1408-channel layers: FETCH_SIZE 9x the algorithmic bytes before).
+    // The packed weight needs no re-ordering: slice (chunk, tap) is the contiguous run at k = tap*Cin + chunk*64.
     int kc = slot * VE, tap = 0, dy = 0, dx = 0;
     while (kc >= p.Cin) {
         kc -= p.Cin;
         ++tap;
         if (++dx == p.kw) { dx = 0; ++dy; }
     }
-    uint32_t w_off = (uint32_t)(((n0 + 8 * wave + prow) * p.Kpad + slot * VE) * ES);
+    const uint32_t w_row = (uint32_t)(((n0 + 8 * wave + prow) * p.Kpad + slot * VE) * ES);
+    uint32_t w_off = w_row;
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.weight, 0, p.w_bytes, 0x00020000);
@@ -403,12 +409,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + A_STAGE + it * NW * 1024), 16,
                                                          w_off + (uint32_t)(it * NW * 8 * p.Kpad * ES), 0, 0, 0);
         }
-        w_off += BKE * ES;
-        kc += BKE;
-        while (kc >= p.Cin) {
-            kc -= p.Cin;
+        if (p.chunk_major) {
             ++tap;
             if (++dx == p.kw) { dx = 0; ++dy; }
+            if (tap == p.ntaps) { tap = 0; dx = 0; dy = 0; kc += BKE; }
+            w_off = w_row + (uint32_t)((tap * p.Cin + kc - slot * VE) * ES);
+        } else {
+            w_off += BKE * ES;
+            kc += BKE;
+            while (kc >= p.Cin) {
+                kc -= p.Cin;
+                ++tap;
+                if (++dx == p.kw) { dx = 0; ++dy; }
+            }
         }
     };
 
@@ -797,6 +810,7 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
                      (!p->scale || ((uintptr_t)p->scale % 16) == 0) && (!p->shift || ((uintptr_t)p->shift % 16) == 0);
     // 16-byte bf16 stores (half-wave pairing) need 16-channel groups inside Cout and 16-byte aligned rows
     a.wide_store = a.vec_epilogue && oes == 2 && (p->Cout % 16 == 0) && (p->out_pix_stride % 8 == 0) && (((uintptr_t)p->out & 15) == 0);
+    a.chunk_major = (a.ntaps > 1) && (p->Cin % bke == 0);
     hipStream_t s = (hipStream_t)stream;
     return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : dispatch<float>(a, s);
 }
