@@ -71,7 +71,9 @@ def profile_convs(model, inputs, reps=3):
         o = orig(x, pc, out=out, residual=residual, relu=relu, out_f32=out_f32)
         e.record()
         B, Ho, Wo, Co = o.shape
-        records.append((2.0 * B * Ho * Wo * Co * pc.kh * pc.kw * pc.Cin, s, e))
+        nbytes = (x.shape[0] * x.shape[1] * x.shape[2] * pc.Cin * x.element_size() + pc.Cout * pc.kh * pc.kw * pc.Cin * x.element_size()
+                  + o.numel() * o.element_size() + (residual.numel() * residual.element_size() if residual is not None else 0))
+        records.append((2.0 * B * Ho * Wo * Co * pc.kh * pc.kw * pc.Cin, s, e, nbytes))
         return o
 
     ops.conv2d = timed
@@ -93,7 +95,7 @@ def profile_convs(model, inputs, reps=3):
             print('  conv %2d  %8.2f GF  %8.1f us  %7.1f TF/s' % (i, fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     flops = sum(r[0] for r in records) / reps
     secs = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3 / reps
-    return flops, secs, len(records) // reps
+    return flops, secs, len(records) // reps, sum(r[3] for r in records) / reps
 
 
 def cpu_baseline(cfg, sd, args):
@@ -206,7 +208,11 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        flops, secs, nl = profile_convs(model, inputs)
+        flops, secs, nl, alg_bytes = profile_convs(model, inputs)
+        traffic = None
+        pmc = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
+        if args.dtype == 'bf16' and B == 8 and os.path.exists(pmc):
+            traffic = json.load(open(pmc))['conv_hbm_bytes_per_forward']   # PMC pass of this same command, see profiles/
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         ach = flops / secs / 1e12
         line = {
@@ -219,7 +225,8 @@ def main():
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None},
             'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (all %d launches per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                         'traffic': None,
+                         'traffic': traffic, 'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
+                         'algorithmic_bytes': alg_bytes,
                          'whole_path_frac': round(value / world * GFLOP_PER_PAIR * (args.height * args.width) / (384 * 1280) / 1e3 / peak, 4)},
         }
         if not args.no_cpu_baseline:
