@@ -218,6 +218,18 @@ int vd3d_look_ground_sample(const void* x, const float* disp, const float* P2s, 
                             int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Hill-climbing yaw post-optimisation for a padded batch of detections (heads/detection_3d_head.py:294-308
+ * _post_process; lib/fast_utils/hill_climbing.py:7-122 post_opt/hill_climb/test_projection; fast_utils/bbox3d.py:19-82;
+ * fast_utils/bbox2d.py:39-66; utils/utils.py:30-45).  fp64 per box, one lane per detection, no host round trip.
+ *   boxes  [B][cap][11] fp32 (x1,y1,x2,y2,cx,cy,z,w,h,l,alpha): alpha is rewritten in place for the boxes with
+ *          z > min_depth (reference: 3) and label == target_label (reference: 0);
+ *   labels [B][cap] int32; counts [B] int32 valid detections per sample (NULL: all cap; negative: none);
+ *   P2s    [B][3][4] fp32; clamp_w/clamp_h: the projection clamp the reference hard-codes to 1280 x 288
+ *          (hill_climbing.py:111-113). */
+int vd3d_post_opt(float* boxes, const int32_t* labels, const int32_t* counts, const float* P2s, int B, int cap,
+                  float clamp_w, float clamp_h, float min_depth, int target_label, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * KM3D / RTM3D keypoint-head decoding (heads/km3d_head.py:155-314 _decode + get_bboxes; networks/utils/rtm3d_utils.py
  * _nms :122-127, _topk :201-216, _topk_channel :219-228, gen_position :314-455; torchvision nms) for a whole batch.
  * All maps are fp32 NHWC logits / regressions [B][H][W][n] (n: hm n_cls, wh 2, hps 18, rot 8, dim 3, prob 1, reg 2,

@@ -48,3 +48,28 @@ def test_bf16_mode_close_to_bf16_oracle(name):
         _, st = orc.mono3d_forward(sd, cfg, img, P2, rnd=orc.bf16_round, return_stages=True)
     assert rel_err(cls.cpu(), st['cls_preds']) < 4e-2
     assert rel_err(reg.cpu(), st['reg_preds']) < 4e-2
+
+
+@pytest.mark.parametrize('name', ['groundaware_r34_96x320', 'yolo3d_dcn_r34_96x320'])
+def test_post_optimization_enabled(name):
+    """config/Yolo3D_example:136 turns the hill-climbing yaw refinement on: the detector output must be the oracle's
+    _post_process of the un-refined output, and land next to what the reference produced from its own detections."""
+    import numpy as np
+    from oracle import post_opt_ref
+    g, gp = load_golden(name), load_golden('post_opt_cases')
+    cfg, (img, P2), winit = mono_case_from_golden(g, name)
+    m, _ = _model(cfg, winit, torch.float32)
+    raw = m.test_forward_batched(img.cuda(), P2.cuda())
+    m.bbox_head.test_cfg.post_optimization = True
+    opt = m.test_forward_batched(img.cuda(), P2.cuda())
+    for f in range(img.shape[0]):
+        s, b, l = [t.cpu().numpy() for t in raw[f]]
+        want = post_opt_ref.post_process(s, b, l, P2[f].numpy())
+        got = opt[f][1].cpu().numpy()
+        assert np.array_equal(got[:, :10], b[:, :10]) and torch.equal(opt[f][0], raw[f][0])
+        np.testing.assert_allclose(got[:, 10], want[:, 10], rtol=0, atol=2e-5)
+        assert (got[:, 10] != b[:, 10]).any()
+        ref = gp['%s_f%d_boxes' % (name, f)]
+        if len(ref) == len(got):      # same detections (fp32 mode): yaw within two final hill-climbing steps of the reference's
+            d = np.abs(np.sort(got[:, 10]) - np.sort(ref[:, 10]))
+            assert (np.minimum(d, 2 * np.pi - d) < 0.03).all()

@@ -518,3 +518,20 @@ def dwconv_transpose(x, weight_kk_c, f, add=None):
                                            add.stride(2) if add is not None else 0, out.stride(2), dtype_code(x.dtype), _stream()),
           'vd3d_dwconv_transpose')
     return out
+
+
+def post_opt_batched(boxes, labels, counts, P2s, clamp_wh=(1280.0, 288.0), min_depth=3.0, target_label=0):
+    """In-place hill-climbing yaw refinement of a padded batch (heads/detection_3d_head.py:294-308 +
+    lib/fast_utils/hill_climbing.py): boxes [B,K,11] fp32, labels [B,K] int32, counts [B] int32 or None, P2s [B,3,4]."""
+    _require_cuda(boxes, labels, P2s)
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 3 and boxes.shape[2] == 11
+    assert labels.dtype == torch.int32 and labels.is_contiguous() and labels.shape == boxes.shape[:2]
+    B, K = labels.shape
+    P2s = P2s.float().contiguous()
+    assert P2s.shape == (B, 3, 4)
+    if counts is not None:
+        assert counts.dtype == torch.int32 and counts.shape == (B,) and counts.is_contiguous()
+    check(_lib.lib().vd3d_post_opt(_p(boxes), _p(labels), _p(counts) if counts is not None else None, _p(P2s), B, K,
+                                   float(clamp_wh[0]), float(clamp_wh[1]), float(min_depth), int(target_label), _stream()),
+          'vd3d_post_opt')
+    return boxes

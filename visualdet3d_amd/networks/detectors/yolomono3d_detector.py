@@ -77,10 +77,7 @@ class Yolo3D(nn.Module):
 
     @torch.no_grad()
     def test_forward_batched(self, img_batch, P2):
-        outs = self.bbox_head.unpad(self.forward_device(img_batch, P2))
-        if getattr(self.bbox_head.test_cfg, 'post_optimization', False):
-            outs = [self.bbox_head._post_process(s, b, l, P2[i:i + 1]) for i, (s, b, l) in enumerate(outs)]
-        return outs
+        return self.bbox_head.unpad(self.forward_device(img_batch, P2))   # post_optimization runs inside get_bboxes_batched
 
     @torch.no_grad()
     def test_forward(self, img_batch, P2):

@@ -166,11 +166,17 @@ class AnchorBasedDetection3DHead(nn.Module):
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         lo, hi = self.anchors.filter_y_threshold_min_max
-        return ops.head_postprocess(
-            cls_preds, reg_preds, anchors, prior, P2s.to(dev), A, self.num_classes, len(self.anchors.obj_types), img_hw,
+        P2s = P2s.to(dev)
+        padded = ops.head_postprocess(
+            cls_preds, reg_preds, anchors, prior, P2s, A, self.num_classes, len(self.anchors.obj_types), img_hw,
             getattr(self.test_cfg, 'score_thr', 0.5), getattr(self.test_cfg, 'nms_iou_thr', 0.5),
             use_filter=bool(self._is_filtering() and self.anchors.readConfigFile), y_min_max=(lo, hi),
             x_max=self.anchors.filter_x_threshold, max_cand=self.max_candidates, workspace=self._workspace)
+        if getattr(self.test_cfg, 'post_optimization', False):
+            # detection_3d_head.py:396-398 -> _post_process, here on the padded batch (count < 0 rows are skipped)
+            from ..lib.fast_utils.hill_climbing import post_opt_batch
+            post_opt_batch(padded[1], padded[2], P2s, counts=padded[4])
+        return padded
 
     @staticmethod
     def unpad(padded):
@@ -191,21 +197,14 @@ class AnchorBasedDetection3DHead(nn.Module):
         assert cls_scores.shape[0] == 1
         assert img_batch is not None, 'image batch (for its H, W) is required'
         padded = self.get_bboxes_batched(cls_scores.float().contiguous(), reg_preds.float().contiguous(), P2s, img_batch.shape[2:])
-        max_score, bboxes, label = self.unpad(padded)[0]
-        if getattr(self.test_cfg, 'post_optimization', False):
-            max_score, bboxes, label = self._post_process(max_score, bboxes, label, P2s)
-        return max_score, bboxes, label
+        return self.unpad(padded)[0]
 
     def _post_process(self, scores, bboxes, labels, P2s):
-        from ..lib.fast_utils.hill_climbing import post_opt
-        N = len(scores)
-        bbox2d = bboxes[:, 0:4]
-        bbox3d = bboxes[:, 4:]
-        state = self.backprojector.forward(bbox3d, P2s[0])
-        for i in range(N):
-            if state[i, 2] > 3 and labels[i] == 0:
-                bbox3d[i] = post_opt(bbox2d[i], state[i], P2s[0].cpu().numpy(), bbox3d[i, 0].item(), bbox3d[i, 1].item())
-        return scores, torch.cat([bbox2d, bbox3d], dim=-1), labels
+        """heads/detection_3d_head.py:294-308: hill-climb the yaw of every label-0 box deeper than 3 m so that its
+        projection matches the 2D box.  One device launch for all boxes instead of the reference's per-box host loop."""
+        from ..lib.fast_utils.hill_climbing import post_opt_batch
+        bboxes = post_opt_batch(bboxes.float().contiguous(), labels, P2s[0:1])
+        return scores, bboxes, labels
 
 
 class StereoHead(AnchorBasedDetection3DHead):
