@@ -73,7 +73,8 @@ def profile_convs(model, inputs, reps=3):
         B, Ho, Wo, Co = o.shape
         nbytes = (x.shape[0] * x.shape[1] * x.shape[2] * pc.Cin * x.element_size() + pc.Cout * pc.kh * pc.kw * pc.Cin * x.element_size()
                   + o.numel() * o.element_size() + (residual.numel() * residual.element_size() if residual is not None else 0))
-        records.append((2.0 * B * Ho * Wo * Co * pc.kh * pc.kw * pc.Cin, s, e, nbytes))
+        records.append((2.0 * B * Ho * Wo * Co * pc.kh * pc.kw * pc.Cin, s, e, nbytes,
+                        '%dx%d s%d %4d->%4d @ %dx%dx%d' % (pc.kh, pc.kw, pc.stride, pc.Cin, pc.Cout, B, Ho, Wo)))
         return o
 
     ops.conv2d = timed
@@ -92,7 +93,7 @@ def profile_convs(model, inputs, reps=3):
         for i in range(per):
             fl = records[i][0]
             t = sum(records[i + r * per][1].elapsed_time(records[i + r * per][2]) for r in range(reps)) / reps
-            print('  conv %2d  %8.2f GF  %8.1f us  %7.1f TF/s' % (i, fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
+            print('  conv %2d  %-32s %8.2f GF  %8.1f us  %7.1f TF/s' % (i, records[i][4], fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     flops = sum(r[0] for r in records) / reps
     secs = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3 / reps
     return flops, secs, len(records) // reps, sum(r[3] for r in records) / reps

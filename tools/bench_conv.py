@@ -15,6 +15,9 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('head 1408->256', 8, 24, 80, 1408, 256),
 ]
 cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+import os
+if os.environ.get('VD3D_SHAPES'):
+    SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ['VD3D_SHAPES'].split(','))]
 torch.manual_seed(0)
 for name, B, H, W, Cin, Cout in SHAPES:
     x = torch.randn(B, H, W, Cin, device='cuda').to(torch.bfloat16)
@@ -25,7 +28,7 @@ for name, B, H, W, Cin, Cout in SHAPES:
     ref = None
     line = '%-18s' % name
     for c in cfgs:
-        if (Cout <= 64 and c in (1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 21, 22, 23, 24, 25, 27)) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 128 and c == 33) or (Cout <= 64 and c == 29) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and c >= 20):
+        if (Cout <= 64 and c in (1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 36, 37, 38, 21, 22, 23, 24, 25, 27)) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 128 and c == 33) or (Cout <= 64 and c == 29) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 40):
             line += '  cfg%d    --   ' % c
             continue
         _lib.lib().vd3d_conv2d_set_tuning(c)
