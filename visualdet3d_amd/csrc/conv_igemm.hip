@@ -173,6 +173,85 @@ VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int 
     }
 }
 
+// MFMA shape selector for the pipelined loop: 32 -> the Mma<T> above, 16 -> v_mfma_f32_16x16x32_bf16
+template <typename T, int MS> struct MmaShape {
+    typedef f32x16 acc_t;
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) { Mma<T>::run(a, b, acc); }
+};
+template <> struct MmaShape<short, 16> {
+    typedef f32x4 acc_t;
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+};
+
+// Epilogue for the 16x16x32 layout (weights = A operand): lane (l16, q) holds output channels 4q .. 4q+3 of pixel l16 of
+// the 16x16 block; bf16 only, 8-byte NHWC stores (vector path) or scalar stores.
+template <int TM, int TN, int WTN>
+VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int q) {
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = mrow[j];
+        if (m < 0) continue;
+        const int64_t obase = (int64_t)m * p.out_pix_stride;
+        const int64_t rbase = (int64_t)m * p.res_pix_stride;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = n0 + wn * WTN + i * 16 + 4 * q;
+            if (nb >= p.Cout) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
+            if (p.vec_epilogue) {
+                if (p.scale) {
+                    const f32x4 s = *(const f32x4*)(p.scale + nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= s[e];
+                }
+                if (p.shift) {
+                    const f32x4 s = *(const f32x4*)(p.shift + nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += s[e];
+                }
+                if (p.residual) {
+                    const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
+                    const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
+                    v[0] += i2f((int)(r0 << 16));
+                    v[1] += i2f((int)(r0 & 0xffff0000u));
+                    v[2] += i2f((int)(r1 << 16));
+                    v[3] += i2f((int)(r1 & 0xffff0000u));
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.out_f32) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(p.out + (obase + nb) * 4) = o;
+                } else {
+                    i32x2 o;
+                    o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+                    o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                    *(i32x2*)(p.out + (obase + nb) * 2) = o;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = nb + e;
+                    if (n >= p.Cout) continue;
+                    float x = v[e];
+                    if (p.scale) x *= p.scale[n];
+                    if (p.shift) x += p.shift[n];
+                    if (p.residual) x += bf2f(((const short*)p.residual)[rbase + n]);
+                    if (p.relu) x = fmaxf(x, 0.f);
+                    if (p.out_f32) ((float*)p.out)[obase + n] = x;
+                    else ((short*)p.out)[obase + n] = f2bf(x);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
@@ -329,17 +408,23 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
 // logical slot (L%8) ^ ((row/2)%8) of its row -- the same 128 contiguous bytes per row, permuted among 8 lanes, so
 // global coalescing is unchanged and the fragment reads keep the conflict-free swizzled addressing.
 // Zero padding still comes from the SRD bounds check (out-of-range lanes write zeros into LDS).
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
     constexpr int BKE = 128 / ES;
     constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
-    constexpr int TM = WTM / 32, TN = WTN / 32;
+    // MS = MFMA tile edge: 32 (32x32x16, four 16-deep sub-steps per slice) or 16 (16x16x32 bf16, two 32-deep sub-steps:
+    // lets a wave own e.g. 64 x 176 -- 0.68 KB of LDS fragment reads per 32x32x16-equivalent instead of 1.09 for 32 x 352)
+    constexpr int TM = WTM / MS, TN = WTN / MS;
+    constexpr int SPK = MS == 32 ? 2 : 4;        // 16-byte k slots consumed per sub-step by one MFMA row
+    constexpr int NSUB = 8 / SPK;                // sub-steps per 128-byte slice
+    static_assert(MS == 32 || (MS == 16 && PIPE && sizeof(T) == 2), "16x16x32 path: bf16, pipelined loop only");
+    static_assert(WTM % MS == 0 && WTN % MS == 0, "wave tile vs MFMA shape");
     constexpr int A_PIECES = BM / 8 / NW, W_PIECES = (BN / 8 + NW - 1) / NW;  // per wave (last W round may be partial)
     constexpr int A_STAGE = BM * 128, STAGE = (BM + BN) * 128;
-    static_assert((BM / 8) % NW == 0 && BN % 32 == 0, "pixel rows must split evenly into 8-row pieces per wave");
+    static_assert((BM / 8) % NW == 0 && BN % 16 == 0, "pixel rows must split evenly into 8-row pieces per wave");
     static_assert((8 * NW) % 16 == 0, "piece stride must keep the swizzle phase constant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -442,16 +527,17 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         }
     };
 
-    f32x16 acc[TN][TM];
+    typename MmaShape<T, MS>::acc_t acc[TN][TM];
 #pragma unroll
     for (int i = 0; i < TN; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < MS * MS / 64; ++e) acc[i][j][e] = 0.f;
 
-    const int lr = lane & 31, half = lane >> 5;
+    const int lr = lane & (MS - 1), half = lane / MS;   // half: k-slot group of the lane (0..1 for MS 32, 0..3 for MS 16)
     auto compute = [&](int st, bool more) {
+      if constexpr (MS == 32) {
         const char* As = smem + st * STAGE;
         const char* Ws = As + A_STAGE;
 #pragma unroll
@@ -475,6 +561,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                 for (int j = 0; j < TM; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
         if (more) advance_k();
+      }
     };
 
     if constexpr (!PIPE) {
@@ -497,12 +584,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         //    registers, so after the barrier the stage is free (DMA of slice t+2 goes into it) and the first fragments of
         //    slice t+1 are fetched under the last sub-step's MFMAs.
         auto ld_w = [&](int st, int ks, int i) {
-            const int row = wn * WTN + i * 32 + lr;
-            return *(const i32x4*)(smem + st * STAGE + A_STAGE + row * 128 + (((2 * ks + half) ^ ((row >> 1) & 7)) << 4));
+            const int row = wn * WTN + i * MS + lr;
+            return *(const i32x4*)(smem + st * STAGE + A_STAGE + row * 128 + (((SPK * ks + half) ^ ((row >> 1) & 7)) << 4));
         };
         auto ld_a = [&](int st, int ks, int j) {
-            const int row = wm * WTM + j * 32 + lr;
-            return *(const i32x4*)(smem + st * STAGE + row * 128 + (((2 * ks + half) ^ ((row >> 1) & 7)) << 4));
+            const int row = wm * WTM + j * MS + lr;
+            return *(const i32x4*)(smem + st * STAGE + row * 128 + (((SPK * ks + half) ^ ((row >> 1) & 7)) << 4));
         };
 #pragma unroll
         for (int g = 0; g < 4; ++g) issue_group(0, g);
@@ -512,9 +599,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         __syncthreads();
         // weight fragments live in a ring of R registers refilled R fragments ahead (R | 4*TN keeps the register <->
         // fragment assignment identical in every slice); pixel fragments are double buffered per sub-step.
-        constexpr int R = TM == 1 ? 4 : TN;
-        static_assert((4 * TN) % R == 0 && R <= TN, "fragment ring");
-        constexpr int F0 = 4 * TN - R;      // first fragment whose refill comes from the NEXT slice: the barrier sits here
+        constexpr int R = TM == 1 ? 4 : (MS == 16 ? 2 : TN);
+        static_assert((NSUB * TN) % R == 0 && R <= TN, "fragment ring");
+        constexpr int F0 = NSUB * TN - R;      // first fragment whose refill comes from the NEXT slice: the barrier sits here
         i32x4 fa[R], fb[2][TM];
 #pragma unroll
         for (int i = 0; i < R; ++i) fa[i] = ld_w(0, 0, i);
@@ -526,7 +613,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             const int st = kt & 1;
             const bool more1 = kt + 1 < p.nk, more2 = kt + 2 < p.nk;
 #pragma unroll
-            for (int f = 0; f < 4 * TN; ++f) {
+            for (int f = 0; f < NSUB * TN; ++f) {
                 const int ks = f / TN, i = f - ks * TN;
                 if (f == F0) {
                     // Every read of this stage has been issued (lgkmcnt(0): and has completed), and slice t+1 must have
@@ -537,41 +624,49 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     asm volatile("" ::: "memory");
                     issue_group(st, 0, more2);
                 }
-                if ((i == 0 && ks < 3) || f == F0) {
+                if ((i == 0 && ks < NSUB - 1) || f == F0) {
                     // pixel fragments of the next sub-step (past the last slice they read a dead stage; never consumed)
-                    const int k2 = f == F0 ? 3 : ks;
+                    const int k2 = f == F0 ? NSUB - 1 : ks;
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) fb[(k2 & 1) ^ 1][j] = ld_a(k2 < 3 ? st : st ^ 1, (k2 + 1) & 3, j);
+                    for (int j = 0; j < TM; ++j) fb[(k2 & 1) ^ 1][j] = ld_a(k2 < NSUB - 1 ? st : st ^ 1, (k2 + 1) % NSUB, j);
                     __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
                 }
-                if (i == 0 && ks == 0) { issue_group(st ^ 1, 1, more1); issue_group(st ^ 1, 2, more1); }
-                if (i == 0 && ks == 1) { issue_group(st ^ 1, 3, more1); advance_k(); }
+                if (i == 0 && ks == 0) {
+                    issue_group(st ^ 1, 1, more1);
+                    issue_group(st ^ 1, 2, more1);
+                    if (NSUB == 2) { issue_group(st ^ 1, 3, more1); advance_k(); }
+                }
+                if (NSUB == 4 && i == 0 && ks == 1) { issue_group(st ^ 1, 3, more1); advance_k(); }
 #pragma unroll
-                for (int j = 0; j < TM; ++j) Mma<T>::run(fa[f % R], fb[ks & 1][j], acc[i][j]);
+                for (int j = 0; j < TM; ++j) MmaShape<T, MS>::run(fa[f % R], fb[ks & 1][j], acc[i][j]);
                 const int nf = f + R, nks = nf / TN, ni = nf - nks * TN;
-                fa[f % R] = ld_w(nks < 4 ? st : st ^ 1, nks & 3, ni);
+                fa[f % R] = ld_w(nks < NSUB ? st : st ^ 1, nks % NSUB, ni);
                 // pin the schedule (otherwise the scheduler sinks every ds_read to its use): MFMAs of this fragment, its
                 // ring refill, then this fragment's share of the DMA pieces issued in the sub-step (spread evenly)
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                const int i0 = ks == 3 ? TN - R : 0, nfr = TN - i0;
-                const int D = ks == 0 ? group_size(1) + group_size(2) : (ks == 1 ? group_size(3) : (ks == 3 ? group_size(0) : 0));
+                const int i0 = ks == NSUB - 1 ? TN - R : 0, nfr = TN - i0;
+                const int D = NSUB == 4 ? (ks == 0 ? group_size(1) + group_size(2) : (ks == 1 ? group_size(3) : (ks == 3 ? group_size(0) : 0)))
+                                        : (ks == 0 ? group_size(1) + group_size(2) + group_size(3) : group_size(0));
                 const int o = i - i0;
                 const int q = o >= 0 ? (D * (o + 1)) / nfr - (D * o) / nfr : 0;
                 if (q >= 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (q >= 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (q >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (q >= 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (q >= 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
     }
     int mrow[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * WTM + j * 32 + lr;
+        const int m = m0 + wm * WTM + j * MS + lr;
         mrow[j] = m < p.M ? m : -1;
     }
-    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
+    if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
+    else conv_epilogue16<TM, TN, WTN>(p, acc, mrow, n0, wn, half);
 }
 
 // =====================================================================================================
@@ -758,7 +853,7 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_halo");
 }
 
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
@@ -766,7 +861,7 @@ int launch(ConvArgs& a, hipStream_t stream) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static bool attr_done = false;
     void (*kern)(const ConvArgs);
-    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE>;
+    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -798,6 +893,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 42: return launch<T, 256, 256, 2, 4, true, true>(a, stream);
         case 43: return launch<T, 128, 192, 2, 2, true, true>(a, stream);
         case 44: return launch<T, 128, 128, 2, 2, true, true>(a, stream);
+        case 50: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream); else break;
+        case 51: if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16>(a, stream); else break;
         case 21: return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
         case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
@@ -852,8 +949,14 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         // the software-pipelined main loop (PIPE) measured +2.5 % (256x352) ... +17 % (256x288 on Cout 576) over the
         // barrier-per-slice loop on every shape of the hot path
         case 1: return launch<T, 256, 256, 2, 4, true, true>(a, stream);
-        case 2: return launch<T, 256, 352, 8, 1, true, true>(a, stream);
-        case 3: return launch<T, 256, 288, 8, 1, true, true>(a, stream);
+        // strips: bf16 uses 16x16x32 MFMAs so that a wave owns 64 pixels x half the strip (0.68 KB of fragment reads per
+        // 32x32x16-equivalent instead of 1.09 for 32 x the whole strip): +11 % (352) / +8 % (288) measured
+        case 2:
+            if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream);
+            else return launch<T, 256, 352, 8, 1, true, true>(a, stream);
+        case 3:
+            if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16>(a, stream);
+            else return launch<T, 256, 288, 8, 1, true, true>(a, stream);
         case 4: return launch<T, 128, 352, 4, 1, true>(a, stream);
         case 5: return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 6: return launch<T, 128, 192, 2, 2, true, true>(a, stream);
