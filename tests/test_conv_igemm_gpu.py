@@ -147,3 +147,13 @@ def test_dwconv_and_copy():
         assert ((got - y).abs().max() / y.abs().max()).item() < tol
         ops.copy_channels(buf[..., 2 * C:], buf[..., :C])
         assert torch.equal(buf[..., :C], buf[..., 2 * C:])
+
+
+def test_conv_resident_weights_64():
+    """The persistent resident-weight kernel (3x3 s1 p1, 64 -> 64, bf16): fewer tiles than CUs, many tiles per workgroup,
+    with/without residual, ReLU, BN; channel-slice input and output."""
+    assert _case(1, 8, 16, 64, 64, 3, 1, 1, 1, False, False, torch.bfloat16, bias=False, bn=False) < 1e-2       # one tile
+    assert _case(1, 16, 48, 64, 64, 3, 1, 1, 1, True, False, torch.bfloat16, seed=1) < 1e-2
+    assert _case(3, 96, 320, 64, 64, 3, 1, 1, 1, True, True, torch.bfloat16, seed=2) < 1e-2                      # 720 tiles
+    assert _case(2, 96, 320, 64, 64, 3, 1, 1, 1, False, True, torch.bfloat16, bn=False, seed=3) < 1e-2
+    assert _case(2, 24, 32, 64, 64, 3, 1, 1, 1, True, True, torch.bfloat16, in_extra=64, out_extra=64, seed=4) < 1e-2

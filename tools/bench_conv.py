@@ -6,7 +6,7 @@ sys.path.insert(0, '.')
 from visualdet3d_amd import hip_ops as ops, _lib
 
 SHAPES = [  # name, B, H, W, Cin, Cout
-    ('layer1 64->64', 16, 96, 320, 64, 64),
+    ("layer1 64->64", 16, 96, 320, 64, 64),
     ('layer2 128->128', 16, 48, 160, 128, 128),
     ('layer3 256->256', 16, 24, 80, 256, 256),
     ('neck 1152->1152', 8, 24, 80, 1152, 1152),

@@ -832,6 +832,197 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const 
     conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
 }
 
+// =====================================================================================================
+// v5 "resident weights" kernel: 3x3 / stride 1 / pad 1, 64 -> 64 channels, bf16 (ResNet layer1: six launches per forward,
+// K = 576 only).  The tile kernels above spend such a layer waiting: nine tiny K slices per tile, each a DMA round trip
+// and a barrier for 8 MFMAs per wave, and the 73 KB weight panel is re-fetched by every tile.  Here the whole weight
+// panel lives in REGISTERS (a wave owns 32 output channels: 9 taps x 4 sub-steps x 16 B = 144 VGPRs), the workgroups are
+// persistent (one per CU, tiles t = wg, wg + nwg, ...), and LDS only holds a 4-deep ring of input halos (8 x 16 pixels
+// + border, one 128-byte row per pixel) filled by LDS-DMA two to three tiles ahead.  Per tile: ONE barrier, 36 MFMAs per
+// wave each fed by one ds_read_b128 through a 4-fragment ring, epilogue fused as elsewhere.  The layer is then HBM-bound
+// (in x1.4 halo + out + residual ~= 215 MB per launch at B = 16 x 96 x 320), not latency-bound.
+constexpr int kResTH = 8, kResTW = 16, kResStages = 4;
+constexpr int kResHW2 = kResTW + 2, kResHR = (kResTH + 2) * kResHW2;       // 18, 180 halo pixels
+constexpr int kResPiecesTot = (kResHR + 7) / 8;                            // 23 pieces of 1 KiB
+constexpr int kResStageBytes = kResPiecesTot * 1024;
+constexpr int kResLds = kResStages * kResStageBytes + 512;   // + scale[64], shift[64] (fp32): epilogue reads them through
+                                                             // lgkmcnt, a global load per tile would drain the DMA queue (vmcnt)
+
+template <bool RES>
+__global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, int ntiles) {
+    constexpr int NW = 8, HP = 3;                     // waves; halo pieces per wave (23 = 7 waves x 3 + 1 wave x 2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves: 32 pixels x 32 channels each
+    const int lr = lane & 31, half = lane >> 5;
+    const int tiles_x = p.W / kResTW, tiles_y = p.H / kResTH, tiles_img = tiles_x * tiles_y;
+
+    // ---- weights -> registers, MFMA A-operand layout: row = output channel, 16 bytes = 8 k values -----------
+    i32x4 wf[36];
+    {
+        const char* wrow = p.weight + (size_t)(wn * 32 + lr) * p.Kpad * 2;
+#pragma unroll
+        for (int f = 0; f < 36; ++f) wf[f] = *(const i32x4*)(wrow + ((f >> 2) * 64 + (2 * (f & 3) + half) * 8) * 2);
+    }
+    // ---- halo DMA lane state (same lane-linear image + source-side swizzle as the halo kernel) -------------------
+    const int prow = lane >> 3;
+    const int slot = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    int h_y[HP], h_x[HP];
+    bool h_ok[HP];
+    int h_piece[HP];
+#pragma unroll
+    for (int it = 0; it < HP; ++it) {
+        int piece = wave + it * NW;
+        if (piece >= kResPiecesTot) piece -= NW;      // branch-free partial round: repeat the previous piece
+        h_piece[it] = piece;
+        const int hr = 8 * piece + prow;
+        h_y[it] = hr / kResHW2;
+        h_x[it] = hr - h_y[it] * kResHW2;
+        h_ok[it] = hr < kResHR;
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto issue_halo = [&](int t, int stage) {
+        const bool tv = t < ntiles;
+        const int tt = tv ? t : 0;
+        const int b = tt / tiles_img, trem = tt - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        char* base = smem + stage * kResStageBytes;
+#pragma unroll
+        for (int it = 0; it < HP; ++it) {
+            const int iy = ty * kResTH - 1 + h_y[it], ix = tx * kResTW - 1 + h_x[it];
+            const bool v = tv && h_ok[it] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const uint32_t off = v ? (uint32_t)((int)(b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + slot * 8) * 2 : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + h_piece[it] * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    // ---- fragment addressing: pixel pp of the tile, tap (dy, dx) -> halo row; byte = row*128 + ((2ks+half) ^ sw(row))*16
+    //      = A_tap ^ (ks << 5) with A_tap = row*128 + ((half ^ sw(row)) << 4)
+    const int pp = wm * 32 + lr;
+    const int hrow0 = (pp / kResTW) * kResHW2 + (pp & (kResTW - 1));
+    int a_tap[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int row = hrow0 + (tap / 3) * kResHW2 + (tap % 3);
+        a_tap[tap] = row * 128 + ((half ^ ((row >> 1) & 7)) << 4);
+    }
+    auto ld_frag = [&](int stage, int f) {
+        return *(const i32x4*)(smem + stage * kResStageBytes + (a_tap[f >> 2] ^ ((f & 3) << 5)));
+    };
+
+    float* ss = (float*)(smem + kResStages * kResStageBytes);
+    if (tid < 64) {
+        ss[tid] = p.scale ? p.scale[tid] : 1.f;
+        ss[64 + tid] = p.shift ? p.shift[tid] : 0.f;
+    }
+    const int nwg = gridDim.x;
+    int t = blockIdx.x;
+#pragma unroll
+    for (int s0 = 0; s0 < kResStages; ++s0) issue_halo(t + s0 * nwg, s0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kResStages - 1) * HP) : "memory");   // the first halo has landed (per wave) ...
+    __builtin_amdgcn_s_barrier();                                        // ... for every wave
+    asm volatile("" ::: "memory");
+    i32x4 ring[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) ring[f] = ld_frag(0, f);
+
+    // Per tile k a wave issues, in order: [R(k): 4 residual loads] D(k+4): HP DMA pieces, S(k): 2 stores.  At tile k's barrier
+    // "at most 2*HP outstanding" leaves only S(k-1), D(k+3) (and one older op) in flight: D(k+2) and everything older -- in
+    // particular this barrier's D(k+1) -- has landed, and each halo gets two tile times to arrive.  Also right for k = 0
+    // (prologue D(0..3): D(0), D(1) landed).  gfx9 vmcnt retires loads and stores in issue order.
+    constexpr int kYounger = 2 * HP;
+    int stage = 0;
+    for (; t < ntiles; t += nwg) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const int b = t / tiles_img, trem = t - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int y = ty * kResTH + pp / kResTW, x = tx * kResTW + (pp & (kResTW - 1));
+        const int64_t m = ((int64_t)b * p.H + y) * p.W + x;
+        const int nb0 = wn * 32 + 4 * half;
+        i32x2 rr[4];
+        const int nstage = stage + 1 == kResStages ? 0 : stage + 1;
+#pragma unroll
+        for (int f = 0; f < 36; ++f) {
+            if (f == 32) {
+                // all reads of this tile's halo are issued (and, with lgkmcnt(0), done); the next halo must have landed
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kYounger) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if constexpr (RES) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rr[g] = *(const i32x2*)(p.residual + (m * p.res_pix_stride + nb0 + 8 * g) * 2);
+                }
+                issue_halo(t + kResStages * nwg, stage);                 // tile k+4 into the stage just released
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[f]), __builtin_bit_cast(bf16x8, ring[f & 3]), acc, 0, 0, 0);
+            ring[f & 3] = f + 4 < 36 ? ld_frag(stage, f + 4) : ld_frag(nstage, f + 4 - 36);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // ---- epilogue: scale/shift (+residual) (+ReLU), 2 x 16-byte NHWC stores per lane (half-wave pairing) ----
+        int pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int nb = nb0 + 8 * g;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e];
+            if (p.scale) {
+                const f32x4 sc = *(const f32x4*)(ss + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= sc[e];
+            }
+            if (p.shift) {
+                const f32x4 sh = *(const f32x4*)(ss + 64 + nb);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += sh[e];
+            }
+            if constexpr (RES) {
+                const uint32_t r0 = (uint32_t)(int)rr[g][0], r1 = (uint32_t)(int)rr[g][1];
+                v[0] += i2f((int)(r0 << 16));
+                v[1] += i2f((int)(r0 & 0xffff0000u));
+                v[2] += i2f((int)(r1 << 16));
+                v[3] += i2f((int)(r1 & 0xffff0000u));
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            pk[g][0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+            pk[g][1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+            i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
+            *(i32x4*)(p.out + (m * p.out_pix_stride + wn * 32 + 8 * (g + half)) * 2) = o;
+        }
+        stage = nstage;
+    }
+}
+
+int launch_resident64(ConvArgs& a, hipStream_t stream) {
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return vd3d_check_launch("hipGetDeviceProperties");
+        num_cu = prop.multiProcessorCount;
+        if (hipFuncSetAttribute((const void*)conv_resident64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kResLds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv_resident64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kResLds) != hipSuccess)
+            return vd3d_check_launch("hipFuncSetAttribute(conv_resident64)");
+    }
+    const int ntiles = a.B * (a.H / kResTH) * (a.W / kResTW);
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    if (a.residual) hipLaunchKernelGGL(conv_resident64_kernel<true>, dim3(grid), dim3(512), kResLds, stream, a, ntiles);
+    else hipLaunchKernelGGL(conv_resident64_kernel<false>, dim3(grid), dim3(512), kResLds, stream, a, ntiles);
+    return vd3d_check_launch("conv_resident64");
+}
+
 template <typename T, int TH, int TW, int BN, int WARPS_M, int WARPS_N, int STAGES = 4>
 int launch_halo(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
@@ -899,6 +1090,11 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
         default: break;
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
+            a.H % kResTH == 0 && a.W % kResTW == 0 && a.wide_store && !a.out_f32)
+            return launch_resident64(a, stream);
     }
     if (a.Cout <= 32) return launch<T, 256, 32, 4, 1, true>(a, stream);
     if (a.Cout <= 64) return launch<T, 128, 64, 4, 1, true>(a, stream);   // 48 KiB LDS -> 3 workgroups / CU (short K: latency bound)
