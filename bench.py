@@ -79,7 +79,9 @@ def profile_convs(model, inputs, reps=3):
 
     ops.conv2d = timed
     overlap = model.bbox_head.overlap_towers
+    overlap_neck = model.core.overlap_neck
     model.bbox_head.overlap_towers = False     # serial launches: per-kernel event times must not overlap
+    model.core.overlap_neck = False
     try:
         with torch.no_grad():
             for _ in range(reps):
@@ -88,6 +90,7 @@ def profile_convs(model, inputs, reps=3):
     finally:
         ops.conv2d = orig
         model.bbox_head.overlap_towers = overlap
+        model.core.overlap_neck = overlap_neck
     if os.environ.get('VD3D_BENCH_LAYERS'):
         per = len(records) // reps
         for i in range(per):
@@ -141,6 +144,8 @@ def main():
     L, R, P2 = L.to(device), R.to(device), P2.to(device)   # inputs resident in HBM before the timed region
     inputs = (L, R, P2)
 
+    if os.environ.get('VD3D_BENCH_NONECK'):
+        model.core.overlap_neck = False
     graph = None
     static_out = None
     with torch.no_grad():

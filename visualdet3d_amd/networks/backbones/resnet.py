@@ -112,7 +112,9 @@ class ResNet(nn.Module):
             layers.append(block(self.inplanes, planes, dilation=dilation))
         return nn.Sequential(*layers)
 
-    def forward_nhwc(self, img_nchw, dtype=None):
+    def forward_nhwc(self, img_nchw, dtype=None, on_stage=None):
+        """``on_stage(i, x)``: optional callback right after stage i's output has been enqueued (the stereo neck uses it to
+        start the work that only depends on that stage on a side stream)."""
         """img_nchw: [B,3,H,W] fp32 (the reference's input format).  Returns the NHWC feature list."""
         dtype = dtype or fused.default_compute_dtype()
         pc = self._cache.get(('stem', dtype), [self.conv1.weight] + fused.bn_sources(self.bn1),
@@ -127,6 +129,8 @@ class ResNet(nn.Module):
                 x = blk.forward_nhwc(x)
             if i in self.out_indices:
                 outs.append(x)
+            if on_stage is not None:
+                on_stage(i, x)
         return outs
 
     def forward(self, img_batch):

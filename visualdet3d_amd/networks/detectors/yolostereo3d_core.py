@@ -62,40 +62,59 @@ class StereoMerging(nn.Module):
                                                  self.cost_volume_2.output_channel)
         self.final_channel = self.depth_reasoning.output_channel_num + base_features * 4
 
-    def forward_nhwc(self, feats, batch):
-        """feats: [s4, s8, s16] NHWC tensors of the stacked [left; right] batch.  Returns features [B,H16,W16,C]."""
-        f4, f8, f16 = feats
+    # The neck in four parts so that each can start as soon as the backbone stage it depends on is done
+    # (YoloStereo3DCore.forward_nhwc runs parts s4 / s8 on a side stream under backbone layer2 / layer3).
+    def alloc(self, f4, B):
         dr = self.depth_reasoning
         dt, dev = f4.dtype, f4.device
         d4, d8, d16 = dr.depth_channel_4, dr.depth_channel_8, dr.depth_channel_16
-        B = batch
         _, H4, W4, _ = f4.shape
-        _, H8, W8, _ = f8.shape
-        _, H16, W16, C16 = f16.shape
+        H8, W8 = (H4 - 1) // 2 + 1, (W4 - 1) // 2 + 1          # 3x3 / stride 2 / pad 1 stages
+        H16, W16 = (H8 - 1) // 2 + 1, (W8 - 1) // 2 + 1
         c72, c288, c1152 = 3 * d4, 3 * (3 * d4 + d8), dr.output_channel_num
-        buf72 = torch.empty((B, H4, W4, c72), dtype=dt, device=dev)
-        buf288 = torch.empty((B, H8, W8, c288), dtype=dt, device=dev)
-        buf1152 = torch.empty((B, H16, W16, c1152), dtype=dt, device=dev)
-        feat = torch.empty((B, H16, W16, C16 + c1152), dtype=dt, device=dev)
+        return dict(B=B, d4=d4, d8=d8, d16=d16, c72=c72, c288=c288, c1152=c1152,
+                    buf72=torch.empty((B, H4, W4, c72), dtype=dt, device=dev),
+                    buf288=torch.empty((B, H8, W8, c288), dtype=dt, device=dev),
+                    buf1152=torch.empty((B, H16, W16, c1152), dtype=dt, device=dev), hw16=(H16, W16))
 
-        # cost volumes, written straight into their concat slices
-        self.cost_volume_0.forward_nhwc(f4[:B], f4[B:], out=buf72[..., :d4])
-        self.cost_volume_1.forward_nhwc(f8[:B], f8[B:], out=buf288[..., c72:c72 + d8])
-        self.cost_volume_2.forward_nhwc(f16, B, out=buf1152[..., c288:c288 + d16])
+    def part_s4(self, f4, st):
+        dr, B, d4, c72 = self.depth_reasoning, st['B'], st['d4'], st['c72']
+        self.cost_volume_0.forward_nhwc(f4[:B], f4[B:], out=st['buf72'][..., :d4])
+        x = dr.four_to_eight[0].forward_nhwc(st['buf72'][..., :d4], out=st['buf72'])
+        x = ops.avgpool2x2(x)
+        dr.four_to_eight[2].forward_nhwc(x, out=st['buf288'][..., :c72])
 
-        # s4 -> s8
-        x = dr.four_to_eight[0].forward_nhwc(buf72[..., :d4], out=buf72)
+    def part_s8(self, f8, st):
+        dr, B, d8, c72, c288 = self.depth_reasoning, st['B'], st['d8'], st['c72'], st['c288']
+        self.cost_volume_1.forward_nhwc(f8[:B], f8[B:], out=st['buf288'][..., c72:c72 + d8])
+        x = dr.eight_to_sixteen[0].forward_nhwc(st['buf288'][..., :c72 + d8], out=st['buf288'])
         x = ops.avgpool2x2(x)
-        dr.four_to_eight[2].forward_nhwc(x, out=buf288[..., :c72])
-        # s8 -> s16
-        x = dr.eight_to_sixteen[0].forward_nhwc(buf288[..., :c72 + d8], out=buf288)
-        x = ops.avgpool2x2(x)
-        dr.eight_to_sixteen[2].forward_nhwc(x, out=buf1152[..., :c288])
-        # s16
-        x = dr.depth_reason[0].forward_nhwc(buf1152[..., :c288 + d16], out=buf1152)
+        dr.eight_to_sixteen[2].forward_nhwc(x, out=st['buf1152'][..., :c288])
+
+    def part_s16(self, f16, st):
+        B, d16, c288 = st['B'], st['d16'], st['c288']
+        _, H16, W16, C16 = f16.shape
+        assert (H16, W16) == st['hw16']
+        st['feat'] = torch.empty((B, H16, W16, C16 + st['c1152']), dtype=f16.dtype, device=f16.device)
+        self.cost_volume_2.forward_nhwc(f16, B, out=st['buf1152'][..., c288:c288 + d16])
+        ops.copy_channels(f16[:B], st['feat'][..., :C16])
+
+    def part_merge(self, st):
+        dr, d16, c288 = self.depth_reasoning, st['d16'], st['c288']
+        feat = st['feat']
+        C16 = feat.shape[3] - st['c1152']
+        x = dr.depth_reason[0].forward_nhwc(st['buf1152'][..., :c288 + d16], out=st['buf1152'])
         dr.depth_reason[1].forward_nhwc(x, out=feat[..., C16:])
-        ops.copy_channels(f16[:B], feat[..., :C16])
         return feat
+
+    def forward_nhwc(self, feats, batch):
+        """feats: [s4, s8, s16] NHWC tensors of the stacked [left; right] batch.  Returns features [B,H16,W16,C]."""
+        f4, f8, f16 = feats
+        st = self.alloc(f4, batch)
+        self.part_s4(f4, st)
+        self.part_s8(f8, st)
+        self.part_s16(f16, st)
+        return self.part_merge(st)
 
 
 class YoloStereo3DCore(nn.Module):
@@ -106,12 +125,43 @@ class YoloStereo3DCore(nn.Module):
         self.backbone = resnet(**backbone_arguments)
         base_features = 256 if backbone_arguments['depth'] > 34 else 64
         self.neck = StereoMerging(base_features)
+        self.overlap_neck = True     # False: everything on one stream (per-kernel profiling)
+        self._side_streams = {}
 
     def forward_nhwc(self, left_images, right_images, dtype=None):
+        """The s4 / s8 parts of the neck (PSM cost volumes, ghost pyramid: ~15 small launches) only depend on backbone
+        layer1 / layer2, so they run on a side HIP stream underneath layer2 / layer3 instead of after layer3: their
+        launch gaps and partially-filled rounds disappear from the critical path (fork/join is captured into the hipGraph)."""
         B = left_images.shape[0]
         images = torch.cat([left_images, right_images], dim=0)  # batch-axis stack of the raw inputs (plumbing)
-        feats = self.backbone.forward_nhwc(images, dtype)
-        return self.neck.forward_nhwc(feats, B)
+        if not self.overlap_neck or not images.is_cuda:
+            feats = self.backbone.forward_nhwc(images, dtype)
+            return self.neck.forward_nhwc(feats, B)
+        main = torch.cuda.current_stream()
+        side = self._side_streams.get(images.device)
+        if side is None:
+            side = self._side_streams[images.device] = torch.cuda.Stream(device=images.device)
+        st = {}
+        keep = []
+
+        def on_stage(i, x):
+            if i == 0:
+                st.update(self.neck.alloc(x, B))
+            if i in (0, 1):
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    (self.neck.part_s4 if i == 0 else self.neck.part_s8)(x, st)
+                x.record_stream(side)
+                keep.append(x)
+            elif i == 2:
+                self.neck.part_s16(x, st)
+
+        feats = self.backbone.forward_nhwc(images, dtype, on_stage=on_stage)
+        assert len(feats) == 3, 'stereo neck needs the s4, s8 and s16 stages'
+        main.wait_stream(side)
+        for k in ('buf72', 'buf288', 'buf1152'):
+            st[k].record_stream(side)
+        return self.neck.part_merge(st)
 
     def forward(self, images):
         """Reference signature: ``images`` = [B,6,H,W] (left | right on the channel axis)."""
