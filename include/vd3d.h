@@ -88,6 +88,13 @@ int vd3d_pack_image_nhwc(const float* in_nchw, void* out, int B, int H, int W, i
 /* nn.MaxPool2d(2, stride 2) on NHWC (backbones/dla.py:213, Tree.downsample). */
 int vd3d_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int in_pix_stride, int out_pix_stride,
                     int dtype, void* stream);
+/* Fused ResNet stem (backbones/resnet.py:118-121,187-190): 7x7/s2/p3 conv + eval BatchNorm + ReLU + MaxPool2d(3, 2, 1) in one
+ * pass, bf16.  packed: output of vd3d_pack_image_nhwc4 with pads (3, 3, 5) = [B][H+6][W+8][4] bf16; weight: the stem's packed
+ * panel [CoutPad][Kpad] bf16 with k = ky*32 + kx*4 + c (kx = 7 and c = 3 zero); scale/shift: fp32[64] folded BN (may be NULL);
+ * out: [B][H/4][W/4][out_pix_stride >= 64] bf16.  Needs 64 output channels, H/4 % 8 == 0, W/4 % 16 == 0. */
+int vd3d_stem_conv_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out,
+                        int B, int H, int W, int Kpad, int out_pix_stride, void* stream);
+
 /* Depth-wise nn.ConvTranspose2d(C, C, 2f, stride f, padding f/2, groups C, bias False) on NHWC (backbones/dla_utils.py:69-71)
  * fused with the `+ layers[i-1]` that follows it (:83); weight [(2f)^2][C] fp32; add may be NULL. */
 int vd3d_dwconv_transpose(const void* in, const float* weight, const void* add, void* out, int B, int H, int W, int C,

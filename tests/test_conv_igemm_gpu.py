@@ -157,3 +157,31 @@ def test_conv_resident_weights_64():
     assert _case(3, 96, 320, 64, 64, 3, 1, 1, 1, True, True, torch.bfloat16, seed=2) < 1e-2                      # 720 tiles
     assert _case(2, 96, 320, 64, 64, 3, 1, 1, 1, False, True, torch.bfloat16, bn=False, seed=3) < 1e-2
     assert _case(2, 24, 32, 64, 64, 3, 1, 1, 1, True, True, torch.bfloat16, in_extra=64, out_extra=64, seed=4) < 1e-2
+
+
+def test_stem_conv_pool_fused():
+    """vd3d_stem_conv_pool (conv 7x7/s2 + BN + ReLU + maxpool 3x3/s2 in one kernel, bf16) against torch CPU on bf16-rounded
+    operands, and against the unfused HIP path (same MFMA chain and rounding point before the pool: identical up to an
+    occasional 1-ulp bf16 difference from mul/add contraction in the two epilogues)."""
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    for B, H, W in [(1, 32, 64), (3, 96, 320), (2, 64, 192)]:
+        img = torch.randn(B, 3, H, W, generator=g)
+        w = torch.randn(64, 3, 7, 7, generator=g) * 0.12
+        bn = (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1,
+              torch.rand(64, generator=g) + 0.5, 1e-5)
+        rnd = lambda t: t.to(torch.bfloat16).float()
+        y = F.conv2d(rnd(img), rnd(w), None, 2, 3)
+        s = bn[0] / torch.sqrt(bn[3] + bn[4])
+        y = F.relu(y * s.view(1, -1, 1, 1) + (bn[1] - bn[2] * s).view(1, -1, 1, 1))
+        want = F.max_pool2d(rnd(y), 3, 2, 1)
+        pc = ops.pack_stem_conv(w.cuda(), tuple(t.cuda() if torch.is_tensor(t) else t for t in bn), torch.bfloat16)
+        halves = [img[:1].cuda().contiguous(), img[1:].cuda().contiguous()] if B > 1 else img.cuda()
+        got = ops.stem_conv_pool(halves, pc, torch.bfloat16)
+        unfused = ops.maxpool3x3s2(ops.stem_conv(img.cuda(), pc, torch.bfloat16))
+        torch.cuda.synchronize()
+        assert got.shape == (B, H // 4, W // 4, 64)
+        d = (got.float() - unfused.float()).abs()
+        assert float((d > 0).float().mean()) < 1e-4 and bool((d <= unfused.float().abs() * 2.0 ** -7 + 1e-30).all()), d.max()
+        err = (got.float().cpu().permute(0, 3, 1, 2) - want).abs().max().item() / want.abs().max().item()
+        assert err < 1e-2, err

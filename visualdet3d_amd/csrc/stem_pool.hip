@@ -1,0 +1,213 @@
+// stem_pool.hip -- ResNet stem fused: 7x7/s2 conv + BN + ReLU + 3x3/s2/p1 max pool in one persistent kernel (bf16, gfx950).
+//
+// Replaces conv1 / bn1 / relu / maxpool of backbones/resnet.py:118-121,187-190 when only the pooled map is consumed.
+// The unfused path writes the 64-channel half-resolution map (252 MB at 16 x 384 x 1280) and reads it back for the pool,
+// and its implicit-GEMM tiles re-fetch every input pixel ~25 times through L2.  Here a workgroup owns 8 x 16 POOLED
+// pixels: it stages the 39 x 72-pixel patch of the packed NHWC4 image once (22 KiB, LDS-DMA, 3-deep ring), computes the
+// 17 x 33 conv outputs the pool windows need as 18 blocks of 32 pixels x 64 channels on the MFMA pipe (K = 7 rows x 32:
+// 14 v_mfma_f32_32x32x16_bf16 per block and channel half, weights resident in registers), applies BN + ReLU, parks the
+// bf16 results in LDS, and the pool phase takes 3x3 maxima (packed 16-bit integer max: post-ReLU bf16 are monotone as
+// int16, and -0 loses) and writes 16 bytes per lane.  HBM traffic: packed image once + pooled map once.
+#include "common.h"
+
+namespace {
+
+constexpr int kTPY = 8, kTPX = 16;                 // pooled tile
+constexpr int kCY = 2 * kTPY + 1, kCX = 2 * kTPX + 1;   // conv outputs needed: 17 x 33
+constexpr int kNQ = kCY * kCX;                     // 561
+constexpr int kNBLK = (kNQ + 31) / 32;             // 18 blocks of 32 conv pixels
+constexpr int kIR = 2 * (kCY - 1) + 7;             // 39 packed rows
+constexpr int kCPR = (2 * (kCX - 1) + 8) / 2;      // 36 16-byte chunks (2 NHWC4 pixels) per packed row
+constexpr int kChunks = kIR * kCPR;                // 1404
+constexpr int kPieces = (kChunks + 63) / 64;       // 22 DMA pieces of 1 KiB
+constexpr int kInStage = kPieces * 1024;
+constexpr int kInStages = 3;
+constexpr int kStaging = kNBLK * 32 * 128;         // conv outputs: one 128-byte row (64 bf16) per conv pixel
+constexpr int kLds = kInStages * kInStage + kStaging + 512;
+constexpr uint32_t kOOB = 0x80000000u;
+
+struct StemArgs {
+    const char* packed;
+    const char* weight;
+    const float* scale;
+    const float* shift;
+    char* out;
+    int B, Hp, Wp, Ho, Wo, Hq, Wq, Kpad, out_pix_stride;
+    uint32_t in_bytes;
+    int ntiles;
+};
+
+__global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
+    constexpr int NW = 8, HP = 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* stg = smem + kInStages * kInStage;
+    float* ss = (float*)(stg + kStaging);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wmi = wave >> 1;
+    const int lr = lane & 31, half = lane >> 5;
+    const int tiles_x = p.Wq / kTPX, tiles_y = p.Hq / kTPY, tiles_img = tiles_x * tiles_y;
+
+    if (tid < 64) {
+        ss[tid] = p.scale ? p.scale[tid] : 1.f;
+        ss[64 + tid] = p.shift ? p.shift[tid] : 0.f;
+    }
+    // weights -> registers (A operand): row = output channel, fragment (ky, ks) = 16 bytes at k = ky*32 + (2ks+half)*8
+    i32x4 wf[14];
+    {
+        const char* wrow = p.weight + (size_t)(wn * 32 + lr) * p.Kpad * 2;
+#pragma unroll
+        for (int f = 0; f < 14; ++f) wf[f] = *(const i32x4*)(wrow + ((f >> 1) * 32 + (2 * (f & 1) + half) * 8) * 2);
+    }
+    // DMA lane state: chunk c = 64*piece + lane -> (row r, chunk j) of the patch; lane-linear LDS image (no swizzle needed:
+    // a fragment read is 32 lanes x consecutive 16-byte chunks)
+    int d_r[HP], d_j[HP], d_piece[HP];
+    bool d_ok[HP];
+#pragma unroll
+    for (int it = 0; it < HP; ++it) {
+        int piece = wave + it * NW;
+        if (piece >= kPieces) piece -= NW;            // branch-free partial round: repeat the previous piece
+        d_piece[it] = piece;
+        const int c = 64 * piece + lane;
+        d_r[it] = c / kCPR;
+        d_j[it] = c - d_r[it] * kCPR;
+        d_ok[it] = c < kChunks;
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.packed, 0, p.in_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto issue_patch = [&](int t, int stage) {
+        const bool tv = t < p.ntiles;
+        const int tt = tv ? t : 0;
+        const int b = tt / tiles_img, trem = tt - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int pr0 = 4 * ty * kTPY - 2, pc0 = 4 * tx * kTPX - 2;      // packed row / column of the patch origin
+        char* base = smem + stage * kInStage;
+#pragma unroll
+        for (int it = 0; it < HP; ++it) {
+            const int pr = pr0 + d_r[it], pc = pc0 + 2 * d_j[it];
+            const bool v = tv && d_ok[it] && (unsigned)pr < (unsigned)p.Hp && pc >= 0 && pc + 1 < p.Wp;
+            const uint32_t off = v ? (uint32_t)(((b * p.Hp + pr) * p.Wp + pc) * 8) : kOOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + d_piece[it] * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    // conv pixel q of block blk for this lane; fragment byte = ((2cy + ky)*36 + cx + 2ks + half)*16
+    constexpr int MAXB = (kNBLK + 3) / 4;
+    int q_of[MAXB], fbase[MAXB], cy_of[MAXB], cx_of[MAXB];
+#pragma unroll
+    for (int i = 0; i < MAXB; ++i) {
+        const int blk = wmi + 4 * i;
+        const int q = blk * 32 + lr;
+        const int qc = q < kNQ ? q : kNQ - 1;
+        cy_of[i] = qc / kCX;
+        cx_of[i] = qc - cy_of[i] * kCX;
+        q_of[i] = q;
+        fbase[i] = ((2 * cy_of[i]) * kCPR + cx_of[i] + half) * 16;
+    }
+
+    const int nwg = gridDim.x;
+    int t = blockIdx.x;
+    issue_patch(t, 0);
+    issue_patch(t + nwg, 1);
+    int stage = 0;
+    for (; t < p.ntiles; t += nwg) {
+        // patch(k) landed for every wave; pool phase of tile k-1 finished -> staging and input stage (k-1)%3 are free
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HP) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int st2 = stage >= 1 ? stage - 1 : kInStages - 1;      // (k+2) % 3 == (k-1) % 3
+        issue_patch(t + 2 * nwg, st2);
+
+        const int b = t / tiles_img, trem = t - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int cy0 = 2 * ty * kTPY - 1, cx0 = 2 * tx * kTPX - 1;   // conv coordinates of conv pixel (0, 0) of the tile
+        const char* in_s = smem + stage * kInStage;
+        // ---- conv phase --------------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) {
+            if (wmi + 4 * i < kNBLK) {                 // wave-uniform
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int f = 0; f < 14; ++f) {
+                    const i32x4 frag = *(const i32x4*)(in_s + fbase[i] + ((f >> 1) * kCPR + 2 * (f & 1)) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[f]), __builtin_bit_cast(bf16x8, frag), acc, 0, 0, 0);
+                }
+                const int q = q_of[i];
+                const bool qv = q < kNQ && (unsigned)(cy0 + cy_of[i]) < (unsigned)p.Ho && (unsigned)(cx0 + cx_of[i]) < (unsigned)p.Wo;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nb = wn * 32 + 8 * g + 4 * half;
+                    const f32x4 sc = *(const f32x4*)(ss + nb);
+                    const f32x4 sh = *(const f32x4*)(ss + 64 + nb);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[4 * g + e] * sc[e];
+                        v[e] += sh[e];
+                        v[e] = qv ? fmaxf(v[e], 0.f) : 0.f;
+                    }
+                    i32x2 o;
+                    o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+                    o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                    *(i32x2*)(stg + q * 128 + (((wn * 4 + g) ^ (q & 7)) << 4) + half * 8) = o;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- pool phase: item = (pooled pixel, 8-channel slot); 1024 items / 512 threads -------------------------
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int item = pass * 512 + tid;
+            const int pp = item >> 3, s = item & 7;
+            const int ly = pp >> 4, lx = pp & 15;
+            s16x8 m;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int q = (2 * ly + dy) * kCX + 2 * lx + dx;
+                    const s16x8 v = *(const s16x8*)(stg + q * 128 + ((s ^ (q & 7)) << 4));
+                    m = (dy == 0 && dx == 0) ? v : __builtin_elementwise_max(m, v);
+                }
+            const int64_t pix = ((int64_t)b * p.Hq + ty * kTPY + ly) * p.Wq + tx * kTPX + lx;
+            *(s16x8*)(p.out + (pix * p.out_pix_stride + s * 8) * 2) = m;
+        }
+        stage = stage + 1 == kInStages ? 0 : stage + 1;
+    }
+}
+
+}  // namespace
+
+extern "C" int vd3d_stem_conv_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out,
+                                   int B, int H, int W, int Kpad, int out_pix_stride, void* stream) {
+    if (!packed || !weight || !out) { vd3d_set_error("stem_conv_pool: null pointer"); return VD3D_EINVAL; }
+    if (B <= 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || (H / 4) % kTPY || (W / 4) % kTPX || Kpad < 224 || out_pix_stride < 64 ||
+        out_pix_stride % 8 || ((uintptr_t)packed & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) {
+        vd3d_set_error("stem_conv_pool: needs H/4 % 8 == 0, W/4 % 16 == 0, Kpad >= 224, 16-byte aligned pointers / rows");
+        return VD3D_EINVAL;
+    }
+    StemArgs a;
+    a.packed = (const char*)packed; a.weight = (const char*)weight; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    a.B = B; a.Hp = H + 6; a.Wp = W + 8; a.Ho = H / 2; a.Wo = W / 2; a.Hq = H / 4; a.Wq = W / 4; a.Kpad = Kpad;
+    a.out_pix_stride = out_pix_stride;
+    const int64_t in_bytes = (int64_t)B * a.Hp * a.Wp * 8;
+    if (in_bytes > 0x7ffffff0ll) { vd3d_set_error("stem_conv_pool: packed image exceeds 2 GiB; split the batch"); return VD3D_ERANGE; }
+    a.in_bytes = (uint32_t)in_bytes;
+    a.ntiles = B * (a.Hq / kTPY) * (a.Wq / kTPX);
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return vd3d_check_launch("hipGetDeviceProperties");
+        if (hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+            return vd3d_check_launch("hipFuncSetAttribute(stem_pool)");
+        num_cu = prop.multiProcessorCount;
+    }
+    const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(512), kLds, (hipStream_t)stream, a);
+    return vd3d_check_launch("stem_conv_pool");
+}

@@ -150,17 +150,44 @@ def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
     return out
 
 
+def _pack_stem_images(img_nchw, dtype):
+    """NCHW fp32 image(s) -> bordered NHWC4 [B, H+6, W+8, 4].  A list / tuple of images is packed into consecutive batch
+    slices (stereo: left then right -- no torch.cat copy)."""
+    imgs = list(img_nchw) if isinstance(img_nchw, (list, tuple)) else [img_nchw]
+    _require_cuda(*imgs)
+    _, Cc, H, W = imgs[0].shape
+    B = sum(int(t.shape[0]) for t in imgs)
+    Hp, Wp = H + 6, W + 8  # 3 px border top/bottom/left, 5 px right (keeps rows 16-byte aligned, covers the 8-px tap)
+    packed = torch.empty((B, Hp, Wp, 4), dtype=dtype, device=imgs[0].device)
+    b0 = 0
+    for t in imgs:
+        assert t.shape[1:] == (3, H, W) and t.dtype == torch.float32 and t.is_contiguous()
+        check(_lib.lib().vd3d_pack_image_nhwc4(_p(t), _p(packed[b0:]), int(t.shape[0]), H, W, 3, 3, 5, dtype_code(dtype), _stream()),
+              'vd3d_pack_image_nhwc4')
+        b0 += int(t.shape[0])
+    return packed, B, H, W
+
+
+def stem_pool_supported(H, W, dtype, Cout):
+    return dtype == torch.bfloat16 and Cout == 64 and H % 4 == 0 and W % 4 == 0 and (H // 4) % 8 == 0 and (W // 4) % 16 == 0
+
+
+def stem_conv_pool(img_nchw, pc, dtype):
+    """Stem conv 7x7/s2 + BN + ReLU + MaxPool(3, 2, 1) fused (vd3d_stem_conv_pool): returns the pooled NHWC map."""
+    packed, B, H, W = _pack_stem_images(img_nchw, dtype)
+    assert stem_pool_supported(H, W, dtype, pc.Cout)
+    out = torch.empty((B, H // 4, W // 4, 64), dtype=dtype, device=packed.device)
+    check(_lib.lib().vd3d_stem_conv_pool(_p(packed), _p(pc.w), _p(pc.scale) if pc.scale is not None else None, _p(pc.shift), _p(out),
+                                         B, H, W, pc.Kpad, 64, _stream()), 'vd3d_stem_conv_pool')
+    return out
+
+
 def stem_conv(img_nchw, pc, dtype):
     """Stem: pack NCHW fp32 image to bordered NHWC4, then the 7x7/s2 conv + BN + ReLU as an implicit GEMM."""
-    _require_cuda(img_nchw)
-    B, Cc, H, W = img_nchw.shape
-    assert Cc == 3 and img_nchw.dtype == torch.float32 and img_nchw.is_contiguous()
-    Hp, Wp = H + 6, W + 8  # 3 px border top/bottom/left, 5 px right (keeps rows 16-byte aligned, covers the 8-px tap)
-    packed = torch.empty((B, Hp, Wp, 4), dtype=dtype, device=img_nchw.device)
-    check(_lib.lib().vd3d_pack_image_nhwc4(_p(img_nchw), _p(packed), B, H, W, 3, 3, 5, dtype_code(dtype), _stream()),
-          'vd3d_pack_image_nhwc4')
+    packed, B, H, W = _pack_stem_images(img_nchw, dtype)
+    Hp, Wp = H + 6, W + 8
     Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
-    out = torch.empty((B, Ho, Wo, pc.Cout), dtype=dtype, device=img_nchw.device)
+    out = torch.empty((B, Ho, Wo, pc.Cout), dtype=dtype, device=packed.device)
     p = ConvParams()
     p.in_, p.weight, p.out = packed.data_ptr(), pc.w.data_ptr(), out.data_ptr()
     p.scale = pc.scale.data_ptr() if pc.scale is not None else None

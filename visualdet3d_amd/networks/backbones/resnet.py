@@ -97,6 +97,7 @@ class ResNet(nn.Module):
             setattr(self, 'layer%d' % (i + 1),
                     self._make_layer(block, self.planes[i], layers[i], stride=self.strides[i], dilation=self.dilations[i]))
         self._cache = fused.PackCache()
+        self.fuse_stem_pool = True
 
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
         downsample = None
@@ -113,17 +114,22 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def forward_nhwc(self, img_nchw, dtype=None, on_stage=None):
-        """``on_stage(i, x)``: optional callback right after stage i's output has been enqueued (the stereo neck uses it to
-        start the work that only depends on that stage on a side stream)."""
-        """img_nchw: [B,3,H,W] fp32 (the reference's input format).  Returns the NHWC feature list."""
+        """img_nchw: [B,3,H,W] fp32 (the reference's input format), or a tuple of such tensors stacked on the batch axis.
+        Returns the NHWC feature list.  ``on_stage(i, x)``: optional callback right after stage i's output has been
+        enqueued (the stereo neck uses it to start the work that only depends on that stage on a side stream)."""
         dtype = dtype or fused.default_compute_dtype()
         pc = self._cache.get(('stem', dtype), [self.conv1.weight] + fused.bn_sources(self.bn1),
                              lambda: ops.pack_stem_conv(self.conv1.weight, fused.bn_tuple(self.bn1), dtype))
         outs = []
-        x = ops.stem_conv(img_nchw.float().contiguous(), pc, dtype)
-        if -1 in self.out_indices:
-            outs.append(x)
-        x = ops.maxpool3x3s2(x)
+        imgs = [t.float().contiguous() for t in img_nchw] if isinstance(img_nchw, (list, tuple)) else img_nchw.float().contiguous()
+        H, W = (imgs[0] if isinstance(imgs, list) else imgs).shape[2:]
+        if self.fuse_stem_pool and -1 not in self.out_indices and ops.stem_pool_supported(H, W, dtype, pc.Cout):
+            x = ops.stem_conv_pool(imgs, pc, dtype)      # conv1 + bn1 + relu + maxpool in one kernel
+        else:
+            x = ops.stem_conv(imgs, pc, dtype)
+            if -1 in self.out_indices:
+                outs.append(x)
+            x = ops.maxpool3x3s2(x)
         for i in range(self.num_stages):
             for blk in getattr(self, 'layer%d' % (i + 1)):
                 x = blk.forward_nhwc(x)

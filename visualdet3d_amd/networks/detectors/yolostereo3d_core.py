@@ -133,14 +133,15 @@ class YoloStereo3DCore(nn.Module):
         layer1 / layer2, so they run on a side HIP stream underneath layer2 / layer3 instead of after layer3: their
         launch gaps and partially-filled rounds disappear from the critical path (fork/join is captured into the hipGraph)."""
         B = left_images.shape[0]
-        images = torch.cat([left_images, right_images], dim=0)  # batch-axis stack of the raw inputs (plumbing)
-        if not self.overlap_neck or not images.is_cuda:
+        images = (left_images, right_images)     # stacked on the batch axis by the stem's image pack (no cat copy)
+        if not self.overlap_neck or not left_images.is_cuda:
             feats = self.backbone.forward_nhwc(images, dtype)
             return self.neck.forward_nhwc(feats, B)
         main = torch.cuda.current_stream()
-        side = self._side_streams.get(images.device)
+        dev = left_images.device
+        side = self._side_streams.get(dev)
         if side is None:
-            side = self._side_streams[images.device] = torch.cuda.Stream(device=images.device)
+            side = self._side_streams[dev] = torch.cuda.Stream(device=dev)
         st = {}
         keep = []
 
