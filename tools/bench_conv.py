@@ -15,6 +15,11 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('head 1408->256', 8, 24, 80, 1408, 256),
 ]
 cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
+
+
+def skip(c, Cout):
+    return (Cout <= 64 and 1 <= c < 30) or (Cout <= 64 and c >= 36 and c != 60) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 40)
+
 import os
 if os.environ.get('VD3D_SHAPES'):
     SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ['VD3D_SHAPES'].split(','))]
@@ -27,32 +32,42 @@ for name, B, H, W, Cin, Cout in SHAPES:
     flops = 2.0 * B * H * W * Cout * 9 * Cin
     ref = None
     line = '%-18s' % name
+    ok_cfgs, best = [], {}
     for c in cfgs:
-        if (Cout <= 64 and c in (1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 36, 37, 38, 21, 22, 23, 24, 25, 27)) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 128 and c == 33) or (Cout <= 64 and c == 29) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 40):
-            line += '  cfg%d    --   ' % c
+        if skip(c, Cout):
             continue
         _lib.lib().vd3d_conv2d_set_tuning(c)
         try:
             out = ops.conv2d(x, pc, residual=res, relu=True)
             torch.cuda.synchronize()
         except Exception as e:
-            line += '  cfg%d ERR' % c
+            best[c] = 'ERR'
             continue
         if ref is None:
             ref = out.float()
-            err = 0.0
-        else:
-            err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(3):
-            ops.conv2d(x, pc, out=out, residual=res, relu=True)
-        s.record()
-        n = 20
-        for _ in range(n):
-            ops.conv2d(x, pc, out=out, residual=res, relu=True)
-        e.record()
-        torch.cuda.synchronize()
-        t = s.elapsed_time(e) / n * 1e-3
-        line += '  cfg%d %6.0f TF%s' % (c, flops / t / 1e12, '' if err < 2e-2 else ' BAD(%.1e)' % err)
+        err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+        if err >= 2e-2:
+            best[c] = 'BAD(%.1e)' % err
+            continue
+        ok_cfgs.append(c)
+        best[c] = 0.0
+    out = torch.empty_like(res)
+    for rnd in range(4):                       # round-robin, several rounds: the first round is a clock warm-up
+        for c in ok_cfgs:
+            _lib.lib().vd3d_conv2d_set_tuning(c)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(3):
+                ops.conv2d(x, pc, out=out, residual=res, relu=True)
+            s.record()
+            n = 20
+            for _ in range(n):
+                ops.conv2d(x, pc, out=out, residual=res, relu=True)
+            e.record()
+            torch.cuda.synchronize()
+            if rnd > 0:
+                best[c] = max(best[c], flops / (s.elapsed_time(e) / n * 1e-3) / 1e12)
+    for c in cfgs:
+        v = best.get(c, '--')
+        line += '  cfg%d %s' % (c, ('%6.0f TF' % v) if isinstance(v, float) else v)
     _lib.lib().vd3d_conv2d_set_tuning(0)
     print(line, flush=True)

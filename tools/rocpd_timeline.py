@@ -10,6 +10,7 @@ path = sys.argv[1]
 if os.path.isdir(path):
     path = sorted(glob.glob(os.path.join(path, '**', '*.db'), recursive=True))[-1]
 first = sys.argv[2] if len(sys.argv) > 2 else 'pack_image'
+per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # launches of that kernel per step (stereo: left, right)
 db = sqlite3.connect(path)
 cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
@@ -21,7 +22,7 @@ name_col = 'display_name' if 'display_name' in scol else 'kernel_name'
 qcol = 'queue_id' if 'queue_id' in kcols else ('stream_id' if 'stream_id' in kcols else 'tid')
 rows = list(cur.execute('select s.%s, d.start, d.end, d.%s from %s d join %s s on d.kernel_id = s.id order by d.start' % (name_col, qcol, kd, ks)))
 idx = [i for i, r in enumerate(rows) if first in r[0]]
-a, b = idx[-2], idx[-1]
+a, b = idx[-2 * per_step], idx[-per_step]
 step = rows[a:b]
 t0 = step[0][1]
 prev_end = t0

@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
 // logical slot (L%8) ^ ((row/2)%8) of its row -- the same 128 contiguous bytes per row, permuted among 8 lanes, so
 // global coalescing is unchanged and the fragment reads keep the conflict-free swizzled addressing.
 // Zero padding still comes from the SRD bounds check (out-of-range lanes write zeros into LDS).
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int ES = (int)sizeof(T);
@@ -595,11 +595,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         for (int g = 0; g < 4; ++g) issue_group(0, g);
         advance_k();
         issue_group(1, 0, p.nk > 1);
+        issue_group(1, 1, p.nk > 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // weight fragments live in a ring of R registers refilled R fragments ahead (R | 4*TN keeps the register <->
         // fragment assignment identical in every slice); pixel fragments are double buffered per sub-step.
-        constexpr int R = TM == 1 ? 4 : (MS == 16 ? 2 : TN);
+        constexpr int R = RING ? RING : (TM == 1 ? 4 : (MS == 16 ? 2 : TN));
         static_assert((NSUB * TN) % R == 0 && R <= TN, "fragment ring");
         constexpr int F0 = NSUB * TN - R;      // first fragment whose refill comes from the NEXT slice: the barrier sits here
         i32x4 fa[R], fb[2][TM];
@@ -622,7 +623,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
+                    // DMA of slice t+2: half of it here, the rest at the top of the next slice -- everything is in flight
+                    // within the first tenth of a slice, i.e. has ~0.9 slice times to land before its barrier (PMC: with
+                    // the pieces spread evenly over the slice a third of the wave cycles were spent parked at that barrier)
                     issue_group(st, 0, more2);
+                    issue_group(st, 1, more2);
                 }
                 if ((i == 0 && ks < NSUB - 1) || f == F0) {
                     // pixel fragments of the next sub-step (past the last slice they read a dead stage; never consumed)
@@ -632,11 +637,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
                 }
                 if (i == 0 && ks == 0) {
-                    issue_group(st ^ 1, 1, more1);
                     issue_group(st ^ 1, 2, more1);
-                    if (NSUB == 2) { issue_group(st ^ 1, 3, more1); advance_k(); }
+                    issue_group(st ^ 1, 3, more1);
+                    advance_k();
                 }
-                if (NSUB == 4 && i == 0 && ks == 1) { issue_group(st ^ 1, 3, more1); advance_k(); }
 #pragma unroll
                 for (int j = 0; j < TM; ++j) MmaShape<T, MS>::run(fa[f % R], fb[ks & 1][j], acc[i][j]);
                 const int nf = f + R, nks = nf / TN, ni = nf - nks * TN;
@@ -646,10 +650,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 const int i0 = ks == NSUB - 1 ? TN - R : 0, nfr = TN - i0;
-                const int D = NSUB == 4 ? (ks == 0 ? group_size(1) + group_size(2) : (ks == 1 ? group_size(3) : (ks == 3 ? group_size(0) : 0)))
-                                        : (ks == 0 ? group_size(1) + group_size(2) + group_size(3) : group_size(0));
+                const int D = ks == 0 ? group_size(2) + group_size(3) : (ks == NSUB - 1 ? group_size(0) + group_size(1) : 0);
                 const int o = i - i0;
-                const int q = o >= 0 ? (D * (o + 1)) / nfr - (D * o) / nfr : 0;
+                // front-loaded: ceil(D / nfr) pieces per fragment but at least 2, until the sub-step's pieces are placed
+                const int per = (D + nfr - 1) / nfr > 2 ? (D + nfr - 1) / nfr : 2;
+                const int q = o >= 0 ? (D - per * o > per ? per : (D - per * o > 0 ? D - per * o : 0)) : 0;
                 if (q >= 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (q >= 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (q >= 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -1044,7 +1049,7 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_halo");
 }
 
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
@@ -1052,7 +1057,7 @@ int launch(ConvArgs& a, hipStream_t stream) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static bool attr_done = false;
     void (*kern)(const ConvArgs);
-    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS>;
+    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -1086,6 +1091,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 44: return launch<T, 128, 128, 2, 2, true, true>(a, stream);
         case 50: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream); else break;
         case 51: if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16>(a, stream); else break;
+        case 54: if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream); else break;
         case 21: return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
         case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
@@ -1151,7 +1157,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
             if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream);
             else return launch<T, 256, 352, 8, 1, true, true>(a, stream);
         case 3:
-            if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16>(a, stream);
+            if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream);   // ring of 6: +4 % over 2
             else return launch<T, 256, 288, 8, 1, true, true>(a, stream);
         case 4: return launch<T, 128, 352, 4, 1, true>(a, stream);
         case 5: return launch<T, 128, 288, 4, 1, true>(a, stream);
