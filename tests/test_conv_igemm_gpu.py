@@ -185,3 +185,15 @@ def test_stem_conv_pool_fused():
         assert float((d > 0).float().mean()) < 1e-4 and bool((d <= unfused.float().abs() * 2.0 ** -7 + 1e-30).all()), d.max()
         err = (got.float().cpu().permute(0, 3, 1, 2) - want).abs().max().item() / want.abs().max().item()
         assert err < 1e-2, err
+
+
+@pytest.mark.parametrize('shape', [
+    (2, 16, 64, 128, 128, 3, 1, 1, 1, True, True),      # halo kernel 8x32 px x 128 ch (layer2)
+    (2, 16, 32, 256, 256, 3, 1, 1, 1, True, True),      # halo kernel 8x16 px x 256 ch (layer3)
+    (1, 8, 16, 256, 256, 3, 1, 1, 1, False, False),     # one tile
+    (1, 16, 32, 1408, 256, 3, 1, 1, 1, False, True),    # long K, 8x16 px x 128 ch (cls conv)
+    (1, 24, 80, 64, 128, 3, 1, 1, 1, False, True),      # single 64-channel chunk (9 steps)
+])
+def test_conv_halo_kernel_shapes(shape):
+    assert _case(*shape, dtype=torch.bfloat16) < 1e-2
+    assert _case(*shape, dtype=torch.float32) < 5e-5
