@@ -73,6 +73,16 @@ int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream);
  * drop-in surface. */
 int vd3d_conv2d_set_tuning(int cfg);
 
+/* Test-time image pipeline for ONE frame, fed from uint8 (data/pipeline/stereo_augmentator.py: ConvertToFloat :30-36,
+ * CropTop :214-249, Resize :62-134 = cv2.resize INTER_LINEAR on float32 + crop / zero-pad to the network width, Normalize
+ * :39-59) fused with the collate_fn's HWC -> CHW float cast (data/kitti/dataset/stereo_dataset.py:141-157).
+ *   src_hwc: [Hs][Ws][3] uint8 (host-visible or device memory reachable by the GPU: pass a device pointer);
+ *   (Hr, Wr): size after Resize (the host rounds like stereo_augmentator.py:78-80); (H, W): network input (Hr >= H);
+ *   out_nchw: fp32 [3][H][W] (the reference's network input) or NULL; out_packed: bf16 [H+6][W+8][4] zero-bordered NHWC4
+ *   (what vd3d_stem_conv_pool / the stem conv read) or NULL; mean3 / std3: host pointers to 3 floats. */
+int vd3d_preprocess_image(const uint8_t* src_hwc, int Hs, int Ws, int crop_top, int Hr, int Wr, float* out_nchw,
+                          void* out_packed, int H, int W, const float* mean3, const float* std3, void* stream);
+
 /* Stem input packing: NCHW fp32 image -> zero-bordered NHWC4 (3 channels + 1 zero) so that one kernel row of
  * the 7x7/s2 stem (backbones/resnet.py:118, conv1) is 8 px * 4 ch = 32 contiguous elements.
  * out: [B][H+2*pad_y][W+pad_l+pad_r][4] of `dtype`; borders are written as zeros. */
@@ -235,6 +245,16 @@ int vd3d_look_ground_sample(const void* x, const float* disp, const float* P2s, 
  *          (hill_climbing.py:111-113). */
 int vd3d_post_opt(float* boxes, const int32_t* labels, const int32_t* counts, const float* P2s, int B, int cap,
                   float clamp_w, float clamp_h, float min_depth, int target_label, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Post-path geometry of pipelines/evaluators.py:112-129 (test_one) for a padded batch of detections, one launch:
+ * BackProjection (networks/utils/utils.py:262-278), theta = alpha2theta_3d (utils/utils.py:47-62), 2D-box shift + rescale to
+ * the original image (evaluators.py:118-127), bottom-centre y (data/kitti/utils.py:180-182).
+ *   boxes [B][cap][11] fp32 (x1,y1,x2,y2,cx,cy,z,w,h,l,alpha); counts [B] int32 or NULL; P2s [B][3][4] (network-input
+ *   calibration); xform [B][4] = shift_left, shift_top, scale_x, scale_y (computed by the host in fp64 as evaluators.py:118-122);
+ *   out [B][cap][12] fp32 = x1,y1,x2,y2 (original image), x3d, y_bottom, z, w, h, l, alpha, theta (rows >= count are zero). */
+int vd3d_kitti_postpath(const float* boxes, const int32_t* counts, const float* P2s, const float* xform, float* out,
+                        int B, int cap, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * KM3D / RTM3D keypoint-head decoding (heads/km3d_head.py:155-314 _decode + get_bboxes; networks/utils/rtm3d_utils.py

@@ -98,6 +98,8 @@ SIGNATURES = {
     'vd3d_km3d_workspace_bytes': (c_int64, [c_int] * 5),
     'vd3d_km3d_decode': (c_int, [C.POINTER(Km3dParams), c_void_p]),
     'vd3d_stem_conv_pool': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    'vd3d_kitti_postpath': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    'vd3d_preprocess_image': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vd3d_post_opt': (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_float] * 3 + [c_int, c_void_p]),
 }
 # declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)

@@ -562,3 +562,62 @@ def post_opt_batched(boxes, labels, counts, P2s, clamp_wh=(1280.0, 288.0), min_d
                                    float(clamp_wh[0]), float(clamp_wh[1]), float(min_depth), int(target_label), _stream()),
           'vd3d_post_opt')
     return boxes
+
+
+def kitti_postpath(boxes, counts, P2s, xform):
+    """Batched post-path geometry (pipelines/evaluators.py:112-129): boxes [B,K,11] fp32, counts [B] int32 or None,
+    P2s [B,3,4], xform [B,4] = (shift_left, shift_top, scale_x, scale_y).  Returns [B,K,12] fp32 rows
+    (x1,y1,x2,y2 in the original image, x3d, y_bottom, z, w, h, l, alpha, theta)."""
+    _require_cuda(boxes, P2s, xform)
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.dim() == 3 and boxes.shape[2] == 11
+    B, K = boxes.shape[:2]
+    P2s = P2s.float().contiguous()
+    xform = xform.float().contiguous()
+    assert P2s.shape == (B, 3, 4) and xform.shape == (B, 4)
+    if counts is not None:
+        assert counts.dtype == torch.int32 and counts.shape == (B,) and counts.is_contiguous()
+    out = torch.empty((B, K, 12), dtype=torch.float32, device=boxes.device)
+    check(_lib.lib().vd3d_kitti_postpath(_p(boxes), _p(counts) if counts is not None else None, _p(P2s), _p(xform), _p(out), B, K,
+                                         _stream()), 'vd3d_kitti_postpath')
+    return out
+
+
+def resized_shape(Hs, Ws, crop_top, size):
+    """(Hr, Wr, scale) of Resize(size, preserve_aspect_ratio=True) after CropTop (stereo_augmentator.py:75-80)."""
+    import numpy as np
+    hc = Hs - crop_top
+    scale = size[0] / hc
+    return int(np.round(hc * scale).astype(int)), int(np.round(Ws * scale).astype(int)), scale
+
+
+def adjust_calib(P, crop_top, scale):
+    """CropTop (:236-242) then Resize (:114-120) applied to a [3,4] projection matrix, float64 like the reference's numpy."""
+    import numpy as np
+    P = np.array(P, dtype=np.float64, copy=True)
+    P[1, 2] = P[1, 2] - crop_top
+    P[1, 3] = P[1, 3] - crop_top * P[2, 3]
+    P[0, :] = P[0, :] * scale
+    P[1, :] = P[1, :] * scale
+    return P
+
+
+def preprocess_images(frames_u8, crop_top, size, mean, std, packed=False):
+    """uint8 HWC frames (list of [Hs,Ws,3] cuda tensors, or one [B,Hs,Ws,3]) -> the network input: fp32 NCHW [B,3,H,W]
+    (``packed=False``: what the reference's pipeline + collate_fn produce) or the bordered NHWC4 bf16 image of the fused stem
+    (``packed=True``)."""
+    frames = list(frames_u8)
+    _require_cuda(*frames)
+    H, W = int(size[0]), int(size[1])
+    B = len(frames)
+    dev = frames[0].device
+    out = (torch.empty((B, H + 6, W + 8, 4), dtype=torch.bfloat16, device=dev) if packed
+           else torch.empty((B, 3, H, W), dtype=torch.float32, device=dev))
+    m = (C.c_float * 3)(*[float(v) for v in mean])
+    sd = (C.c_float * 3)(*[float(v) for v in std])
+    for b, f in enumerate(frames):
+        assert f.dtype == torch.uint8 and f.dim() == 3 and f.shape[2] == 3 and f.is_contiguous()
+        Hs, Ws = int(f.shape[0]), int(f.shape[1])
+        Hr, Wr, _ = resized_shape(Hs, Ws, crop_top, size)
+        check(_lib.lib().vd3d_preprocess_image(_p(f), Hs, Ws, int(crop_top), Hr, Wr, None if packed else _p(out[b]),
+                                               _p(out[b]) if packed else None, H, W, m, sd, _stream()), 'vd3d_preprocess_image')
+    return out
