@@ -247,6 +247,13 @@ int vd3d_post_opt(float* boxes, const int32_t* labels, const int32_t* counts, co
                   float clamp_w, float clamp_h, float min_depth, int target_label, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Rotated-rectangle IoU of the KITTI AP evaluator (evaluator/kitti/rotate_iou.py:261-328 rotate_iou_gpu_eval, a numba.cuda
+ * kernel in the reference; callers evaluator/kitti/eval.py:124,173).  boxes [N][5], query_boxes [K][5] = (cx, cy, dx, dy, angle)
+ * fp32; iou [N][K] fp32.  criterion -1: inter / union, 0: inter / area(query), 1: inter / area(box), other: the intersection
+ * area (rotate_iou.py:245-258; note the kernel passes the QUERY box first, :290-291). */
+int vd3d_rotate_iou_eval(const float* boxes, const float* query_boxes, int N, int K, int criterion, float* iou, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Post-path geometry of pipelines/evaluators.py:112-129 (test_one) for a padded batch of detections, one launch:
  * BackProjection (networks/utils/utils.py:262-278), theta = alpha2theta_3d (utils/utils.py:47-62), 2D-box shift + rescale to
  * the original image (evaluators.py:118-127), bottom-centre y (data/kitti/utils.py:180-182).
