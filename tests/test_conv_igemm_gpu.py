@@ -197,3 +197,19 @@ def test_stem_conv_pool_fused():
 def test_conv_halo_kernel_shapes(shape):
     assert _case(*shape, dtype=torch.bfloat16) < 1e-2
     assert _case(*shape, dtype=torch.float32) < 5e-5
+
+
+def test_conv_batch_chunking_for_large_views(monkeypatch):
+    """Inputs whose view spans more than the 32-bit buffer range are processed in batch chunks (hit by KM3D's head at B = 16,
+    512 x 1760): force the path with a small limit and compare with the one-launch result."""
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(5, 16, 32, 192, generator=g).cuda().to(torch.bfloat16)
+    w = torch.randn(64, 64, 3, 3, generator=g).cuda() * 0.05
+    pc = ops.pack_conv(w, None, None, torch.bfloat16, 1, 1, 1)
+    res = torch.randn(5, 16, 32, 64, generator=g).cuda().to(torch.bfloat16)
+    xv = x[..., 64:128]                                   # channel slice of a wider buffer
+    want = ops.conv2d(xv, pc, residual=res, relu=True)
+    monkeypatch.setattr(ops, '_MAX_IN_BYTES', 2 * 16 * 32 * 192 * 2 + 100)
+    got = ops.conv2d(xv, pc, residual=res, relu=True)
+    assert torch.equal(got, want)

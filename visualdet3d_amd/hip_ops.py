@@ -119,12 +119,28 @@ def pack_stem_conv(weight, bn, dtype):
     return PackedConv(packed, scale, shift, 32, O, 7, 1, 2, 0, 1, Kpad, CoutPad, dtype)
 
 
+_MAX_IN_BYTES = 0x7ffffff0      # the kernels address the input with 32-bit buffer offsets
+
+
 def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
-    """Fused conv (+bias/BN) (+residual) (+ReLU).  x: NHWC (C >= pc.Cin used), returns NHWC ``[B,Ho,Wo,Cout]``."""
+    """Fused conv (+bias/BN) (+residual) (+ReLU).  x: NHWC (C >= pc.Cin used), returns NHWC ``[B,Ho,Wo,Cout]``.  An input
+    view spanning more than 2 GiB (e.g. a channel slice of KM3D's 9 x 256-channel head buffer at 16 x 128 x 440) is processed
+    in batch chunks."""
     _require_cuda(x, pc.w, out, residual)
     B, H, W, Cx = x.shape
     assert x.dtype == pc.dtype and Cx == pc.Cin, (x.dtype, pc.dtype, Cx, pc.Cin)
     ips, irs, ibs = _nhwc_strides(x)
+    span1 = ((H - 1) * irs + (W - 1) * ips + Cx) * x.element_size()          # bytes one sample's view reaches over
+    if B > 1 and (B - 1) * ibs * x.element_size() + span1 > _MAX_IN_BYTES:
+        nb = max(1, (_MAX_IN_BYTES - span1) // (ibs * x.element_size()) + 1)
+        Ho_ = (H + 2 * pc.pad - pc.dil * (pc.kh - 1) - 1) // pc.stride + 1
+        Wo_ = (W + 2 * pc.pad - pc.dil * (pc.kw - 1) - 1) // pc.stride + 1
+        if out is None:
+            out = torch.empty((B, Ho_, Wo_, pc.Cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+        for b0 in range(0, B, nb):
+            conv2d(x[b0:b0 + nb], pc, out=out[b0:b0 + nb], residual=None if residual is None else residual[b0:b0 + nb],
+                   relu=relu, out_f32=out_f32)
+        return out
     Ho = (H + 2 * pc.pad - pc.dil * (pc.kh - 1) - 1) // pc.stride + 1
     Wo = (W + 2 * pc.pad - pc.dil * (pc.kw - 1) - 1) // pc.stride + 1
     odt = torch.float32 if out_f32 else x.dtype
@@ -140,7 +156,7 @@ def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
         p.residual, p.res_pix_stride = residual.data_ptr(), residual.stride(2)
     p.B, p.H, p.W, p.Cin = B, H, W, pc.Cin
     p.in_pix_stride, p.in_row_stride, p.in_batch_stride = ips, irs, ibs
-    p.in_bytes = _bytes_from(x)
+    p.in_bytes = min(_bytes_from(x), (B - 1) * ibs * x.element_size() + span1)
     p.Ho, p.Wo, p.Cout = Ho, Wo, pc.Cout
     p.out_pix_stride = out.stride(2)
     p.kh, p.kw, p.stride, p.pad, p.dil = pc.kh, pc.kw, pc.stride, pc.pad, pc.dil
