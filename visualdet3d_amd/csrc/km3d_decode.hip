@@ -46,35 +46,52 @@ __global__ void km3d_zero_kernel(int32_t* a, int n) {
 }
 
 // ---- 1. peaks -----------------------------------------------------------------------------------------------------
+// One (sample, channel) per blockIdx.y, consecutive pixels per lane: the append is wave-aggregated (one atomicAdd per wave and
+// channel instead of one per peak -- with many candidates, e.g. untrained weights, per-peak atomics on B x 12 counters
+// serialise the whole kernel).  The order inside a list is irrelevant: the top-K kernel sorts it.
 __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
     const int nch = p.n_cls + p.J;
-    const int64_t total = (int64_t)p.B * p.H * p.W * nch;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % nch);
-        const int64_t pix = i / nch;
-        const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), b = (int)(pix / ((int64_t)p.W * p.H));
-        const bool is_hm = ch < p.n_cls;
-        const float* m = is_hm ? p.hm : p.hm_hp;
-        const int C = is_hm ? p.n_cls : p.J, c = is_hm ? ch : ch - p.n_cls;
-        const float thr = is_hm ? p.score_thr : 0.1f;
-        const float v = sigm(m[pix * C + c]);
-        if (!(v > thr)) continue;
-        bool peak = true;
-        for (int dy = -1; dy <= 1 && peak; ++dy) {
-            const int yy = y + dy;
-            if ((unsigned)yy >= (unsigned)p.H) continue;
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if ((unsigned)xx >= (unsigned)p.W || (dx == 0 && dy == 0)) continue;
-                if (sigm(m[(((int64_t)b * p.H + yy) * p.W + xx) * C + c]) > v) { peak = false; break; }
+    const int slot = blockIdx.y;                       // b * nch + ch
+    const int b = slot / nch, ch = slot - b * nch;
+    const bool is_hm = ch < p.n_cls;
+    const float* m = (is_hm ? p.hm : p.hm_hp);
+    const int C = is_hm ? p.n_cls : p.J, c = is_hm ? ch : ch - p.n_cls;
+    const float thr = is_hm ? p.score_thr : 0.1f;
+    const int HW = p.H * p.W;
+    const float* mb = m + (int64_t)b * HW * C + c;
+    const int lane = threadIdx.x & 63;
+    for (int base = blockIdx.x * blockDim.x; base < HW; base += gridDim.x * blockDim.x) {
+        const int pix = base + threadIdx.x;
+        bool peak = false;
+        float v = 0.f;
+        if (pix < HW) {
+            const int y = pix / p.W, x = pix - y * p.W;
+            v = sigm(mb[(int64_t)pix * C]);
+            if (v > thr) {
+                peak = true;
+                for (int dy = -1; dy <= 1 && peak; ++dy) {
+                    const int yy = y + dy;
+                    if ((unsigned)yy >= (unsigned)p.H) continue;
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int xx = x + dx;
+                        if ((unsigned)xx >= (unsigned)p.W || (dx == 0 && dy == 0)) continue;
+                        if (sigm(mb[((int64_t)yy * p.W + xx) * C]) > v) { peak = false; break; }
+                    }
+                }
             }
         }
-        if (!peak) continue;
-        const int slot = b * nch + ch;
-        const int pos = atomicAdd(p.peak_count + slot, 1);
-        if (pos < p.max_peaks) {
-            p.peak_score[(int64_t)slot * p.max_peaks + pos] = v;
-            p.peak_idx[(int64_t)slot * p.max_peaks + pos] = y * p.W + x;
+        const uint64_t mask = __ballot(peak);
+        if (mask) {
+            int pos0 = 0;
+            if (lane == 0) pos0 = atomicAdd(p.peak_count + slot, __popcll(mask));
+            pos0 = __shfl(pos0, 0);
+            if (peak) {
+                const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < p.max_peaks) {
+                    p.peak_score[(int64_t)slot * p.max_peaks + pos] = v;
+                    p.peak_idx[(int64_t)slot * p.max_peaks + pos] = pix;
+                }
+            }
         }
     }
 }
@@ -335,10 +352,9 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_cls = q->out_cls; a.out_count = q->out_count;
     const int nz = (int)(((int64_t)q->B * nch * 4 + 255) / 256 * 256 + (int64_t)q->B * 4) / 4;
     hipLaunchKernelGGL(km3d_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, w.peak_count, nz);
-    const int64_t total = (int64_t)q->B * q->H * q->W * nch;
-    int64_t g = (total + 255) / 256;
-    if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(km3d_peaks_kernel, dim3((unsigned)g), dim3(256), 0, s, a);
+    int gx = (q->H * q->W + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(km3d_peaks_kernel, dim3((unsigned)gx, (unsigned)(q->B * nch)), dim3(256), 0, s, a);
     int rc = vd3d_check_launch("km3d_peaks");
     if (rc) return rc;
     const int lds = q->max_peaks * 8;
