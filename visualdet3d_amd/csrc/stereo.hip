@@ -10,6 +10,7 @@
 //  * conv3d_3x3x3 : the two Conv3d+BN3d+ReLU of CostVolume (lib/PSM_cost_volume.py:34-41), direct fp32 FMA
 //                   (C <= 16: 0.25 GFLOP per pair, not MFMA-shaped); weights are wave-uniform -> scalar loads.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -184,6 +185,83 @@ __global__ void __launch_bounds__(256) conv3d_kernel(const T* __restrict__ in, c
     }
 }
 
+// 3x3x3 conv on the matrix cores (bf16, COUT = 8): the volume conv of the cost-volume block is a GEMM with M = voxels,
+// N = 8, K = 27 * CIN.  v_mfma_f32_16x16x32_bf16 with the weights as the A operand (rows 8..15 zero) and 16 voxels as the
+// B operand: one K slice of 32 = 2 taps x 16 channels (CIN 16) or 4 taps x 8 channels (CIN 8), so lane (voxel, q) fetches
+// its 16 bytes = 8 channels of ONE neighbour voxel straight from global memory -- no LDS, zero padding by predication.
+// The weight fragments (14 / 7 per lane) are built once per wave in registers; waves walk 16-voxel groups grid-stride.
+// The VALU kernel above (one voxel per lane, 3456 scalar FMAs each) ran at 12 % of the fp32 vector peak: 86 + 49 us per
+// stereo step for 2 GFLOP; it remains the fp32 (validation mode) path.
+template <int CIN>
+__global__ void __launch_bounds__(256) conv3d_mfma_kernel(const short* __restrict__ in, const float* __restrict__ w,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          short* __restrict__ out, int B, int D, int H, int W, int relu,
+                                                          int out_fd_major, int ops) {
+    constexpr int COUT = 8;
+    constexpr int TPS = 32 / CIN;                    // taps per 32-deep K slice: 2 or 4
+    constexpr int NS = (27 + TPS - 1) / TPS;         // 14 or 7 slices
+    const int lane = threadIdx.x & 63, l16 = lane & 15, q = lane >> 4;
+    const int my_tap_off = CIN == 16 ? (q >> 1) : q; // tap of this lane inside a slice
+    const int my_ch = CIN == 16 ? 8 * (q & 1) : 0;   // first of its 8 channels
+    // weight fragments: row = output channel l16 (zero for rows >= 8), k = this lane's 8 (tap, channel) values
+    i32x4 wf[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int tap = s * TPS + my_tap_off;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (l16 < COUT && tap < 27) ? w[(tap * CIN + my_ch + e) * COUT + l16] : 0.f;
+        Vec16<short> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o.set2(e, v[2 * e], v[2 * e + 1]);
+        wf[s] = o.raw;
+    }
+    const int64_t total = (int64_t)B * D * H * W;
+    const int64_t ngroups = (total + 15) / 16;
+    const int64_t wave_id = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t g = wave_id; g < ngroups; g += nwaves) {
+        const int64_t vox = g * 16 + l16;
+        const bool vvalid = vox < total;
+        int64_t r = vvalid ? vox : 0;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); r /= H;
+        const int d = (int)(r % D);
+        const int b = (int)(r / D);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int tap = s * TPS + my_tap_off;
+            const int kd = tap / 9, ky = (tap - kd * 9) / 3, kx = tap - kd * 9 - ky * 3;
+            const int id = d - 1 + kd, iy = y - 1 + ky, ix = x - 1 + kx;
+            const bool ok = vvalid && tap < 27 && (unsigned)id < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            i32x4 frag = {0, 0, 0, 0};
+            if (ok) frag = *(const i32x4*)(in + ((((int64_t)b * D + id) * H + iy) * W + ix) * CIN + my_ch);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[s]), __builtin_bit_cast(bf16x8, frag), acc, 0, 0, 0);
+        }
+        // accumulator: lane (voxel l16, q) holds output channels 4q .. 4q+3; q >= 2 are the zero padding rows
+        if (vvalid && q < 2) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int o = 4 * q + e;
+                const float t = acc[e] * scale[o] + shift[o];
+                v[e] = relu ? fmaxf(t, 0.f) : t;
+            }
+            if (out_fd_major) {
+                short* dst = out + (((int64_t)b * H + y) * W + x) * ops;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[(4 * q + e) * D + d] = f2bf(v[e]);
+            } else {
+                i32x2 o2;
+                o2[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+                o2[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                *(i32x2*)(out + vox * COUT + 4 * q) = o2;
+            }
+        }
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -237,7 +315,12 @@ extern "C" int vd3d_conv3d_3x3x3(const void* in, const float* weight, const floa
 #define VD3D_C3D(T, CI, CO)                                                                                         \
     hipLaunchKernelGGL((conv3d_kernel<T, CI, CO>), dim3(grid), dim3(256), 0, s, (const T*)in, weight, scale, shift, \
                        (T*)out, B, D, H, W, relu, out_fd_major, ops)
-    if (Cin == 16 && Cout == 8) { if (dtype == VD3D_BF16) VD3D_C3D(short, 16, 8); else VD3D_C3D(float, 16, 8); }
+    const unsigned mgrid = (unsigned)(((total + 15) / 16 + 3) / 4 < 2048 ? ((total + 15) / 16 + 3) / 4 : 2048);   // 4 waves / block
+    if (dtype == VD3D_BF16 && Cout == 8 && (Cin == 16 || Cin == 8) && ((uintptr_t)in & 15) == 0 && !getenv("VD3D_CONV3D_VALU")) {
+        if (Cin == 16) hipLaunchKernelGGL(conv3d_mfma_kernel<16>, dim3(mgrid), dim3(256), 0, s, (const short*)in, weight, scale, shift, (short*)out, B, D, H, W, relu, out_fd_major, ops);
+        else hipLaunchKernelGGL(conv3d_mfma_kernel<8>, dim3(mgrid), dim3(256), 0, s, (const short*)in, weight, scale, shift, (short*)out, B, D, H, W, relu, out_fd_major, ops);
+    }
+    else if (Cin == 16 && Cout == 8) { if (dtype == VD3D_BF16) VD3D_C3D(short, 16, 8); else VD3D_C3D(float, 16, 8); }
     else if (Cin == 8 && Cout == 8) { if (dtype == VD3D_BF16) VD3D_C3D(short, 8, 8); else VD3D_C3D(float, 8, 8); }
     else { vd3d_set_error("conv3d: only (Cin,Cout) in {(16,8),(8,8)} are instantiated (CostVolume PSM_features=8)"); return VD3D_EINVAL; }
 #undef VD3D_C3D
