@@ -222,12 +222,13 @@ __global__ void __launch_bounds__(256) dcn_kernel(const DcnArgs p) {
 //   * column and weight tiles are double buffered in LDS: sampling of slice k+1 overlaps the MFMAs of slice k, one barrier
 //     per slice.
 template <typename T, int BN>
-__global__ void __launch_bounds__(256) dcn_nhwc_kernel(const DcnArgs p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ? 2 : 4, 8))) dcn_nhwc_kernel(const DcnArgs p) {
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES, BKE = 128 / ES;
     constexpr int TN = BN / 64;                      // 32-channel MFMA blocks per wave (2 x 2 waves: 32 px x BN/2 ch)
     constexpr int STAGE = (64 + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* geo_tab = smem + 2 * STAGE;                // [tap][64 pixels] x { int32 off[4]; float w[4] (already x modulation) }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z;
@@ -246,35 +247,59 @@ __global__ void __launch_bounds__(256) dcn_nhwc_kernel(const DcnArgs p) {
     const int chunks = p.Cg / BKE;                   // K slices per tap
     const int nk = KK * chunks;
 
-    struct Geo { int64_t o[4]; float w[4]; float m; };
+    // ---- phase 0: the sampling geometry of every (pixel, tap) of the tile, once, into LDS.  In the K loop a thread then
+    // needs no dependent global load (offset -> address -> corner): the corner loads of slice k+1 are issued straight away
+    // and overlap the MFMAs of slice k.
+    for (int it = tid; it < 64 * KK; it += 256) {
+        const int tap = it >> 6, px = it & 63;
+        const int pix = pix0 + px;
+        int32_t go[4] = {0, 0, 0, 0};
+        float gw[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pix < HoWo) {
+            const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+            const int ti = tap / p.kw, tj = tap - ti * p.kw;
+            const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
+            const float off_h = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
+            const float off_w = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+            float m = 1.f;
+            if (p.mask) {
+                m = p.mask[b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx + (int64_t)tap * p.msk_sc];
+                if (p.mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
+            }
+            const float h_im = (float)(oy * p.sh - p.ph + ti * p.dh) + off_h;
+            const float w_im = (float)(ox * p.sw - p.pw + tj * p.dw) + off_w;
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
+                if (t_ok && l_ok) { gw[0] = hh * hw; go[0] = (int32_t)((h_low * p.in_sy + w_low * p.in_sx) * ES); }
+                if (t_ok && r_ok) { gw[1] = hh * lw; go[1] = (int32_t)((h_low * p.in_sy + w_high * p.in_sx) * ES); }
+                if (b_ok && l_ok) { gw[2] = lh * hw; go[2] = (int32_t)((h_high * p.in_sy + w_low * p.in_sx) * ES); }
+                if (b_ok && r_ok) { gw[3] = lh * lw; go[3] = (int32_t)((h_high * p.in_sy + w_high * p.in_sx) * ES); }
+                // weights stay unmodulated: the modulation multiplies the blended value (reference order)
+                *(float*)(geo_tab + (size_t)it * 48 + 32) = m;
+            } else {
+                *(float*)(geo_tab + (size_t)it * 48 + 32) = 0.f;
+            }
+        } else {
+            *(float*)(geo_tab + (size_t)it * 48 + 32) = 0.f;
+        }
+        *(i32x4*)(geo_tab + (size_t)it * 48) = i32x4{go[0], go[1], go[2], go[3]};
+        *(f32x4*)(geo_tab + (size_t)it * 48 + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
+    }
+    __syncthreads();
+
+    struct Geo { int32_t o[4]; float w[4]; float m; };
     auto geometry = [&](int tap) {
         Geo g;
+        const char* e = geo_tab + (size_t)(tap * 64 + srow) * 48;
+        const i32x4 go = *(const i32x4*)e;
+        const f32x4 gw = *(const f32x4*)(e + 16);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { g.o[c] = 0; g.w[c] = 0.f; }
-        g.m = 0.f;
-        if (!pvalid) return g;
-        const int ti = tap / p.kw, tj = tap - ti * p.kw;
-        const float off_h = p.offset[off_base + (int64_t)(2 * tap) * p.off_sc];
-        const float off_w = p.offset[off_base + (int64_t)(2 * tap + 1) * p.off_sc];
-        float m = 1.f;
-        if (p.mask) {
-            m = p.mask[msk_base + (int64_t)tap * p.msk_sc];
-            if (p.mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
-        }
-        const float h_im = (float)(h_in + ti * p.dh) + off_h;
-        const float w_im = (float)(w_in + tj * p.dw) + off_w;
-        if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-            const int h_high = h_low + 1, w_high = w_low + 1;
-            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
-            if (t_ok && l_ok) { g.w[0] = hh * hw; g.o[0] = (h_low * p.in_sy + w_low * p.in_sx) * ES; }
-            if (t_ok && r_ok) { g.w[1] = hh * lw; g.o[1] = (h_low * p.in_sy + w_high * p.in_sx) * ES; }
-            if (b_ok && l_ok) { g.w[2] = lh * hw; g.o[2] = (h_high * p.in_sy + w_low * p.in_sx) * ES; }
-            if (b_ok && r_ok) { g.w[3] = lh * lw; g.o[3] = (h_high * p.in_sy + w_high * p.in_sx) * ES; }
-            g.m = m;
-        }
+        for (int c = 0; c < 4; ++c) { g.o[c] = go[c]; g.w[c] = gw[c]; }
+        g.m = *(const float*)(e + 32);
         return g;
     };
     // global -> registers for slice kt (sampled column vectors + this thread's share of the weight tile)
@@ -311,7 +336,13 @@ __global__ void __launch_bounds__(256) dcn_nhwc_kernel(const DcnArgs p) {
             float vals[VE];
 #pragma unroll
             for (int e = 0; e < VE; ++e) {
-                const float val = geo.w[0] * c1.get(e) + geo.w[1] * c2.get(e) + geo.w[2] * c3.get(e) + geo.w[3] * c4.get(e);
+                float val;
+                if constexpr (sizeof(T) == 2) {
+                    // bf16 mode: the result is rounded to bf16 anyway -- fused multiply-adds (4 ops instead of 7)
+                    val = fmaf(geo.w[3], c4.get(e), fmaf(geo.w[2], c3.get(e), fmaf(geo.w[1], c2.get(e), geo.w[0] * c1.get(e))));
+                } else {
+                    val = geo.w[0] * c1.get(e) + geo.w[1] * c2.get(e) + geo.w[2] * c3.get(e) + geo.w[3] * c4.get(e);
+                }
                 vals[e] = val * geo.m;
             }
             if constexpr (sizeof(T) == 2) {
@@ -407,10 +438,11 @@ __global__ void __launch_bounds__(256) dcn_nhwc_kernel(const DcnArgs p) {
 
 template <typename T, int BN>
 int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * (64 + BN) * 128;
+    const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * 48;   // two stages + the geometry table
+    if (LDS > 160 * 1024) { vd3d_set_error("deform_conv: kernel window too large for the NHWC path"); return VD3D_EINVAL; }
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)dcn_nhwc_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)dcn_nhwc_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return vd3d_check_launch("hipFuncSetAttribute(dcn_nhwc)");
         attr_done = true;
     }
@@ -453,6 +485,7 @@ int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
     if (a.Ho <= 0 || a.Wo <= 0 || q->B <= 0) { vd3d_set_error("deform_conv: empty output"); return VD3D_EINVAL; }
     // channel-contiguous activations, one group: the NHWC fast path (everything the detectors launch)
     if (a.groups == 1 && a.dgroups == 1 && a.in_sc == 1 && a.out_sc == 1 && a.Cg % bke == 0 && ((uintptr_t)q->in & 15) == 0 &&
+        (int64_t)a.H * a.in_sy * es < 0x7fffffffll && 64 * a.kh * a.kw * 48 + 2 * (64 + 256) * 128 <= 160 * 1024 &&
         a.in_sx % (16 / es) == 0 && a.in_sy % (16 / es) == 0 && a.in_sb % (16 / es) == 0 && !getenv("VD3D_DCN_GENERIC"))
         return q->dtype == VD3D_BF16 ? dispatch_dcn_nhwc<short>(a, s) : dispatch_dcn_nhwc<float>(a, s);
     dim3 grid((a.Ho * a.Wo + 63) / 64, (q->O + 63) / 64, q->B);
