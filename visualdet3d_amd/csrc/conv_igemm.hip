@@ -724,6 +724,16 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const 
     // ---- DMA lane state ---------------------------------------------------------------------------------
     const int prow = lane >> 3;
     const int slot = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    // Swizzle key of a HALO row.  A wave reads the rows of 32 consecutive pixels (+ a tap shift); with TW = 16 those are two
+    // runs of 16 rows 18 apart, and the plain (row/2)%8 key lets the ds_read_b128 lane groups that straddle the two runs hit
+    // the same bank twice (PMC: SQ_LDS_BANK_CONFLICT = 1/3 of the LDS cycles of the 8x16 kernels).  Keying on the pixel
+    // index py*TW + hx instead makes the 32 keys consecutive again for every tap shift.
+    auto hkey = [&](int row) {
+        // (measured: +1.3 % on the 8x16x256 tile, +5 % on the resident kernel, but -6...-10 % on the 8x16x128 tiles: kept
+        // only where it pays)
+        if constexpr (TW == 16 && BN == 256) { const int hy = row / HW2; return ((hy * TW + row - hy * HW2) >> 1) & 7; }
+        else return (row >> 1) & 7;
+    };
     uint32_t h_off[H_PIECES];   // byte offset of this lane's halo pixel (channel 0 of the slice, logical slot), or OOB
 #pragma unroll
     for (int it = 0; it < H_PIECES; ++it) {
@@ -731,7 +741,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const 
         const int hy = hr / HW2, hx = hr - hy * HW2;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         const bool v = hr < HR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        h_off[it] = v ? (uint32_t)((int)(b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + slot * VE) * ES : kOOB;
+        const int hslot = (lane & 7) ^ hkey(hr);
+        h_off[it] = v ? (uint32_t)((int)(b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + hslot * VE) * ES : kOOB;
     }
     const uint32_t w_base = (uint32_t)(((n0 + 8 * wave + prow) * p.Kpad + slot * VE) * ES);
 
@@ -801,7 +812,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const 
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int row = hrow0[j] + shift;
-                fb[j] = *(const i32x4*)(Hb + row * 128 + ((sk ^ ((row >> 1) & 7)) << 4));
+                fb[j] = *(const i32x4*)(Hb + row * 128 + ((sk ^ hkey(row)) << 4));
             }
             if (next_halo) issue_halo(chunk + 1, ks);
             if (next_w) issue_w(step + STAGES - 1, ks);
@@ -872,7 +883,11 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
     }
     // ---- halo DMA lane state (same lane-linear image + source-side swizzle as the halo kernel) -------------------
     const int prow = lane >> 3;
-    const int slot = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    // swizzle key of a halo row = (pixel index hy*16 + hx) / 2 mod 8: the 32 rows a wave reads for any tap shift then carry
+    // consecutive keys, so every ds_read_b128 lane group covers all 16 bank slots (the plain (row/2)%8 key conflicts 2-way
+    // across the 18-row pitch: PMC showed 47 % of this kernel's LDS cycles as bank conflicts)
+    auto hkey = [](int row) { const int hy = row / kResHW2; return ((hy * kResTW + row - hy * kResHW2) >> 1) & 7; };
+    int h_slot[HP];
     int h_y[HP], h_x[HP];
     bool h_ok[HP];
     int h_piece[HP];
@@ -885,6 +900,7 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
         h_y[it] = hr / kResHW2;
         h_x[it] = hr - h_y[it] * kResHW2;
         h_ok[it] = hr < kResHR;
+        h_slot[it] = (lane & 7) ^ hkey(hr);
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -898,19 +914,19 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
         for (int it = 0; it < HP; ++it) {
             const int iy = ty * kResTH - 1 + h_y[it], ix = tx * kResTW - 1 + h_x[it];
             const bool v = tv && h_ok[it] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint32_t off = v ? (uint32_t)((int)(b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + slot * 8) * 2 : kOOB;
+            const uint32_t off = v ? (uint32_t)((int)(b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + h_slot[it] * 8) * 2 : kOOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + h_piece[it] * 1024), 16, off, 0, 0, 0);
         }
     };
     // ---- fragment addressing: pixel pp of the tile, tap (dy, dx) -> halo row; byte = row*128 + ((2ks+half) ^ sw(row))*16
-    //      = A_tap ^ (ks << 5) with A_tap = row*128 + ((half ^ sw(row)) << 4)
+    //      = A_tap ^ (ks << 5) with A_tap = row*128 + ((half ^ sw(row)) << 4), sw = hkey
     const int pp = wm * 32 + lr;
     const int hrow0 = (pp / kResTW) * kResHW2 + (pp & (kResTW - 1));
     int a_tap[9];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int row = hrow0 + (tap / 3) * kResHW2 + (tap % 3);
-        a_tap[tap] = row * 128 + ((half ^ ((row >> 1) & 7)) << 4);
+        a_tap[tap] = row * 128 + ((half ^ hkey(row)) << 4);
     }
     auto ld_frag = [&](int stage, int f) {
         return *(const i32x4*)(smem + stage * kResStageBytes + (a_tap[f >> 2] ^ ((f & 3) << 5)));
@@ -1095,6 +1111,9 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 21: return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
         case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
+        case 70: return launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream);
+        case 71: return launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream);
+        case 72: return launch_halo<T, 8, 16, 64, 2, 2, 4>(a, stream);
         default: break;
     }
     if constexpr (sizeof(T) == 2) {
