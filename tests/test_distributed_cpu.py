@@ -35,8 +35,13 @@ def _worker(rank, world, port, n_frames, q):
     assert hi - lo == n_frames // world          # equal shards in this test (all_gather needs equal shapes)
     pack, cnt = vdist.pack_detections(scores[lo:hi], boxes[lo:hi], labels[lo:hi], count[lo:hi], k=16)
     allp, allc = vdist.gather_detections(pack, cnt)
+    # the single-collective, allocation-free variant bench.py uses every step (twice: the buffers are reused)
+    g1 = vdist.DetectionGather(hi - lo, 16, 'cpu')
+    for _ in range(2):
+        g1(scores[lo:hi], boxes[lo:hi], labels[lo:hi], count[lo:hi])
+    p1, c1 = g1.detections()
     if rank == 0:
-        q.put((allp, allc))
+        q.put((allp, allc, p1.clone(), c1.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,13 +54,14 @@ def test_shard_and_gather_world2_matches_single_process():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
     for p in procs:
         p.start()
-    allp, allc = q.get(timeout=120)
+    allp, allc, p1, c1 = q.get(timeout=120)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     scores, boxes, labels, count = _fake_padded(n)
     want_p, want_c = vdist.pack_detections(scores, boxes, labels, count, k=16)
     assert torch.equal(allp, want_p) and torch.equal(allc, want_c)
+    assert torch.equal(p1, want_p) and torch.equal(c1, want_c)
     dets = vdist.unpack_detections(allp, allc)
     assert len(dets) == n and all(d[0].numel() == int(c) for d, c in zip(dets, count))
     assert dets[2][2].dtype == torch.int64

@@ -36,3 +36,37 @@ def unpack_detections(pack, count):
     for b, n in enumerate(count.tolist()):
         out.append((pack[b, :n, 0], pack[b, :n, 1:12], pack[b, :n, 12].long()))
     return out
+
+
+class DetectionGather:
+    """Per-step gather with ONE collective and no allocation: the per-rank pack is [B, k + 1, 13] floats, row k of every frame
+    carrying the frame's detection count, all_gather'ed into a preallocated [world, B, k + 1, 13] buffer
+    (``all_gather_into_tensor``; falls back to ``all_gather`` on backends without it, e.g. gloo on CPU)."""
+
+    def __init__(self, B, k, device, world=None, group=None):
+        self.group = group
+        self.world = world or dist.get_world_size(group)
+        self.B, self.k = B, k
+        self.pack = torch.zeros((B, k + 1, 13), dtype=torch.float32, device=device)
+        self.out = torch.zeros((self.world, B, k + 1, 13), dtype=torch.float32, device=device)
+
+    def __call__(self, scores, boxes, labels, count):
+        k, p = self.k, self.pack
+        kk = min(k, scores.shape[1])
+        p[:, :kk, 0] = scores[:, :kk]
+        p[:, :kk, 1:12] = boxes[:, :kk]
+        p[:, :kk, 12] = labels[:, :kk].to(torch.float32)
+        p[:, k, 0] = count.to(torch.float32)                 # negative (overflow marker) survives the round trip
+        try:
+            dist.all_gather_into_tensor(self.out.view(-1), p.view(-1), group=self.group)
+        except (RuntimeError, NotImplementedError):
+            dist.all_gather(list(self.out.unbind(0)), p, group=self.group)
+        return self.out
+
+    def counts(self):
+        """[world, B] int32 detection counts (clamped to k) of the last gather."""
+        return torch.clamp(self.out[:, :, self.k, 0].round().to(torch.int32), max=self.k)
+
+    def detections(self):
+        """-> ([world*B, k, 13], [world*B] counts) in rank order, like ``gather_detections``."""
+        return self.out[:, :, :self.k].reshape(self.world * self.B, self.k, 13), self.counts().reshape(-1)
