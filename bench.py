@@ -146,6 +146,8 @@ def main():
 
     if os.environ.get('VD3D_BENCH_NONECK'):
         model.core.overlap_neck = False
+    if os.environ.get('VD3D_BENCH_NOTOWER'):
+        model.bbox_head.overlap_towers = False
     graph = None
     static_out = None
     with torch.no_grad():

@@ -14,6 +14,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('head 1408->1408', 8, 24, 80, 1408, 1408),
     ('head 1408->576', 8, 24, 80, 1408, 576),
     ('head 1408->256', 8, 24, 80, 1408, 256),
+    ('cls 256->144', 8, 24, 80, 256, 144),
+    ('cls 256->256', 8, 24, 80, 256, 256),
 ]
 cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
 
