@@ -129,12 +129,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = world > 1 or bool(os.environ.get('VD3D_BENCH_FORCE_DIST'))   # the env: exercise the RCCL path on one GPU
+    assert torch.cuda.is_available(), 'bench.py measures the MI355X HIP path; no GPU visible'
+    torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
+    device = torch.device('cuda', local_rank)
     if dist:
         import torch.distributed as td
         td.init_process_group(backend='nccl', init_method='env://')
-    assert torch.cuda.is_available(), 'bench.py measures the MI355X HIP path; no GPU visible'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
 
     from visualdet3d_amd.utils import synthetic as syn
     model, cfg, sd = build_model(args, device)
@@ -229,7 +229,7 @@ def main():
             'config': {'workload': 'Stereo3D_example (YOLOStereo3D, ResNet-34) %dx%d stereo pairs, batch=%d per GPU'
                                    % (args.height, args.width, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv_igemm_kernel (all %d launches per step)' % nl,
+            'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 (all %d launches per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                          'traffic': traffic, 'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
                          'algorithmic_bytes': alg_bytes,
