@@ -948,11 +948,12 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
 #pragma unroll
     for (int f = 0; f < 4; ++f) ring[f] = ld_frag(0, f);
 
-    // Per tile k a wave issues, in order: [R(k): 4 residual loads] D(k+4): HP DMA pieces, S(k): 2 stores.  At tile k's barrier
-    // "at most 2*HP outstanding" leaves only S(k-1), D(k+3) (and one older op) in flight: D(k+2) and everything older -- in
-    // particular this barrier's D(k+1) -- has landed, and each halo gets two tile times to arrive.  Also right for k = 0
-    // (prologue D(0..3): D(0), D(1) landed).  gfx9 vmcnt retires loads and stores in issue order.
-    constexpr int kYounger = 2 * HP;
+    // Per tile k a wave issues, in order: [R(k): 4 residual loads, at the top] D(k+4): HP DMA pieces (after the barrier),
+    // S(k): 2 stores.  At tile k's barrier "at most 2*HP outstanding" leaves only R(k) / S(k-1) (and, without a residual,
+    // D(k+3)) in flight: D(k+2) and everything older -- in particular this barrier's D(k+1) -- has landed, and each halo gets
+    // at least one full tile time to arrive.  Also right for k = 0 (prologue D(0..3): D(0), D(1) landed).  gfx9 vmcnt
+    // retires loads and stores in issue order.
+    constexpr int kYounger = 2 * HP + (RES ? 4 : 0);     // RES: the 4 residual loads of this tile are younger too
     int stage = 0;
     for (; t < ntiles; t += nwg) {
         f32x16 acc;
@@ -964,6 +965,10 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
         const int64_t m = ((int64_t)b * p.H + y) * p.W + x;
         const int nb0 = wn * 32 + 4 * half;
         i32x2 rr[4];
+        if constexpr (RES) {   // issued a whole tile ahead of their use in the epilogue (HBM latency hidden by the 36 MFMAs)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rr[g] = *(const i32x2*)(p.residual + (m * p.res_pix_stride + nb0 + 8 * g) * 2);
+        }
         const int nstage = stage + 1 == kResStages ? 0 : stage + 1;
 #pragma unroll
         for (int f = 0; f < 36; ++f) {
@@ -972,10 +977,6 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
                 asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kYounger) : "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if constexpr (RES) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) rr[g] = *(const i32x2*)(p.residual + (m * p.res_pix_stride + nb0 + 8 * g) * 2);
-                }
                 issue_halo(t + kResStages * nwg, stage);                 // tile k+4 into the stage just released
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[f]), __builtin_bit_cast(bf16x8, ring[f & 3]), acc, 0, 0, 0);
