@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
 // logical slot (L%8) ^ ((row/2)%8) of its row -- the same 128 contiguous bytes per row, permuted among 8 lanes, so
 // global coalescing is unchanged and the fragment reads keep the conflict-free swizzled addressing.
 // Zero padding still comes from the SRD bounds check (out-of-range lanes write zeros into LDS).
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int ES = (int)sizeof(T);
@@ -489,6 +489,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
         for (int pi = 0; pi < NPIECE; ++pi) {
             if ((pi & 3) != g) continue;
+            if (ABL == 6 && pi < A_PIECES) continue;      // timing ablations: 6 = no pixel DMA, 7 = no weight DMA
+            if (ABL == 7 && pi >= A_PIECES) continue;
             if (pi < A_PIECES) {
                 const int it = pi;
                 const bool v = kvalid && (unsigned)(a_iy[it] + ddy) < (unsigned)p.H && (unsigned)(a_ix[it] + ddx) < (unsigned)p.W;
@@ -620,31 +622,33 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     // Every read of this stage has been issued (lgkmcnt(0): and has completed), and slice t+1 must have
                     // landed for everybody: after the barrier the stage is free for slice t+2 and the ring starts
                     // refilling from slice t+1.
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
+                    // ABL != 0: timing ablations for tools/bench_conv.py (WRONG results): 1 = no barrier, 2 = no DMA wait, 3 = neither
+                    if constexpr (ABL == 0 || ABL == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if constexpr (ABL == 0 || ABL == 2) __builtin_amdgcn_s_barrier();   // 4: MFMA only, 5: MFMA + ds_read
                     asm volatile("" ::: "memory");
                     // DMA of slice t+2: half of it here, the rest at the top of the next slice -- everything is in flight
                     // within the first tenth of a slice, i.e. has ~0.9 slice times to land before its barrier (PMC: with
                     // the pieces spread evenly over the slice a third of the wave cycles were spent parked at that barrier)
-                    issue_group(st, 0, more2);
-                    issue_group(st, 1, more2);
+                    if constexpr (ABL < 4) { issue_group(st, 0, more2); issue_group(st, 1, more2); }
                 }
                 if ((i == 0 && ks < NSUB - 1) || f == F0) {
                     // pixel fragments of the next sub-step (past the last slice they read a dead stage; never consumed)
                     const int k2 = f == F0 ? NSUB - 1 : ks;
 #pragma unroll
-                    for (int j = 0; j < TM; ++j) fb[(k2 & 1) ^ 1][j] = ld_a(k2 < NSUB - 1 ? st : st ^ 1, (k2 + 1) % NSUB, j);
+                    for (int j = 0; j < TM; ++j)
+                        if constexpr (ABL != 4) fb[(k2 & 1) ^ 1][j] = ld_a(k2 < NSUB - 1 ? st : st ^ 1, (k2 + 1) % NSUB, j);
+                        else fb[(k2 & 1) ^ 1][j] = fb[k2 & 1][j];
                     __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
                 }
                 if (i == 0 && ks == 0) {
-                    issue_group(st ^ 1, 2, more1);
-                    issue_group(st ^ 1, 3, more1);
+                    if constexpr (ABL < 4) { issue_group(st ^ 1, 2, more1); issue_group(st ^ 1, 3, more1); }
                     advance_k();
                 }
 #pragma unroll
                 for (int j = 0; j < TM; ++j) MmaShape<T, MS>::run(fa[f % R], fb[ks & 1][j], acc[i][j]);
                 const int nf = f + R, nks = nf / TN, ni = nf - nks * TN;
-                fa[f % R] = ld_w(nks < NSUB ? st : st ^ 1, nks % NSUB, ni);
+                if constexpr (ABL != 4) fa[f % R] = ld_w(nks < NSUB ? st : st ^ 1, nks % NSUB, ni);
                 // pin the schedule (otherwise the scheduler sinks every ds_read to its use): MFMAs of this fragment, its
                 // ring refill, then this fragment's share of the DMA pieces issued in the sub-step (spread evenly)
                 __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
@@ -1066,7 +1070,7 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_halo");
 }
 
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
@@ -1074,7 +1078,7 @@ int launch(ConvArgs& a, hipStream_t stream) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static bool attr_done = false;
     void (*kern)(const ConvArgs);
-    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING>;
+    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -1113,6 +1117,13 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
         case 70: return launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream);
+        case 91: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 1>(a, stream); else break;
+        case 92: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 2>(a, stream); else break;
+        case 93: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 3>(a, stream); else break;
+        case 94: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 4>(a, stream); else break;
+        case 95: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 5>(a, stream); else break;
+        case 96: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 6>(a, stream); else break;
+        case 97: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 7>(a, stream); else break;
         case 73: if constexpr (sizeof(T) == 2) return launch<T, 128, 144, 4, 1, true, true, 16>(a, stream); else break;
         case 74: if constexpr (sizeof(T) == 2) return launch<T, 64, 144, 2, 1, true, true, 16>(a, stream); else break;
         case 75: if constexpr (sizeof(T) == 2) return launch<T, 128, 288, 2, 2, true, true, 16>(a, stream); else break;
