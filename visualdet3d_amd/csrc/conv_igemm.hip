@@ -1117,6 +1117,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
         case 70: return launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream);
+        case 77: return launch_halo<T, 8, 16, 256, 2, 2, 3>(a, stream);
+        case 78: return launch_halo<T, 8, 16, 256, 1, 4, 3>(a, stream);
         case 91: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 1>(a, stream); else break;
         case 92: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 2>(a, stream); else break;
         case 93: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 3>(a, stream); else break;
