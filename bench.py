@@ -165,40 +165,73 @@ def main():
             with torch.cuda.graph(graph):
                 static_out = model.forward_device(*inputs)
 
-    gatherer = None
+    # N > 1: the only collective is the gather of the padded detections (+ counts) -- ONE RCCL all_gather per step, ~55 KB
+    # per rank, latency bound.  It runs on its own stream, double buffered, and the host reads the counts of step k while
+    # step k+1 is already enqueued, so the collective's latency overlaps the next forward instead of extending the step.
+    # Every step's results are gathered, copied to the host and checked.
+    gatherers, comm_stream, packed_ev, done_ev, pinned = None, None, None, None, None
     if dist:
         import torch.distributed as td
         from visualdet3d_amd.distributed import DetectionGather
-        gatherer = DetectionGather(B, min(static_out[0].shape[1] if static_out is not None else 128, 128), device, world)
+        kdet = min(static_out[0].shape[1] if static_out is not None else 128, 128)
+        gatherers = [DetectionGather(B, kdet, device, world) for _ in range(2)]
+        comm_stream = torch.cuda.Stream()
+        packed_ev = [torch.cuda.Event() for _ in range(2)]
+        done_ev = [torch.cuda.Event() for _ in range(2)]
+        pinned = [torch.empty((world, B), dtype=torch.float32).pin_memory() for _ in range(2)]
 
-    def step():
+    def forward_step():
         if graph is not None:
             graph.replay()
-            out = static_out
-        else:
-            with torch.no_grad():
-                out = model.forward_device(*inputs)
-        scores, boxes, labels, aidx, count = out
-        if dist:
-            # the trivial batch gather: fixed-size padded detections + counts in ONE RCCL all_gather over xGMI
-            # (latency bound, ~55 KB per rank), preallocated buffers
-            gatherer(scores, boxes, labels, count)
-            count = gatherer.out[:, :, gatherer.k, 0]
-        return count.cpu()                       # the one host sync: detection counts
+            return static_out
+        with torch.no_grad():
+            return model.forward_device(*inputs)
+
+    def run(n):
+        """n steps; returns the (host) detection counts of the last one."""
+        counts = None
+        if not dist:
+            for _ in range(n):
+                counts = forward_step()[-1].cpu()            # the one host sync per step: detection counts
+                assert int(counts.min()) >= 0, 'candidate overflow in the head post-processing'
+            return counts
+        main = torch.cuda.current_stream()
+
+        def collect(i):
+            done_ev[i & 1].synchronize()
+            c = pinned[i & 1]
+            assert float(c.min()) >= 0, 'candidate overflow in the head post-processing'
+            return c.clone()
+
+        for i in range(n):
+            g = gatherers[i & 1]
+            if i >= 2:
+                main.wait_event(done_ev[i & 1])              # the send buffer of step i-2 has been consumed
+            scores, boxes, labels, aidx, count = forward_step()
+            g.fill(scores, boxes, labels, count)
+            packed_ev[i & 1].record(main)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(packed_ev[i & 1])
+                out = g.gather()
+                pinned[i & 1].copy_(out[:, :, g.k, 0], non_blocking=True)
+                done_ev[i & 1].record(comm_stream)
+            if i >= 1:
+                counts = collect(i - 1)
+        if n >= 1:
+            counts = collect(n - 1)
+        return counts
 
     dbg = bool(os.environ.get('VD3D_BENCH_DEBUG'))
     if dbg:
         print('[bench] captured=%s, entering warmup' % (graph is not None), file=sys.stderr, flush=True)
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     if dbg:
         print('[bench] warmup done', file=sys.stderr, flush=True)
     if dist:
         td.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts = step()
+    counts = run(args.steps)
     torch.cuda.synchronize()
     if dist:
         td.barrier()
@@ -209,7 +242,7 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert int(counts.min()) >= 0, 'candidate overflow in the head post-processing'
+    assert counts is not None and float(counts.min()) >= 0, 'candidate overflow in the head post-processing'
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -50,18 +50,27 @@ class DetectionGather:
         self.pack = torch.zeros((B, k + 1, 13), dtype=torch.float32, device=device)
         self.out = torch.zeros((self.world, B, k + 1, 13), dtype=torch.float32, device=device)
 
-    def __call__(self, scores, boxes, labels, count):
+    def fill(self, scores, boxes, labels, count):
+        """Copy one step's padded results into the send buffer (stream-ordered; no collective)."""
         k, p = self.k, self.pack
         kk = min(k, scores.shape[1])
         p[:, :kk, 0] = scores[:, :kk]
         p[:, :kk, 1:12] = boxes[:, :kk]
         p[:, :kk, 12] = labels[:, :kk].to(torch.float32)
         p[:, k, 0] = count.to(torch.float32)                 # negative (overflow marker) survives the round trip
+
+    def gather(self):
+        """The collective on the current stream; returns the [world, B, k + 1, 13] buffer."""
+        p = self.pack
         try:
             dist.all_gather_into_tensor(self.out.view(-1), p.view(-1), group=self.group)
         except (RuntimeError, NotImplementedError):
             dist.all_gather(list(self.out.unbind(0)), p, group=self.group)
         return self.out
+
+    def __call__(self, scores, boxes, labels, count):
+        self.fill(scores, boxes, labels, count)
+        return self.gather()
 
     def counts(self):
         """[world, B] int32 detection counts (clamped to k) of the last gather."""
