@@ -7,6 +7,9 @@ from visualdet3d_amd import hip_ops as ops, _lib
 
 SHAPES = [  # name, B, H, W, Cin, Cout
     ("layer1 64->64", 16, 96, 320, 64, 64),
+    ('ghost 24->24', 8, 96, 320, 24, 24),
+    ('km3d off 64->27', 16, 128, 440, 64, 27),
+    ('down 64->128 s2', 16, 96, 320, 64, 128),
     ('layer2 128->128', 16, 48, 160, 128, 128),
     ('layer3 256->256', 16, 24, 80, 256, 256),
     ('probe3 256->256 w96', 14, 24, 96, 256, 256),
@@ -21,7 +24,7 @@ cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
 
 
 def skip(c, Cout):
-    return (Cout <= 64 and 1 <= c < 30) or (Cout <= 64 and c >= 36 and c != 60) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 40)
+    return (Cout <= 64 and 1 <= c < 30) or (Cout <= 64 and c >= 36 and c not in (60, 84, 85, 86, 87)) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 40)
 
 import os
 if os.environ.get('VD3D_SHAPES'):

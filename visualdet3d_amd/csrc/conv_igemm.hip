@@ -1118,6 +1118,10 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
         case 70: return launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream);
         case 77: return launch_halo<T, 8, 16, 256, 2, 2, 3>(a, stream);
+        case 84: return launch<T, 256, 32, 4, 1, true, true>(a, stream);
+        case 85: return launch<T, 128, 64, 4, 1, true, true, 32, 2>(a, stream);
+        case 86: return launch<T, 128, 64, 2, 2, true, true>(a, stream);
+        case 87: return launch<T, 256, 32, 8, 1, true, true, 32, 1>(a, stream);
         case 78: return launch_halo<T, 8, 16, 256, 1, 4, 3>(a, stream);
         case 91: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 1>(a, stream); else break;
         case 92: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 2>(a, stream); else break;
@@ -1139,7 +1143,9 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
             a.H % kResTH == 0 && a.W % kResTW == 0 && a.wide_store && !a.out_f32)
             return launch_resident64(a, stream);
     }
-    if (a.Cout <= 32) return launch<T, 256, 32, 4, 1, true>(a, stream);
+    // Cout <= 32: 8 waves of 32 pixels x 32 channels, pipelined loop (+8 % on the ghost 24 -> 24 conv, +27 % on KM3D's 64 -> 27
+    // offset convs over the 4-wave barrier-per-slice version)
+    if (a.Cout <= 32) return launch<T, 256, 32, 8, 1, true, true, 32, 1>(a, stream);
     if (a.Cout <= 64) return launch<T, 128, 64, 4, 1, true>(a, stream);   // 48 KiB LDS -> 3 workgroups / CU (short K: latency bound)
     // 3x3 / stride 1 / pad 1 with 64-channel-aligned input: the halo kernel (each input pixel staged once per channel
     // chunk instead of once per tap) wins on the mid-size layers (measured on MI355X, bf16):
