@@ -9,6 +9,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ("layer1 64->64", 16, 96, 320, 64, 64),
     ('ghost 24->24', 8, 96, 320, 24, 24),
     ('km3d off 64->27', 16, 128, 440, 64, 27),
+    ('dla 128->64', 16, 64, 220, 128, 64),
+    ('stereo 72->72', 8, 48, 160, 72, 72),
     ('down 64->128 s2', 16, 96, 320, 64, 128),
     ('layer2 128->128', 16, 48, 160, 128, 128),
     ('layer3 256->256', 16, 24, 80, 256, 256),
