@@ -18,6 +18,7 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('neck 1152->1152', 8, 24, 80, 1152, 1152),
     ('head 1408->1408', 8, 24, 80, 1408, 1408),
     ('head 1408->576', 8, 24, 80, 1408, 576),
+    ('r50head 2176->2176', 16, 18, 80, 2176, 2176),
     ('head 1408->256', 8, 24, 80, 1408, 256),
     ('cls 256->144', 8, 24, 80, 256, 144),
     ('cls 256->256', 8, 24, 80, 256, 256),

@@ -1118,6 +1118,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
         case 70: return launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream);
         case 77: return launch_halo<T, 8, 16, 256, 2, 2, 3>(a, stream);
+        case 79: if constexpr (sizeof(T) == 2) return launch<T, 256, 272, 8, 1, true, true, 16>(a, stream); else break;
         case 84: return launch<T, 256, 32, 4, 1, true, true>(a, stream);
         case 85: return launch<T, 128, 64, 4, 1, true, true, 32, 2>(a, stream);
         case 86: return launch<T, 128, 64, 2, 2, true, true>(a, stream);
@@ -1179,6 +1180,10 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         const double r2 = 900.0 * util(128, 352, 256);
         if (r2 > best) { best = r2; pick = 4; }
     }
+    if (sizeof(T) == 2 && a.Cout % 272 == 0) {   // 2176 = 8 x 272 (Stereo3D R50 head): 8 waves of 32 x 272 on 16x16x32 MFMAs, +20 %
+        const double r = 1320.0 * util(256, 272, 256);
+        if (r > best) { best = r; pick = 7; }
+    }
     if (a.Cout % 192 == 0) {     // 80 KiB LDS: two workgroups per CU
         const double r = 1390.0 * util(128, 192, 512);
         if (r > best) { best = r; pick = 6; }
@@ -1209,6 +1214,9 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
             if constexpr (sizeof(T) == 2) return launch<T, 128, 288, 4, 2, true, true, 16>(a, stream);
             else return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 6: return launch<T, 128, 192, 2, 2, true, true>(a, stream);
+        case 7:
+            if constexpr (sizeof(T) == 2) return launch<T, 256, 272, 8, 1, true, true, 16>(a, stream);
+            else return launch<T, 256, 256, 2, 4, true, true>(a, stream);
         default: return launch<T, 128, 128, 2, 2, true, true>(a, stream);
     }
 }
