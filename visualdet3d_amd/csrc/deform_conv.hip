@@ -236,7 +236,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     const int HoWo = p.Ho * p.Wo;
     const int pix0 = blockIdx.x * 64;
     const int KK = p.kh * p.kw;
-    const int srow = tid & 63, v0 = tid >> 6;        // this thread samples pixel srow, 16-byte vectors v0 and v0 + 4
+    // Sampling map: 8 consecutive lanes fetch the 8 16-byte vectors of ONE pixel's 128-byte channel run, so a corner load of a
+    // wave touches 8 cache lines (one per pixel) instead of 64; a thread handles pixels prow0 and prow0 + 32, vector vslot.
+    const int prow0 = tid >> 3, vslot = tid & 7;
+    const int srow = tid & 63;                       // (pixel of this lane for the phase-0 / bounds bookkeeping below)
     const int mypix = pix0 + srow;
     const bool pvalid = mypix < HoWo;
     const int ho = pvalid ? mypix / p.Wo : 0, wo = pvalid ? mypix - (mypix / p.Wo) * p.Wo : 0;
@@ -292,9 +295,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     __syncthreads();
 
     struct Geo { int32_t o[4]; float w[4]; float m; };
-    auto geometry = [&](int tap) {
+    auto geometry = [&](int tap, int prow) {
         Geo g;
-        const char* e = geo_tab + (size_t)(tap * 64 + srow) * 48;
+        const char* e = geo_tab + (size_t)(tap * 64 + prow) * 48;
         const i32x4 go = *(const i32x4*)e;
         const f32x4 gw = *(const f32x4*)(e + 16);
 #pragma unroll
@@ -304,18 +307,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     };
     // global -> registers for slice kt (sampled column vectors + this thread's share of the weight tile)
     constexpr int WV = BN * 8 / 256;                 // 16-byte weight vectors per thread per slice
-    Geo geo = geometry(0);
+    Geo geo[2] = {geometry(0, prow0), geometry(0, prow0 + 32)};
     int geo_tap = 0;
     auto fetch = [&](int kt, i32x4 (&cv)[2][4], i32x4 (&wv)[WV]) {
         const int tap = kt / chunks, c0 = (kt - tap * chunks) * BKE;
-        if (tap != geo_tap) { geo = geometry(tap); geo_tap = tap; }
+        if (tap != geo_tap) { geo[0] = geometry(tap, prow0); geo[1] = geometry(tap, prow0 + 32); geo_tap = tap; }
+        const int coff = (c0 + vslot * VE) * ES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int coff = (c0 + (v0 + 4 * i) * VE) * ES;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 cv[i][c] = i32x4{0, 0, 0, 0};
-                if (geo.w[c] != 0.f) cv[i][c] = *(const i32x4*)(in_b + geo.o[c] + coff);
+                if (geo[i].w[c] != 0.f) cv[i][c] = *(const i32x4*)(in_b + geo[i].o[c] + coff);
             }
         }
 #pragma unroll
@@ -339,11 +342,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
                 float val;
                 if constexpr (sizeof(T) == 2) {
                     // bf16 mode: the result is rounded to bf16 anyway -- fused multiply-adds (4 ops instead of 7)
-                    val = fmaf(geo.w[3], c4.get(e), fmaf(geo.w[2], c3.get(e), fmaf(geo.w[1], c2.get(e), geo.w[0] * c1.get(e))));
+                    val = fmaf(geo[i].w[3], c4.get(e), fmaf(geo[i].w[2], c3.get(e), fmaf(geo[i].w[1], c2.get(e), geo[i].w[0] * c1.get(e))));
                 } else {
-                    val = geo.w[0] * c1.get(e) + geo.w[1] * c2.get(e) + geo.w[2] * c3.get(e) + geo.w[3] * c4.get(e);
+                    val = geo[i].w[0] * c1.get(e) + geo[i].w[1] * c2.get(e) + geo[i].w[2] * c3.get(e) + geo[i].w[3] * c4.get(e);
                 }
-                vals[e] = val * geo.m;
+                vals[e] = val * geo[i].m;
             }
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -352,8 +355,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.set(e, vals[e]);
             }
-            const int vec = v0 + 4 * i;
-            *(i32x4*)(Cs + srow * 128 + ((vec ^ ((srow >> 1) & 7)) << 4)) = o.raw;
+            const int row = prow0 + 32 * i;
+            *(i32x4*)(Cs + row * 128 + ((vslot ^ ((row >> 1) & 7)) << 4)) = o.raw;
         }
 #pragma unroll
         for (int i = 0; i < WV; ++i) {
