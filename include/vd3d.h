@@ -264,6 +264,16 @@ int vd3d_kitti_postpath(const float* boxes, const int32_t* counts, const float* 
                         int B, int cap, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * KM3D head, fused (heads/km3d_head.py:132-153,353-357: nine branches conv3x3(64 -> 256) + ReLU + conv1x1(256 -> n_h)).  The nine
+ * 3x3 convs run as ONE implicit GEMM with Cout = 256 x heads (`p`: the vd3d_conv2d_igemm parameters of that conv, bf16,
+ * shift = the concatenated first-conv biases, relu implied, `p->out` ignored); each 256-pixel x 256-channel tile applies bias +
+ * ReLU, rounds to bf16 and multiplies by its head's 1x1 weights in the epilogue, so the 9 x 256-channel intermediate never
+ * reaches HBM.  w2_packed: [heads][32][256] bf16 (rows >= n_out[h] zero), b2: [heads][32] fp32, outs[h]: fp32 [B*H*W][n_out[h]]
+ * (host array of device pointers), n_out[h] <= 32, heads <= 9. */
+int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_packed, const float* b2, void* const* outs,
+                         const int32_t* n_out, int n_heads, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * KM3D / RTM3D keypoint-head decoding (heads/km3d_head.py:155-314 _decode + get_bboxes; networks/utils/rtm3d_utils.py
  * _nms :122-127, _topk :201-216, _topk_channel :219-228, gen_position :314-455; torchvision nms) for a whole batch.
  * All maps are fp32 NHWC logits / regressions [B][H][W][n] (n: hm n_cls, wh 2, hps 18, rot 8, dim 3, prob 1, reg 2,

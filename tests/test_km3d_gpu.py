@@ -99,3 +99,26 @@ def test_bf16_mode_close_to_bf16_oracle():
     for h in ('hm', 'hps', 'dim', 'rot'):
         # 16 stacked DCNv2 layers: a 1-ulp bf16 flip upstream moves sampling positions downstream -> looser than the ResNet paths
         assert rel_err(maps[h].permute(0, 3, 1, 2).cpu(), st[h]) < 0.15, h
+
+
+def test_fused_head_matches_unfused():
+    """vd3d_km3d_head_fused (3x3 convs + ReLU + 1x1 convs in one launch, bf16) against the two-stage path: same bf16 rounding
+    point for the intermediate, fp32 accumulation in both."""
+    import torch
+    from visualdet3d_amd.networks.heads.km3d_head import KM3DHead
+    from visualdet3d_amd.utils import synthetic as syn
+    cfg = syn.km3d_cfg(output_w=80)
+    head = KM3DHead(**cfg.head).cuda().eval()
+    sd = syn.seeded_state_dict({'h.' + k: v for k, v in head.state_dict().items()}, seed=9, head_std=0.02)
+    head.load_state_dict({k[2:]: v for k, v in sd.items()})
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3, 24, 80, 64, generator=g).cuda().to(torch.bfloat16)        # 3 x 1920 px: ragged last 256-pixel tile
+    with torch.no_grad():
+        head.fuse_head = True
+        fused_maps = head.forward_nhwc(x)
+        head.fuse_head = False
+        ref_maps = head.forward_nhwc(x)
+    for k in ref_maps:
+        a, b = fused_maps[k].float(), ref_maps[k].float()
+        assert a.shape == b.shape
+        assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 2e-3, k

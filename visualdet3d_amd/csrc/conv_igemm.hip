@@ -43,6 +43,12 @@ struct ConvArgs {
     int Kpad, relu, out_f32;
     int M, tiles_m, tiles_n, ntaps, nk;
     int vec_epilogue, wide_store, chunk_major;
+    // fused KM3D head (vd3d_km3d_head_fused): per 256-channel N tile h, a second GEMM [256 px x 256] x [256 x n_h] in the
+    // epilogue; h_w2 = packed [heads][32][256] bf16, h_b2 = [heads][32] fp32, h_out[h] = fp32 [M][h_n[h]]
+    const char* h_w2 = nullptr;
+    const float* h_b2 = nullptr;
+    float* h_out[9] = {};
+    int h_n[9] = {};
 };
 
 constexpr uint32_t kOOB = 0x80000000u;  // byte offset guaranteed >= num_records (host enforces in_bytes < 2^31)
@@ -408,7 +414,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
 // logical slot (L%8) ^ ((row/2)%8) of its row -- the same 128 contiguous bytes per row, permuted among 8 lanes, so
 // global coalescing is unchanged and the fragment reads keep the conflict-free swizzled addressing.
 // Zero padding still comes from the SRD bounds check (out-of-range lanes write zeros into LDS).
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int ES = (int)sizeof(T);
@@ -673,6 +679,59 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + wm * WTM + j * MS + lr;
         mrow[j] = m < p.M ? m : -1;
+    }
+    if constexpr (HEADF) {
+        // ---- fused KM3D head: this N tile is head h = tile_n.  bias + ReLU, round to bf16 (the rounding point of the unfused
+        // path's `mid` tensor), park the 256 x 256 tile in LDS, then out_h = tile x W2_h + b2_h on the matrix cores.  The
+        // 9 x 256-channel intermediate (4 GB at 16 x 128 x 440) never exists in HBM.
+        static_assert(BM == 256 && BN == 256 && MS == 32 && sizeof(T) == 2, "fused head: 256 x 256 bf16 tiles");
+        __syncthreads();                                   // every wave is done with the operand stages
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int r = wm * WTM + j * 32 + lr;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c = wn * WTN + i * 32 + 8 * g + 4 * half;       // channel inside the head
+                    const f32x4 sh = *(const f32x4*)(p.shift + n0 + c);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * g + e] + sh[e], 0.f);
+                    i32x2 o;
+                    o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
+                    o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                    const int slot16 = c >> 3;
+                    *(i32x2*)(smem + r * 512 + ((slot16 ^ (r & 15)) << 4) + half * 8) = o;
+                }
+        }
+        __syncthreads();
+        const int h = tile_n;
+        const int r2 = wave * 32 + lr;                      // wave w owns pixel rows 32w .. 32w+31 for the second GEMM
+        f32x16 acc2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+        const char* w2row = p.h_w2 + ((size_t)(h * 32 + lr) * 256) * 2;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const int slot16 = 2 * ks + half;
+            const i32x4 fa2 = *(const i32x4*)(w2row + slot16 * 16);
+            const i32x4 fb2 = *(const i32x4*)(smem + r2 * 512 + ((slot16 ^ (r2 & 15)) << 4));
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa2), __builtin_bit_cast(bf16x8, fb2), acc2, 0, 0, 0);
+        }
+        const int m2 = m0 + r2;
+        const int nh = p.h_n[h];
+        if (m2 < p.M) {
+            float* dst = p.h_out[h] + (int64_t)m2 * nh;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = 8 * g + 4 * half + e;
+                    if (n < nh) dst[n] = acc2[4 * g + e] + p.h_b2[h * 32 + n];
+                }
+        }
+        return;
     }
     if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
     else conv_epilogue16<TM, TN, WTN>(p, acc, mrow, n0, wn, half);
@@ -1070,7 +1129,7 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_halo");
 }
 
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int LDS = 2 * (BM + BN) * 128;
@@ -1078,7 +1137,7 @@ int launch(ConvArgs& a, hipStream_t stream) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static bool attr_done = false;
     void (*kern)(const ConvArgs);
-    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL>;
+    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL, HEADF>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
@@ -1228,7 +1287,7 @@ extern "C" int vd3d_conv2d_set_tuning(int cfg) {
     return VD3D_OK;
 }
 
-extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
+static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     if (!p || !p->in || !p->weight || !p->out) { vd3d_set_error("conv2d_igemm: null pointer"); return VD3D_EINVAL; }
     const int es = p->dtype == VD3D_BF16 ? 2 : (p->dtype == VD3D_F32 ? 4 : 0);
     if (!es) { vd3d_set_error("conv2d_igemm: bad dtype"); return VD3D_EINVAL; }
@@ -1250,7 +1309,6 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
         vd3d_set_error("conv2d_igemm: tensor exceeds 2 GiB (32-bit buffer offsets); split the batch");
         return VD3D_ERANGE;
     }
-    ConvArgs a;
     a.in = (const char*)p->in; a.weight = (const char*)p->weight; a.scale = p->scale; a.shift = p->shift;
     a.residual = (const char*)p->residual; a.out = (char*)p->out;
     a.B = p->B; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
@@ -1273,6 +1331,37 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
     // 16-byte bf16 stores (half-wave pairing) need 16-channel groups inside Cout and 16-byte aligned rows
     a.wide_store = a.vec_epilogue && oes == 2 && (p->Cout % 16 == 0) && (p->out_pix_stride % 8 == 0) && (((uintptr_t)p->out & 15) == 0);
     a.chunk_major = (a.ntaps > 1) && (p->Cin % bke == 0);
+    return VD3D_OK;
+}
+
+extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
+    ConvArgs a;
+    const int rc = fill_conv_args(p, a);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : dispatch<float>(a, s);
+}
+
+extern "C" int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_packed, const float* b2, void* const* outs,
+                                    const int32_t* n_out, int n_heads, void* stream) {
+    if (!p || !w2_packed || !b2 || !outs || !n_out) { vd3d_set_error("km3d_head_fused: null pointer"); return VD3D_EINVAL; }
+    if (n_heads < 1 || n_heads > 9 || p->dtype != VD3D_BF16 || p->Cout != 256 * n_heads || p->kh != 3 || p->kw != 3 || p->stride != 1 ||
+        p->pad != 1 || p->dil != 1 || p->Cin % 64 || !p->shift || p->scale || p->residual || ((uintptr_t)w2_packed & 15)) {
+        vd3d_set_error("km3d_head_fused: needs bf16, 3x3/s1/p1, Cin % 64 == 0, Cout = 256 x heads (<= 9), bias only");
+        return VD3D_EINVAL;
+    }
+    ConvArgs a;
+    vd3d_conv_params q = *p;
+    q.out = (void*)outs[0];                       // unused by the fused epilogue; keeps the generic checks happy
+    const int rc = fill_conv_args(&q, a);
+    if (rc) return rc;
+    if (!a.chunk_major) { vd3d_set_error("km3d_head_fused: channel count must be chunk aligned"); return VD3D_EINVAL; }
+    a.h_w2 = (const char*)w2_packed;
+    a.h_b2 = b2;
+    for (int h = 0; h < n_heads; ++h) {
+        if (!outs[h] || n_out[h] < 1 || n_out[h] > 32) { vd3d_set_error("km3d_head_fused: 1 <= n_out <= 32 per head"); return VD3D_EINVAL; }
+        a.h_out[h] = (float*)outs[h];
+        a.h_n[h] = n_out[h];
+    }
+    return launch<short, 256, 256, 2, 4, true, true, 32, 0, 0, true>(a, (hipStream_t)stream);
 }

@@ -637,3 +637,31 @@ def preprocess_images(frames_u8, crop_top, size, mean, std, packed=False):
         check(_lib.lib().vd3d_preprocess_image(_p(f), Hs, Ws, int(crop_top), Hr, Wr, None if packed else _p(out[b]),
                                                _p(out[b]) if packed else None, H, W, m, sd, _stream()), 'vd3d_preprocess_image')
     return out
+
+
+def km3d_head_fused(x, pc_first, w2_packed, b2, n_out):
+    """Fused KM3D head (vd3d_km3d_head_fused): x NHWC bf16 [B,H,W,Cin], pc_first = packed concatenation of the nine 3x3 convs
+    (Cout = 256 * heads, bias in shift), w2_packed [heads,32,256] bf16, b2 [heads,32] fp32 -> list of fp32 [B,H,W,n_h]."""
+    _require_cuda(x, pc_first.w, w2_packed, b2)
+    B, H, W, Cx = x.shape
+    heads = len(n_out)
+    assert x.dtype == torch.bfloat16 and pc_first.dtype == torch.bfloat16 and Cx == pc_first.Cin and pc_first.Cout == 256 * heads
+    assert w2_packed.shape == (heads, 32, 256) and w2_packed.dtype == torch.bfloat16 and w2_packed.is_contiguous()
+    assert b2.shape == (heads, 32) and b2.dtype == torch.float32 and b2.is_contiguous() and pc_first.scale is None
+    outs = [torch.empty((B, H, W, int(n)), dtype=torch.float32, device=x.device) for n in n_out]
+    ips, irs, ibs = _nhwc_strides(x)
+    p = ConvParams()
+    p.in_, p.weight, p.out = x.data_ptr(), pc_first.w.data_ptr(), outs[0].data_ptr()
+    p.scale, p.shift = None, pc_first.shift.data_ptr()
+    p.B, p.H, p.W, p.Cin = B, H, W, pc_first.Cin
+    p.in_pix_stride, p.in_row_stride, p.in_batch_stride = ips, irs, ibs
+    p.in_bytes = min(_bytes_from(x), ((B - 1) * ibs + (H - 1) * irs + (W - 1) * ips + Cx) * x.element_size())
+    p.Ho, p.Wo, p.Cout = H, W, pc_first.Cout
+    p.out_pix_stride = pc_first.Cout
+    p.kh, p.kw, p.stride, p.pad, p.dil = 3, 3, 1, 1, 1
+    p.Kpad, p.CoutPad, p.relu = pc_first.Kpad, pc_first.CoutPad, 1
+    p.dtype, p.out_f32 = dtype_code(x.dtype), 0
+    ptrs = (C.c_void_p * heads)(*[o.data_ptr() for o in outs])
+    ns = (C.c_int32 * heads)(*[int(n) for n in n_out])
+    check(_lib.lib().vd3d_km3d_head_fused(C.byref(p), _p(w2_packed), _p(b2), ptrs, ns, heads, _stream()), 'vd3d_km3d_head_fused')
+    return outs

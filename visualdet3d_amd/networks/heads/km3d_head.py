@@ -46,6 +46,7 @@ class KM3DHead(nn.Module):
         self._cache = fused.PackCache()
         self.max_peaks = 8192      # per (sample, heat-map channel) capacity of the peak list (LDS sort size)
         self._workspace = None
+        self.fuse_head = True        # bf16: the nine head branches in one launch (vd3d_km3d_head_fused)
 
     def _init_layers(self, input_features=256, head_features=64, head_dict=dict(), **kwargs):
         self.head_layers = nn.ModuleDict()
@@ -74,8 +75,24 @@ class KM3DHead(nn.Module):
 
         srcs = [t for c in firsts for t in (c.weight, c.bias)]
         pc = self._cache.get(('first', dt), srcs, build_first)
-        mid = ops.conv2d(x, pc, relu=True)                    # [B,H,W,9*F]
         F_ = firsts[0].out_channels
+        lasts = [self.head_layers[n][2] for n in names]
+        if (self.fuse_head and dt == torch.bfloat16 and F_ == 256 and len(names) <= 9 and x.shape[3] % 64 == 0
+                and all(c.out_channels <= 32 for c in lasts)):
+            # one launch: the nine 3x3 convs as a single GEMM whose epilogue applies ReLU and the head's 1x1 conv; the
+            # [B,H,W,9*256] intermediate (4 GB at 16 x 128 x 440) is never written
+            def build_second():
+                w2 = torch.zeros((len(names), 32, F_), dtype=torch.float32, device=x.device)
+                b2 = torch.zeros((len(names), 32), dtype=torch.float32, device=x.device)
+                for i, c in enumerate(lasts):
+                    w2[i, :c.out_channels] = c.weight.detach().float().reshape(c.out_channels, F_)
+                    b2[i, :c.out_channels] = c.bias.detach().float()
+                return w2.to(torch.bfloat16).contiguous(), b2.contiguous()
+
+            w2, b2 = self._cache.get(('second_fused', dt), [t for c in lasts for t in (c.weight, c.bias)], build_second)
+            outs = ops.km3d_head_fused(x, pc, w2, b2, [c.out_channels for c in lasts])
+            return dict(zip(names, outs))
+        mid = ops.conv2d(x, pc, relu=True)                    # [B,H,W,9*F]
         ret = {}
         for i, n in enumerate(names):
             conv = self.head_layers[n][2]
