@@ -97,3 +97,20 @@ def test_nms_oracle_semantics():
     assert nms_numpy(boxes, scores, 0.5).tolist() == [0, 2]          # tie -> lower index first, duplicates suppressed
     assert nms_numpy(boxes, scores, 0.99).tolist() == [0, 1, 2]      # identical box still suppressed (IoU 1 > .99)
     assert nms_numpy(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5).shape == (0,)
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under visualdet3d_amd/ may import, open or exec it (and bench.py only in its
+    cpu_baseline leg, __graft_entry__ only in smoke())."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b|[\'"]oracle[/\'"]', re.M)
+    for dp, _, fs in os.walk(os.path.join(root, 'visualdet3d_amd')):
+        for f in fs:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dp, f), errors='ignore').read()
+                assert not pat.search(src), os.path.join(dp, f)
+    bench = open(os.path.join(root, 'bench.py')).read()
+    uses = [m.start() for m in re.finditer(r'from oracle|import oracle', bench)]
+    assert uses and all(bench.rfind('def ', 0, u) == bench.find('def cpu_baseline') for u in uses)
