@@ -157,6 +157,8 @@ def test_conv_resident_weights_64():
     assert _case(3, 96, 320, 64, 64, 3, 1, 1, 1, True, True, torch.bfloat16, seed=2) < 1e-2                      # 720 tiles
     assert _case(2, 96, 320, 64, 64, 3, 1, 1, 1, False, True, torch.bfloat16, bn=False, seed=3) < 1e-2
     assert _case(2, 24, 32, 64, 64, 3, 1, 1, 1, True, True, torch.bfloat16, in_extra=64, out_extra=64, seed=4) < 1e-2
+    assert _case(2, 20, 40, 64, 64, 3, 1, 1, 1, True, True, torch.bfloat16, out_extra=64, seed=5) < 1e-2      # ragged H and W
+    assert _case(1, 5, 7, 64, 64, 3, 1, 1, 1, False, True, torch.bfloat16, seed=6) < 1e-2                       # smaller than a tile
 
 
 def test_stem_conv_pool_fused():

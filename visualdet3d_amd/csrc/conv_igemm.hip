@@ -935,7 +935,8 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves: 32 pixels x 32 channels each
     const int lr = lane & 31, half = lane >> 5;
-    const int tiles_x = p.W / kResTW, tiles_y = p.H / kResTH, tiles_img = tiles_x * tiles_y;
+    const int tiles_x = (p.W + kResTW - 1) / kResTW, tiles_y = (p.H + kResTH - 1) / kResTH, tiles_img = tiles_x * tiles_y;   // ragged
+    // edges: halo rows beyond the image are zero-filled by the bounds check, pixels beyond it are computed and dropped
 
     // ---- weights -> registers, MFMA A-operand layout: row = output channel, 16 bytes = 8 k values -----------
     i32x4 wf[36];
@@ -1025,12 +1026,13 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
         const int b = t / tiles_img, trem = t - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
         const int y = ty * kResTH + pp / kResTW, x = tx * kResTW + (pp & (kResTW - 1));
-        const int64_t m = ((int64_t)b * p.H + y) * p.W + x;
+        const bool pin = y < p.H && x < p.W;
+        const int64_t m = pin ? ((int64_t)b * p.H + y) * p.W + x : 0;
         const int nb0 = wn * 32 + 4 * half;
         i32x2 rr[4];
         if constexpr (RES) {   // issued a whole tile ahead of their use in the epilogue (HBM latency hidden by the 36 MFMAs)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) rr[g] = *(const i32x2*)(p.residual + (m * p.res_pix_stride + nb0 + 8 * g) * 2);
+            for (int g = 0; g < 4; ++g) rr[g] = *(const i32x2*)(p.residual + (m * p.res_pix_stride + nb0 + 8 * g) * 2);   // (pixel 0 if outside)
         }
         const int nstage = stage + 1 == kResStages ? 0 : stage + 1;
 #pragma unroll
@@ -1084,7 +1086,7 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
             auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
             auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
             i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
-            *(i32x4*)(p.out + (m * p.out_pix_stride + wn * 32 + 8 * (g + half)) * 2) = o;
+            if (pin) *(i32x4*)(p.out + (m * p.out_pix_stride + wn * 32 + 8 * (g + half)) * 2) = o;
         }
         stage = nstage;
     }
@@ -1101,7 +1103,7 @@ int launch_resident64(ConvArgs& a, hipStream_t stream) {
             hipFuncSetAttribute((const void*)conv_resident64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kResLds) != hipSuccess)
             return vd3d_check_launch("hipFuncSetAttribute(conv_resident64)");
     }
-    const int ntiles = a.B * (a.H / kResTH) * (a.W / kResTW);
+    const int ntiles = a.B * ((a.H + kResTH - 1) / kResTH) * ((a.W + kResTW - 1) / kResTW);
     const int grid = ntiles < num_cu ? ntiles : num_cu;
     if (a.residual) hipLaunchKernelGGL(conv_resident64_kernel<true>, dim3(grid), dim3(512), kResLds, stream, a, ntiles);
     else hipLaunchKernelGGL(conv_resident64_kernel<false>, dim3(grid), dim3(512), kResLds, stream, a, ntiles);
@@ -1200,7 +1202,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     }
     if constexpr (sizeof(T) == 2) {
         if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
-            a.H % kResTH == 0 && a.W % kResTW == 0 && a.wide_store && !a.out_f32)
+            a.wide_store && !a.out_f32)
             return launch_resident64(a, stream);
     }
     // Cout <= 32: 8 waves of 32 pixels x 32 channels, pipelined loop (+8 % on the ghost 24 -> 24 conv, +27 % on KM3D's 64 -> 27
