@@ -195,6 +195,8 @@ def test_stem_conv_pool_fused():
     (1, 8, 16, 256, 256, 3, 1, 1, 1, False, False),     # one tile
     (1, 16, 32, 1408, 256, 3, 1, 1, 1, False, True),    # long K, 8x16 px x 128 ch (cls conv)
     (1, 24, 80, 64, 128, 3, 1, 1, 1, False, True),      # single 64-channel chunk (9 steps)
+    (1, 64, 220, 128, 128, 3, 1, 1, 1, True, True),     # ragged W (220 = 6.9 x 32): KM3D level at 512 x 1760
+    (1, 30, 110, 256, 256, 3, 1, 1, 1, False, True),    # ragged H and W on the 8x16 tile
 ])
 def test_conv_halo_kernel_shapes(shape):
     assert _case(*shape, dtype=torch.bfloat16) < 1e-2

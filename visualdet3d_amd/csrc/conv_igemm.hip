@@ -1214,9 +1214,15 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     //   Cout <= 128 (layer2-like): 8x32 patch x 128 channels          +6 %
     //   Cout == 256, short K (layer3-like): 8x16 patch x 256 channels +10 %
     //   Cout == 256, long K (1408 -> 256 cls conv): 8x16 patch x 128  +60 %
+    // ragged image edges are fine (halo rows beyond the image are zero-filled, pixels beyond it are dropped) as long as the
+    // padded patch grid wastes < 8 % of the work
+    auto patch_waste_ok = [&](int th, int tw) {
+        const int64_t padded = (int64_t)((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw);
+        return padded * 100 <= (int64_t)a.H * a.W * 108;
+    };
     const bool halo_ok = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W &&
-                         a.Cin % (128 / (int)sizeof(T)) == 0 && a.H % 8 == 0 && a.W % 16 == 0;
-    if (halo_ok && a.Cout <= 128 && a.Cout % 128 == 0 && a.W % 32 == 0) return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
+                         a.Cin % (128 / (int)sizeof(T)) == 0 && patch_waste_ok(8, 16);
+    if (halo_ok && a.Cout <= 128 && a.Cout % 128 == 0 && patch_waste_ok(8, 32)) return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
     if (halo_ok && a.Cout == 256) {
         if (a.Cin >= 1024) return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
         return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
