@@ -69,9 +69,14 @@ typedef struct vd3d_conv_params {
 } vd3d_conv_params;
 
 int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream);
-/* Tuning hook for tools/bench_conv.py: force a tile configuration (0 = built-in heuristic). Not part of the
- * drop-in surface. */
+/* Test / tuning hook, not part of the drop-in surface: force a tile configuration (0 = built-in heuristic) for every
+ * following vd3d_conv2d_igemm call of the process.  The product library only accepts the ids of the tiles its heuristic can
+ * select (vd3d_conv2d_production_tiles); a forced tile that cannot run a given convolution makes that call return
+ * VD3D_EINVAL -- the library never returns numbers from a kernel that is wrong for the shape.  Experimental tiles and the
+ * timing ablations live in the separate -DVD3D_TUNING build (libvd3d_hip_tuning.so, tools/bench_conv.py). */
 int vd3d_conv2d_set_tuning(int cfg);
+/* ids of the production tiles -> ids[0..cap); returns how many there are. */
+int vd3d_conv2d_production_tiles(int32_t* ids, int cap);
 
 /* Test-time image pipeline for ONE frame, fed from uint8 (data/pipeline/stereo_augmentator.py: ConvertToFloat :30-36,
  * CropTop :214-249, Resize :62-134 = cv2.resize INTER_LINEAR on float32 + crop / zero-pad to the network width, Normalize
@@ -167,7 +172,7 @@ typedef struct vd3d_head_params {
     const float* prior_mean_std;
     const float* P2;
     int32_t B, N, A, n_cls, n_types;
-    int32_t img_h, img_w;
+    int32_t img_h, img_w;      /* ClipBoxes bounds; img_w <= 0: no clipping (the reference's `img_batch is None`) */
     float score_thr, nms_iou_thr;
     float filter_y_min, filter_y_max, filter_x_max;
     int32_t use_filter;

@@ -289,9 +289,10 @@ def decode(anchor, deltas, mean_std_sel, alpha_score):
     return boxes, mean_std_sel[:, 0, 0] > 0
 
 
-def get_bboxes(cls_preds, reg_preds, anchors, mean_std, mask, img_hw, num_classes, score_thr, nms_iou_thr):
+def get_bboxes(cls_preds, reg_preds, anchors, mean_std, mask, img_hw, num_classes, score_thr, nms_iou_thr, clip=True):
     """heads/detection_3d_head.py:341-400 for ONE sample (class-agnostic NMS).
-    Returns (scores[K], boxes[K,11], labels[K], anchor_index[K])."""
+    Returns (scores[K], boxes[K,11], labels[K], anchor_index[K]).  ``clip=False`` = the reference's ``img_batch is None``
+    (:375-376: ClipBoxes skipped)."""
     cls = cls_preds.sigmoid()
     idx = torch.nonzero(mask, as_tuple=False)[:, 0]
     cls_score = cls[idx, :num_classes]
@@ -302,10 +303,11 @@ def get_bboxes(cls_preds, reg_preds, anchors, mean_std, mask, img_hw, num_classe
     sel = mean_std[idx, label]  # [K,6,2]
     boxes, zmask = decode(anchors[idx], reg_preds[idx], sel, alpha_score)
     H, W = img_hw
-    boxes[:, 0].clamp_(min=0)
-    boxes[:, 1].clamp_(min=0)
-    boxes[:, 2].clamp_(max=W)
-    boxes[:, 3].clamp_(max=H)
+    if clip:
+        boxes[:, 0].clamp_(min=0)
+        boxes[:, 1].clamp_(min=0)
+        boxes[:, 2].clamp_(max=W)
+        boxes[:, 3].clamp_(max=H)
     # QUIRK kept from the reference (detection_3d_head.py:375-379,392-394): cls_score / max_score / bboxes are
     # filtered by the z-prior mask but `label` is NOT, and is then indexed with the NMS keep indices of the
     # FILTERED list -> labels are those of the unfiltered list at the same positions.

@@ -41,5 +41,5 @@ def result_text(scores, rows, obj_types, threshold=0.4):
             continue
         r = rows[i]
         text += ('{} -1 -1 {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {} \n').format(
-            obj_types[i], r[10], r[0], r[1], r[2], r[3], r[8], r[7], r[9], r[4], r[5], r[6], r[11], scores[i])
+            obj_types[i], r[10], r[0], r[1], r[2], r[3], r[8], r[7], r[9], r[4], r[5], r[6], r[11], float(scores[i]))
     return text

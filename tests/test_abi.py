@@ -39,3 +39,16 @@ def test_cpu_tensors_fail_loudly():
     from visualdet3d_amd import hip_ops as ops
     with pytest.raises(_lib.Vd3dError):
         ops.maxpool3x3s2(torch.zeros(1, 8, 8, 8, dtype=torch.bfloat16))
+
+
+def test_production_tile_list_is_the_one_the_tile_tests_force():
+    """tests/test_conv_tiles_gpu.py forces every id of this list against the oracle; ids outside it are rejected by the
+    product library (timing ablations / experimental tiles only exist in the -DVD3D_TUNING build)."""
+    import ctypes as C
+    ids = (C.c_int32 * 64)()
+    n = _lib.lib().vd3d_conv2d_production_tiles(ids, 64)
+    from tests.test_conv_tiles_gpu import PRODUCTION_TILES
+    assert sorted(ids[i] for i in range(n)) == sorted(PRODUCTION_TILES)
+    out = subprocess.run(['nm', '-C', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    # no ablation instantiation (template argument ABL != 0) in the product library: <..., (int)16, (int)0, (int)N, ...>
+    assert not re.search(r'conv_igemm_dma_kernel<short, \d+, \d+, \d+, \d+, true, 16, 0, [1-9]', out)

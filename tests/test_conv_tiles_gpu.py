@@ -1,0 +1,170 @@
+"""GPU: EVERY production tile of the implicit-GEMM conv family against the CPU oracle (torch fp32 convolution on operands
+rounded exactly like the HIP path rounds them), not against another tile of the same family.
+
+  * `vd3d_conv2d_production_tiles` lists the tile ids the heuristic in csrc/conv_igemm.hip can select; each one is FORCED
+    (`vd3d_conv2d_set_tuning`) on small shapes that are deliberately awkward for it: M not a tile multiple, Cout not a
+    tile multiple, with / without residual, channel-slice input and output, fp32 output from bf16 compute.
+  * the tiles the bench (BASELINE config 2, batch 8) actually runs are then checked under NATURAL dispatch at the
+    bench's own layer shapes (M = 8 x 24 x 80 = 15360 pixels: 1408->1408, 1152->1152, 1408->576, 1408->256; layer1/2/3 of
+    the stacked L/R batch; the R50 head 2176->2176 at 16 x 18 x 80), with `VD3D_CONV_DEBUG`-free proof of which kernel ran
+    left to the rocprof traces in profiles/.
+
+Bars: bf16 -- every element within ONE bf16 ulp of the oracle (|d| <= 2^-7 |ref|) plus the fp32 summation-order noise of a
+K-long dot product (3e-5 of the output scale); fp32 -- 2e-5 of the output scale (v_mfma_f32_32x32x2_f32 chains)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16_TILES = {50, 54, 76, 79}            # 16x16x32 bf16 MFMA tiles
+HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
+NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
+
+
+# = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 87, 30, 21, 23, 27]
+
+
+class forced_tile:
+    def __init__(self, cfg):
+        self.cfg = cfg
+
+    def __enter__(self):
+        from visualdet3d_amd import _lib
+        _lib.lib().vd3d_conv2d_set_tuning(self.cfg)
+
+    def __exit__(self, *exc):
+        from visualdet3d_amd import _lib
+        _lib.lib().vd3d_conv2d_set_tuning(0)
+
+
+def run_case(B, H, W, Cin, Cout, k=3, stride=1, pad=1, dil=1, residual=False, relu=True, dtype=torch.bfloat16, bn=True,
+             in_extra=0, out_extra=0, out_f32=False, seed=0, cfg=0):
+    """-> (max ulp-normalised error, max error relative to the output scale)."""
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    rnd = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    y = F.conv2d(rnd(x), rnd(w), None, stride, pad, dil)
+    bnp = None
+    scale, shift = torch.ones(Cout), b.clone()
+    if bn:
+        bnp = (torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.1, torch.randn(Cout, generator=g) * 0.1,
+               torch.rand(Cout, generator=g) + 0.5, 1e-5)
+        s = bnp[0] / torch.sqrt(bnp[3] + bnp[4])
+        shift = shift * s + (bnp[1] - bnp[2] * s)
+        scale = s
+    y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    Ho, Wo = y.shape[2:]
+    res = None
+    if residual:
+        res = rnd(torch.randn(B, Cout, Ho, Wo, generator=g))
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    dev = 'cuda'
+    xin = torch.zeros(B, H, W, Cin + in_extra, dtype=dtype, device=dev)
+    xin[..., in_extra:] = x.permute(0, 2, 3, 1).to(dev).to(dtype)
+    pc = ops.pack_conv(w.to(dev), b.to(dev), tuple(t.to(dev) if torch.is_tensor(t) else t for t in bnp) if bn else None, dtype, stride, pad, dil)
+    odt = torch.float32 if out_f32 else dtype
+    obuf = torch.full((B, Ho, Wo, Cout + out_extra), 7.0, dtype=odt, device=dev)
+    rv = res.permute(0, 2, 3, 1).contiguous().to(dev).to(dtype) if residual else None
+    with forced_tile(cfg):
+        out = ops.conv2d(xin[..., in_extra:], pc, out=obuf[..., :Cout], residual=rv, relu=relu, out_f32=out_f32)
+        torch.cuda.synchronize()
+    if out_extra:
+        assert bool((obuf[..., Cout:] == 7.0).all()), 'kernel wrote outside its channel slice'
+    got = out.float().cpu().permute(0, 3, 1, 2)
+    sc = y.abs().max().item()
+    d = (got - y).abs()
+    rel = d.max().item() / sc
+    if dtype == torch.bfloat16 and not out_f32:
+        ulp = (d / (y.abs() * 2.0 ** -7 + 3e-5 * sc)).max().item()      # <= 1: within one bf16 ulp (+ summation noise)
+    elif dtype == torch.bfloat16:
+        ulp = rel / 1e-4                                                  # fp32 epilogue from bf16 operands: summation noise only
+    else:
+        ulp = rel / 2e-5
+    return ulp, rel
+
+
+def _shapes_for(cfg):
+    """Small shapes that are awkward for tile `cfg` (B, H, W, Cin, Cout, kwargs)."""
+    if cfg in HALO_TILES:
+        return [
+            (1, 11, 37, 64, 136, dict(residual=True)),                 # ragged patch grid, partial N tile
+            (2, 8, 16, 128, 256, dict(residual=False, relu=False)),    # exactly one patch per image
+            (1, 17, 50, 192, 128, dict(residual=True, in_extra=64, out_extra=128)),
+        ]
+    if cfg in NARROW:
+        n = NARROW[cfg]
+        return [
+            (1, 13, 27, 64, n, dict(residual=True)),
+            (2, 9, 31, 24, n - 5, dict(residual=False, bn=False)),     # Cout % 4 != 0 -> scalar epilogue
+            (1, 10, 18, 72, n - 8, dict(k=1, pad=0, in_extra=8, out_extra=8)),
+        ]
+    return [
+        (1, 13, 27, 64, 400, dict(residual=True)),                      # M = 351, two / three / four N tiles, last one partial
+        (2, 7, 45, 200, 360, dict(residual=False, relu=False, in_extra=56, out_extra=40)),   # Cin not a K-slice multiple (tap-major walk)
+        (1, 9, 33, 128, 300, dict(k=1, pad=0, residual=True)),          # 1x1
+        (1, 15, 21, 64, 290, dict(stride=2, residual=False)),           # stride 2, Cout % 4 != 0 -> scalar epilogue
+        (1, 6, 50, 256, 288, dict(out_f32=True, bn=False, relu=False)), # fp32 output (final head convs)
+    ]
+
+
+@pytest.mark.parametrize('cfg', PRODUCTION_TILES)
+def test_every_production_tile_bf16_vs_oracle(cfg):
+    for i, (B, H, W, Cin, Cout, kw) in enumerate(_shapes_for(cfg)):
+        ulp, rel = run_case(B, H, W, Cin, Cout, dtype=torch.bfloat16, seed=100 + i, cfg=cfg, **kw)
+        assert ulp <= 1.0, 'tile %d shape %s: %.2f bf16 ulp (rel %.2e)' % (cfg, (B, H, W, Cin, Cout, kw), ulp, rel)
+
+
+@pytest.mark.parametrize('cfg', [c for c in PRODUCTION_TILES if c not in BF16_TILES])
+def test_every_production_tile_fp32_vs_oracle(cfg):
+    for i, (B, H, W, Cin, Cout, kw) in enumerate(_shapes_for(cfg)):
+        ulp, rel = run_case(B, H, W, Cin, Cout, dtype=torch.float32, seed=200 + i, cfg=cfg, **kw)
+        assert rel <= 2e-5, 'tile %d shape %s: rel %.2e' % (cfg, (B, H, W, Cin, Cout, kw), rel)
+
+
+def test_forced_tile_that_cannot_run_the_shape_is_an_error():
+    """The product library never computes with a kernel that is wrong for the shape: a halo tile forced on a 1x1 conv, a
+    bf16-only tile forced in fp32 mode and an id that is not a production tile all fail loudly."""
+    from visualdet3d_amd._lib import Vd3dError
+    with pytest.raises(Vd3dError):
+        run_case(1, 8, 16, 64, 128, k=1, pad=0, cfg=21)
+    with pytest.raises(Vd3dError):
+        run_case(1, 8, 16, 64, 352, dtype=torch.float32, cfg=50)
+    for bad in (93, 1, 7):                # 93: a timing ablation of the tuning build; 1: the retired v1 kernel
+        with pytest.raises(Vd3dError):
+            run_case(1, 8, 16, 64, 128, cfg=bad)
+    ulp, _ = run_case(1, 8, 16, 64, 128, cfg=0)       # and the override is really back to the heuristic afterwards
+    assert ulp <= 1.0
+
+
+# ---- the bench's own layer shapes, natural dispatch (BASELINE config 2: 8 pairs of 384 x 1280 -> 16 stacked images) --------
+BENCH_SHAPES = [
+    # name, B, H, W, Cin, Cout, kwargs                                   tile the heuristic picks (conv_igemm.hip dispatch)
+    ('head 1408->1408 + res', 8, 24, 80, 1408, 1408, dict(residual=True)),         # 256x352 16x16x32 strips
+    ('head 1408->1408', 8, 24, 80, 1408, 1408, dict(residual=False)),
+    ('neck 1152->1152 + res', 8, 24, 80, 1152, 1152, dict(residual=True)),         # 256x288 16x16x32 strips, ring of 6
+    ('reg out 1408->576 f32', 8, 24, 80, 1408, 576, dict(out_f32=True, bn=False, relu=False)),   # 128x192
+    ('cls 1408->256', 8, 24, 80, 1408, 256, dict(bn=False)),                        # halo 8x16x128
+    ('cls 256->144 f32', 8, 24, 80, 256, 144, dict(out_f32=True, bn=False, relu=False)),
+    ('layer3 256->256 + res', 16, 24, 80, 256, 256, dict(residual=True)),           # halo 8x16x256
+    ('layer2 128->128 + res', 16, 48, 160, 128, 128, dict(residual=True)),          # halo 8x32x128
+    ('layer1 64->64 + res', 16, 96, 320, 64, 64, dict(residual=True)),              # resident weights
+    ('layer2.0 64->128 s2', 16, 96, 320, 64, 128, dict(stride=2)),                  # 128x128
+    ('layer3.0 128->256 s2', 16, 48, 160, 128, 256, dict(stride=2)),
+    ('ghost 384->384', 8, 24, 80, 384, 384, dict()),
+    ('r50 head 2176->2176', 16, 18, 80, 2176, 2176, dict(residual=True)),           # 256x272 16x16x32 strips
+]
+
+
+@pytest.mark.parametrize('case', BENCH_SHAPES, ids=[c[0] for c in BENCH_SHAPES])
+def test_bench_shapes_natural_dispatch_bf16_vs_oracle(case):
+    name, B, H, W, Cin, Cout, kw = case
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    ulp, rel = run_case(B, H, W, Cin, Cout, dtype=torch.bfloat16, seed=7, cfg=0, **kw)
+    assert ulp <= 1.0, '%s: %.2f bf16 ulp (rel %.2e)' % (name, ulp, rel)

@@ -88,3 +88,75 @@ def test_pack_module_nhwc_engine_path_with_bn_relu(dtype, tol):
         got = m.forward_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda().to(dtype), bn=bn, relu=True)
     got = got.float().cpu().permute(0, 3, 1, 2)
     assert ((got - want).abs().max() / want.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize('name', list(DCN_CASES))
+def test_pybind_shaped_ext_surface_with_reference_argument_order(name):
+    """``deform_conv_ext.{modulated_deform_conv_forward, deform_conv_forward}`` called exactly as the reference's autograd
+    Functions call the pybind module (lib/ops/dcn/deform_conv.py:90-95,181-186): caller-allocated ``output`` written in place,
+    two empty scratch tensors that stay empty, W-before-H order for DCNv1; results = the reference's own im2col goldens."""
+    from visualdet3d_amd.networks.lib.ops.dcn import deform_conv_ext
+    g = load_golden('dcn_cases')
+    x, off, mask, w, bias, kw = dcn_inputs(name)
+    x, off, w = x.cuda(), off.cuda(), w.cuda()
+    st, pad, dil = kw['stride'], kw['padding'], kw['dilation']
+    want = g[name + '_out']
+    output = torch.full(want.shape, 123.0, device='cuda')
+    bufs = [x.new_empty(0), x.new_empty(0)]
+    ptr = output.data_ptr()
+    if mask is not None:
+        ret = deform_conv_ext.modulated_deform_conv_forward(x, w, bias.cuda(), bufs[0], off, mask.cuda(), output, bufs[1], w.shape[2], w.shape[3],
+                                                            st, st, pad, pad, dil, dil, kw['groups'], kw['deformable_groups'], True)
+        assert ret is None
+    else:
+        ret = deform_conv_ext.deform_conv_forward(x, w, off, output, bufs[0], bufs[1], w.size(3), w.size(2), st, st, pad, pad, dil, dil,
+                                                  kw['groups'], kw['deformable_groups'], min(64, x.shape[0]))
+        assert ret == 1
+    assert output.data_ptr() == ptr and bufs[0].numel() == 0 and bufs[1].numel() == 0
+    err = np.abs(output.cpu().numpy() - want).max() / np.abs(want).max()
+    assert err < 1e-5, err
+
+
+def test_ext_surface_error_behaviour_and_asymmetric_geometry():
+    """CPU tensors / bad shapes raise RuntimeError like the reference's AT_ERROR / TORCH_CHECK; backward names raise
+    NotImplementedError; H != W strides / pads go to the right axes (W-before-H for v1, H-before-W for v2) -- checked against
+    the oracle (oracle/dcn_ref.py) on an asymmetric case the symmetric goldens cannot distinguish."""
+    from visualdet3d_amd.networks.lib.ops.dcn import deform_conv_ext
+    x, off, mask, w, bias, kw = dcn_inputs('v2_3x3')
+    out = torch.empty(2, 24, 9, 13)
+    with pytest.raises(RuntimeError, match='not implemented on CPU'):
+        deform_conv_ext.modulated_deform_conv_forward(x, w, bias, x.new_empty(0), off, mask, out, x.new_empty(0), 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, True)
+    with pytest.raises(RuntimeError, match='not implemented on CPU'):
+        deform_conv_ext.deform_conv_forward(x, w, off, out, x.new_empty(0), x.new_empty(0), 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 2)
+    xc, wc, oc, mc, bc = x.cuda(), w.cuda(), off.cuda(), mask.cuda(), bias.cuda()
+    outc = torch.empty(2, 24, 9, 13, device='cuda')
+    with pytest.raises(RuntimeError, match='kernel shape wont match'):
+        deform_conv_ext.modulated_deform_conv_forward(xc, wc, bc, xc.new_empty(0), oc, mc, outc, xc.new_empty(0), 5, 3, 1, 1, 1, 1, 1, 1, 1, 1, True)
+    with pytest.raises(RuntimeError, match='has to be contiguous'):
+        deform_conv_ext.modulated_deform_conv_forward(xc.transpose(2, 3), wc, bc, xc.new_empty(0), oc, mc, outc, xc.new_empty(0), 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, True)
+    with pytest.raises(RuntimeError, match='invalid number of channels of offset'):
+        deform_conv_ext.deform_conv_forward(xc, wc, oc[:, :10], outc, xc.new_empty(0), xc.new_empty(0), 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 2)
+    for fn in (deform_conv_ext.deform_conv_backward_input, deform_conv_ext.deform_conv_backward_parameters,
+               deform_conv_ext.modulated_deform_conv_backward):
+        with pytest.raises(NotImplementedError):
+            fn()
+    # asymmetric geometry: stride (2, 1), pad (0, 2), dilation (1, 2), 3 x 3 kernel
+    gg = torch.Generator().manual_seed(5)
+    B, C_, H, W, O = 2, 8, 11, 9, 12
+    sh, sw, ph, pw, dh, dw = 2, 1, 0, 2, 1, 2
+    Ho, Wo = (H + 2 * ph - (dh * 2 + 1)) // sh + 1, (W + 2 * pw - (dw * 2 + 1)) // sw + 1
+    x = torch.randn(B, C_, H, W, generator=gg)
+    w = torch.randn(O, C_, 3, 3, generator=gg) * 0.2
+    off = torch.randn(B, 18, Ho, Wo, generator=gg) * 1.5
+    mask = torch.rand(B, 9, Ho, Wo, generator=gg)
+    bias = torch.randn(O, generator=gg)
+    want2 = dcn_ref.deform_conv_forward(x, off, mask, w, bias, (sh, sw), (ph, pw), (dh, dw), 1, 1)
+    want1 = dcn_ref.deform_conv_forward(x, off, None, w, None, (sh, sw), (ph, pw), (dh, dw), 1, 1)
+    o2 = torch.empty(B, O, Ho, Wo, device='cuda')
+    deform_conv_ext.modulated_deform_conv_forward(x.cuda(), w.cuda(), bias.cuda(), x.new_empty(0).cuda(), off.cuda(), mask.cuda(), o2,
+                                                  x.new_empty(0).cuda(), 3, 3, sh, sw, ph, pw, dh, dw, 1, 1, True)
+    o1 = torch.empty(B, O, Ho, Wo, device='cuda')
+    deform_conv_ext.deform_conv_forward(x.cuda(), w.cuda(), off.cuda(), o1, x.new_empty(0).cuda(), x.new_empty(0).cuda(), 3, 3, sw, sh, pw, ph, dw, dh,
+                                        1, 1, 2)
+    assert ((o2.cpu() - want2).abs().max() / want2.abs().max()).item() < 1e-5
+    assert ((o1.cpu() - want1).abs().max() / want1.abs().max()).item() < 1e-5

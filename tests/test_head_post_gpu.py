@@ -78,3 +78,27 @@ def test_nms_bit_exact(n, seed):
     want = nms_numpy(boxes, scores, 0.45)
     got = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.45).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+def test_get_bboxes_reference_signature_no_clip_and_cls_agnostic_flag():
+    """Reference-signature ``get_bboxes`` (detection_3d_head.py:341): ``img_batch=None`` skips ClipBoxes (:375-376) -- compared
+    with the oracle's no-clip branch; the unsupported per-class NMS flag fails loudly."""
+    H, W = 96, 320
+    cfg, head, cls, reg, P2 = _setup(H, W, 1, 7, logit_std=1.5)
+    mean_npy, std_npy = orc.load_priors(cfg.head.preprocessed_path, cfg.obj_types)
+    anchors, means, mean_std = orc.anchors_for_image(H, W, cfg.head.anchors_cfg, mean_npy, std_npy)
+    mask = orc.anchor_mask(anchors, means, P2)
+    img = torch.zeros(1, 3, H, W).cuda()
+    with pytest.raises(RuntimeError):
+        head.get_bboxes(cls.cuda(), reg.cuda(), None, P2.cuda(), img_batch=None)       # shape unknown yet
+    a = head.get_anchor(img, P2.cuda())
+    s, b, l = [t.cpu() for t in head.get_bboxes(cls.cuda(), reg.cuda(), a, P2.cuda(), img_batch=None)]
+    ws, wb, wl, _ = orc.get_bboxes(cls[0], reg[0], anchors, mean_std, mask[0], (H, W), 2, 0.6, 0.4, clip=False)
+    assert len(s) == len(ws) and len(s) >= 3 and torch.equal(l, wl) and torch.allclose(s, ws, rtol=1e-5, atol=1e-6)
+    assert ((b - wb).abs() / wb.abs().amax(dim=0).clamp_min(1.0)).max().item() < 1e-5
+    assert bool((b[:, 0] < 0).any() or (b[:, 1] < 0).any() or (b[:, 2] > W).any() or (b[:, 3] > H).any()), 'case must have a box the clamp would move'
+    sc, bc, lc = [t.cpu() for t in head.get_bboxes(cls.cuda(), reg.cuda(), a, P2.cuda(), img_batch=img)]
+    assert bool((bc[:, 2] <= W).all()) and bool((bc[:, 3] <= H).all()) and bool((bc[:, :2] >= 0).all())
+    head.test_cfg.cls_agnositc = False
+    with pytest.raises(NotImplementedError):
+        head.get_bboxes(cls.cuda(), reg.cuda(), a, P2.cuda(), img_batch=img)

@@ -116,3 +116,80 @@ def test_config3_stereo_core_with_dcn_head_r50():
     assert rel_err(cls.cpu(), want_cls) < 1e-3
     assert rel_err(reg.cpu(), want_reg) < 1e-3
     assert len(outs) == 2
+
+
+def _bench_model_c2(dtype):
+    """BASELINE config 2 exactly as bench.py builds it (Stereo3D R34, score_thr 0.75, nms 0.4, seed-1 weights)."""
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    cfg = syn.stereo3d_cfg(tmp, depth=34, score_thr=0.75, nms_iou_thr=0.4)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    m, sd = _model(cfg, dict(seed=1, head_std=0.00042), dtype)
+    return m, sd, cfg
+
+
+def test_config2_batch8_bf16_detection_level_acceptance():
+    """BASELINE config 2 AT SIZE (8 pairs of 384 x 1280, bf16, the tiles bench.py times) against the bf16-rounded oracle
+    (SURVEY.md 7.3 item 2).  Three levels:
+
+    (a) post-processing at size is EXACT: the oracle's get_bboxes applied to the HIP path's own logits selects the same
+        anchors in the same order (bit-exact index selection) with fields <= 1e-5;
+    (b) logits vs the oracle run with identical bf16 rounding points: two correct bf16 implementations differ by the
+        1-ulp flips their different fp32 summation orders cause ~60 layers upstream, so the bar is what one flip per
+        layer explains (3e-2 of the logit range), NOT 1e-3 -- the 1e-3 bar is met by the fp32 validation mode above and,
+        per layer, by tests/test_conv_tiles_gpu.py (every bench tile within one bf16 ulp of the oracle on identical inputs);
+    (c) detection set: detections are matched BY ANCHOR INDEX; every oracle detection whose score clears the threshold by
+        more than the observed score difference is found by the HIP path (and vice versa) unless an NMS decision involving
+        it was marginal; matched boxes agree within the observed logit difference pushed through the decode."""
+    m, sd, cfg = _bench_model_c2(torch.bfloat16)
+    B, H, W = 8, 384, 1280
+    L, R = syn.stereo_pair(B, H, W, seed=100)
+    P2, P3 = syn.kitti_calib(W, batch=B)
+    scores, boxes, labels, aidx, count = [t.cpu() for t in m.forward_device(L.cuda(), R.cuda(), P2.cuda())]
+    cls, reg = [t.float().cpu() for t in m._last_raw]
+    assert int(count.min()) >= 0
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    with torch.no_grad():
+        ref, st = orc.stereo3d_forward(sd, cfg, L, R, P2, rnd=orc.bf16_round, return_stages=True)
+    thr, iou_thr = 0.75, 0.4
+    # (a) exact post-processing on identical logits
+    n_det = 0
+    for b in range(B):
+        s_o, b_o, l_o, i_o = orc.get_bboxes(cls[b], reg[b], st['anchors'], st['mean_std'], st['mask'][b], (H, W), 2, thr, iou_thr)
+        k = int(count[b])
+        assert torch.equal(aidx[b, :k].long(), i_o.long()), 'frame %d: anchor selection differs on identical logits' % b
+        assert torch.equal(labels[b, :k].long(), l_o.long())
+        assert rel_err(scores[b, :k], s_o) < 1e-5 and rel_err(boxes[b, :k], b_o) < 1e-5
+        n_det += k
+    assert n_det >= 8, 'workload must produce detections (got %d)' % n_det
+    # (b) logits
+    e_cls, e_reg = rel_err(cls, st['cls_preds']), rel_err(reg, st['reg_preds'])
+    d_score = (torch.sigmoid(cls) - torch.sigmoid(st['cls_preds'])).abs().max().item()
+    print('\n[C2 B=8 bf16] logits rel err cls %.3e reg %.3e; max |score diff| %.3e; %d detections' % (e_cls, e_reg, d_score, n_det))
+    assert e_cls < 3e-2 and e_reg < 3e-2
+    # (c) detection set by anchor index, margin = observed score difference
+    margin = max(2.0 * d_score, 1e-3)
+    worst = 0.0
+    unmatched = 0
+    for b in range(B):
+        k = int(count[b])
+        got = {int(a): j for j, a in enumerate(aidx[b, :k].tolist())}
+        s_o, b_o, l_o, i_o = ref[b][0], ref[b][1], ref[b][2], orc.get_bboxes(
+            st['cls_preds'][b], st['reg_preds'][b], st['anchors'], st['mean_std'], st['mask'][b], (H, W), 2, thr, iou_thr)[3]
+        want = {int(a): j for j, a in enumerate(i_o.tolist())}
+        for a, j in want.items():
+            if a in got:
+                gj = got[a]
+                scale = b_o.abs().amax(dim=0).clamp_min(1.0)
+                worst = max(worst, float(((boxes[b, gj] - b_o[j]).abs() / scale).max()), abs(float(scores[b, gj] - s_o[j])))
+                assert int(labels[b, gj]) == int(l_o[j])
+            elif float(s_o[j]) > thr + margin:
+                unmatched += 1
+        for a, gj in got.items():
+            if a not in want and float(scores[b, gj]) > thr + margin:
+                unmatched += 1
+    print('[C2 B=8 bf16] matched-by-anchor worst field/score difference %.3e (margin %.3e), clear-margin unmatched %d' % (worst, margin, unmatched))
+    # an unmatched clear-margin detection can only come from an NMS decision that flipped (IoU within the box difference of
+    # the threshold); allow at most 2 % of the detections for that
+    assert unmatched <= max(1, n_det // 50), unmatched
+    assert worst < 3e-2, worst

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvd3d_hip.so')
+# VD3D_TUNING_LIB=1 (tools/bench_conv.py only): the -DVD3D_TUNING build with the experimental tiles / timing ablations
+LIB_PATH = os.path.join(_HERE, 'libvd3d_hip_tuning.so' if os.environ.get('VD3D_TUNING_LIB') else 'libvd3d_hip.so')
 
 VD3D_BF16 = 0
 VD3D_F32 = 1
@@ -69,6 +70,7 @@ SIGNATURES = {
     'vd3d_last_error': (C.c_char_p, []),
     'vd3d_conv2d_igemm': (c_int, [C.POINTER(ConvParams), c_void_p]),
     'vd3d_conv2d_set_tuning': (c_int, [c_int]),
+    'vd3d_conv2d_production_tiles': (c_int, [c_void_p, c_int]),
     'vd3d_pack_image_nhwc4': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_maxpool3x3s2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_avgpool2x2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

@@ -27,7 +27,17 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, tuning=False):
+    """tuning=True: the -DVD3D_TUNING variant (experimental conv tiles + timing ablations) -> libvd3d_hip_tuning.so; the
+    product library never contains those kernels."""
+    global OBJ, LIB
+    obj_dir, lib_path, flags = OBJ, LIB, FLAGS
+    if tuning:
+        obj_dir, lib_path, flags = OBJ + '_tuning', os.path.join(HERE, 'libvd3d_hip_tuning.so'), FLAGS + ['-DVD3D_TUNING']
+    return _build(force, verbose, obj_dir, lib_path, flags)
+
+
+def _build(force, verbose, OBJ, LIB, FLAGS):
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + [os.path.join(REPO, 'include', 'vd3d.h')]
     jobs = []
@@ -62,4 +72,4 @@ def build(force=False, verbose=True):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
+    build(force='--force' in sys.argv, tuning='--tuning' in sys.argv)

@@ -63,3 +63,12 @@ void vd3d_set_error(const char* msg);
 int vd3d_check_launch(const char* what);
 
 static inline int vd3d_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Per-DEVICE launch bookkeeping.  hipFuncSetAttribute acts on the current device's copy of a kernel, so "dynamic-LDS limit
+// already raised" must be remembered per device ordinal, not per process (one process may drive several GPUs).
+constexpr int kVd3dMaxDevices = 64;
+struct Vd3dLdsLimit { int bytes[kVd3dMaxDevices]; };          // zero-initialise (static storage)
+int vd3d_current_device();                                      // ordinal of the current device, or -1 (error string set)
+int vd3d_device_cu_count();                                     // compute units of the current device (cached per device), or -1
+// raise `kern`'s dynamic shared memory limit to >= bytes on the current device (no-op if already done there)
+int vd3d_raise_lds_limit(const void* kern, int bytes, Vd3dLdsLimit& state, const char* what);

@@ -1093,16 +1093,12 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
 }
 
 int launch_resident64(ConvArgs& a, hipStream_t stream) {
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return vd3d_check_launch("hipGetDeviceProperties");
-        num_cu = prop.multiProcessorCount;
-        if (hipFuncSetAttribute((const void*)conv_resident64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kResLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv_resident64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kResLds) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(conv_resident64)");
-    }
+    static Vd3dLdsLimit lim_res, lim_nores;
+    int rc = vd3d_raise_lds_limit((const void*)conv_resident64_kernel<true>, kResLds, lim_res, "hipFuncSetAttribute(conv_resident64)");
+    if (!rc) rc = vd3d_raise_lds_limit((const void*)conv_resident64_kernel<false>, kResLds, lim_nores, "hipFuncSetAttribute(conv_resident64)");
+    if (rc) return rc;
+    const int num_cu = vd3d_device_cu_count();
+    if (num_cu <= 0) return VD3D_ELAUNCH;
     const int ntiles = a.B * ((a.H + kResTH - 1) / kResTH) * ((a.W + kResTW - 1) / kResTW);
     const int grid = ntiles < num_cu ? ntiles : num_cu;
     if (a.residual) hipLaunchKernelGGL(conv_resident64_kernel<true>, dim3(grid), dim3(512), kResLds, stream, a, ntiles);
@@ -1118,13 +1114,9 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
     static_assert(LDS <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
     a.tiles_m = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     a.tiles_n = (a.Cout + BN - 1) / BN;
-    static bool attr_done = false;
+    static Vd3dLdsLimit lim;
     auto kern = conv_halo_kernel<T, TH, TW, BN, WARPS_M, WARPS_N, STAGES>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(conv_halo)");
-        attr_done = true;
-    }
+    if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_halo)")) return rc;
     const int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
     if (grid <= 0 || grid > 0x7fffffff) return VD3D_EINVAL;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS, stream, a);
@@ -1137,68 +1129,87 @@ int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * (BM + BN) * 128;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
-    static bool attr_done = false;
+    static Vd3dLdsLimit lim;
     void (*kern)(const ConvArgs);
     if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL, HEADF>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(conv_igemm)");
-        attr_done = true;
-    }
+    if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_igemm)")) return rc;
     const int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
     if (grid <= 0 || grid > 0x7fffffff) return VD3D_EINVAL;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS, stream, a);
     return vd3d_check_launch("conv_igemm");
 }
 
-// tuning override (tools/bench_conv.py): 0 = heuristic, otherwise a config id
+// Tile override: 0 = heuristic, otherwise a config id (vd3d_conv2d_set_tuning).  The PRODUCT build only knows the ids of the
+// tiles the heuristic below can pick (tests/test_conv_tiles_gpu.py forces each of them on awkward shapes and compares with
+// the oracle); a forced tile that cannot run the given convolution is an error, never a silent fallback.  Experimental
+// tiles and the timing ablations (results wrong by construction) exist only in a -DVD3D_TUNING build
+// (`python -m visualdet3d_amd.build --tuning` -> libvd3d_hip_tuning.so, used by tools/bench_conv.py).
 static int g_force_cfg = 0;
+
+static int forced_tile_error(const char* why) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "conv2d_igemm: forced tile config %d %s", g_force_cfg, why);
+    vd3d_set_error(msg);
+    return VD3D_EINVAL;
+}
 
 template <typename T>
 int dispatch(ConvArgs& a, hipStream_t stream) {
+    constexpr bool kBf16 = sizeof(T) == 2;
+    const bool halo_shape = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W &&
+                            a.Cin % (128 / (int)sizeof(T)) == 0;
+#define VD3D_BF16_ONLY(...) do { if constexpr (kBf16) return __VA_ARGS__; else return forced_tile_error("is a bf16-only tile"); } while (0)
+#define VD3D_HALO_ONLY(...) do { if (halo_shape) return __VA_ARGS__; return forced_tile_error("needs 3x3 / stride 1 / pad 1 with Cin a multiple of the K slice"); } while (0)
     switch (g_force_cfg) {
+        case 0: break;
+        // ---- production tiles (every one of these is reachable from the heuristic below) ----
+        case 44: return launch<T, 128, 128, 2, 2, true, true>(a, stream);
+        case 42: return launch<T, 256, 256, 2, 4, true, true>(a, stream);
+        case 40: return launch<T, 256, 352, 8, 1, true, true>(a, stream);
+        case 41: return launch<T, 256, 288, 8, 1, true, true>(a, stream);
+        case 50: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16>(a, stream));
+        case 54: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream));
+        case 12: return launch<T, 128, 352, 4, 1, true>(a, stream);
+        case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
+        case 76: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16>(a, stream));
+        case 43: return launch<T, 128, 192, 2, 2, true, true>(a, stream);
+        case 79: VD3D_BF16_ONLY(launch<T, 256, 272, 8, 1, true, true, 16>(a, stream));
+        case 87: return launch<T, 256, 32, 8, 1, true, true, 32, 1>(a, stream);
+        case 30: return launch<T, 128, 64, 4, 1, true>(a, stream);
+        case 21: VD3D_HALO_ONLY(launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream));
+        case 23: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream));
+        case 27: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream));
+        case 60: break;      // heuristic, but without the resident-weight kernel (A/B of that kernel)
+#ifdef VD3D_TUNING
         case 1: return launch<T, 128, 128, 2, 2>(a, stream);
         case 2: return launch<T, 128, 128, 2, 2, true>(a, stream);
         case 8: return launch<T, 256, 256, 2, 4, true>(a, stream);
         case 9: return launch<T, 256, 352, 8, 1, true>(a, stream);
         case 10: return launch<T, 256, 288, 8, 1, true>(a, stream);
-        case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 17: return launch<T, 128, 192, 2, 2, true>(a, stream);
-        case 30: return launch<T, 128, 64, 4, 1, true>(a, stream);
-        case 40: return launch<T, 256, 352, 8, 1, true, true>(a, stream);
-        case 41: return launch<T, 256, 288, 8, 1, true, true>(a, stream);
-        case 42: return launch<T, 256, 256, 2, 4, true, true>(a, stream);
-        case 43: return launch<T, 128, 192, 2, 2, true, true>(a, stream);
-        case 44: return launch<T, 128, 128, 2, 2, true, true>(a, stream);
-        case 50: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream); else break;
-        case 51: if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16>(a, stream); else break;
-        case 54: if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream); else break;
-        case 21: return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
-        case 23: return launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream);
-        case 27: return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
-        case 70: return launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream);
-        case 77: return launch_halo<T, 8, 16, 256, 2, 2, 3>(a, stream);
-        case 79: if constexpr (sizeof(T) == 2) return launch<T, 256, 272, 8, 1, true, true, 16>(a, stream); else break;
+        case 51: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16>(a, stream));
+        case 70: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream));
+        case 77: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 256, 2, 2, 3>(a, stream));
         case 84: return launch<T, 256, 32, 4, 1, true, true>(a, stream);
         case 85: return launch<T, 128, 64, 4, 1, true, true, 32, 2>(a, stream);
         case 86: return launch<T, 128, 64, 2, 2, true, true>(a, stream);
-        case 87: return launch<T, 256, 32, 8, 1, true, true, 32, 1>(a, stream);
-        case 78: return launch_halo<T, 8, 16, 256, 1, 4, 3>(a, stream);
-        case 91: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 1>(a, stream); else break;
-        case 92: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 2>(a, stream); else break;
-        case 93: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 3>(a, stream); else break;
-        case 94: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 4>(a, stream); else break;
-        case 95: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 5>(a, stream); else break;
-        case 96: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 6>(a, stream); else break;
-        case 97: if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16, 0, 7>(a, stream); else break;
-        case 73: if constexpr (sizeof(T) == 2) return launch<T, 128, 144, 4, 1, true, true, 16>(a, stream); else break;
-        case 74: if constexpr (sizeof(T) == 2) return launch<T, 64, 144, 2, 1, true, true, 16>(a, stream); else break;
-        case 75: if constexpr (sizeof(T) == 2) return launch<T, 128, 288, 2, 2, true, true, 16>(a, stream); else break;
-        case 76: if constexpr (sizeof(T) == 2) return launch<T, 128, 288, 4, 2, true, true, 16>(a, stream); else break;
-        case 71: return launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream);
-        case 72: return launch_halo<T, 8, 16, 64, 2, 2, 4>(a, stream);
-        default: break;
+        case 78: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 256, 1, 4, 3>(a, stream));
+        // timing ablations of the 352 strip: WRONG results by construction (ABL template flag)
+        case 91: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 1>(a, stream));
+        case 92: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 2>(a, stream));
+        case 93: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 3>(a, stream));
+        case 94: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 4>(a, stream));
+        case 95: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 5>(a, stream));
+        case 96: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 6>(a, stream));
+        case 97: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 7>(a, stream));
+        case 73: VD3D_BF16_ONLY(launch<T, 128, 144, 4, 1, true, true, 16>(a, stream));
+        case 74: VD3D_BF16_ONLY(launch<T, 64, 144, 2, 1, true, true, 16>(a, stream));
+        case 75: VD3D_BF16_ONLY(launch<T, 128, 288, 2, 2, true, true, 16>(a, stream));
+        case 71: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream));
+        case 72: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 64, 2, 2, 4>(a, stream));
+#endif
+        default: return forced_tile_error("is not a tile of this build");
     }
     if constexpr (sizeof(T) == 2) {
         if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
@@ -1220,8 +1231,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         const int64_t padded = (int64_t)((a.H + th - 1) / th * th) * ((a.W + tw - 1) / tw * tw);
         return padded * 100 <= (int64_t)a.H * a.W * 108;
     };
-    const bool halo_ok = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W &&
-                         a.Cin % (128 / (int)sizeof(T)) == 0 && patch_waste_ok(8, 16);
+    const bool halo_ok = halo_shape && patch_waste_ok(8, 16);
     if (halo_ok && a.Cout <= 128 && a.Cout % 128 == 0 && patch_waste_ok(8, 32)) return launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream);
     if (halo_ok && a.Cout == 256) {
         if (a.Cin >= 1024) return launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream);
@@ -1286,6 +1296,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
             else return launch<T, 256, 256, 2, 4, true, true>(a, stream);
         default: return launch<T, 128, 128, 2, 2, true, true>(a, stream);
     }
+#undef VD3D_BF16_ONLY
+#undef VD3D_HALO_ONLY
 }
 
 }  // namespace
@@ -1293,6 +1305,14 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
 extern "C" int vd3d_conv2d_set_tuning(int cfg) {
     g_force_cfg = cfg;
     return VD3D_OK;
+}
+
+extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
+    // keep in step with the "production tiles" block of dispatch()
+    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 87, 30, 21, 23, 27};
+    const int n = (int)(sizeof(kIds) / sizeof(kIds[0]));
+    for (int i = 0; i < n && i < cap; ++i) ids[i] = kIds[i];
+    return n;
 }
 
 static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {

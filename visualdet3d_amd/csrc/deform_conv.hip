@@ -443,12 +443,8 @@ template <typename T, int BN>
 int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
     const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * 48;   // two stages + the geometry table
     if (LDS > 160 * 1024) { vd3d_set_error("deform_conv: kernel window too large for the NHWC path"); return VD3D_EINVAL; }
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)dcn_nhwc_kernel<T, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(dcn_nhwc)");
-        attr_done = true;
-    }
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)dcn_nhwc_kernel<T, BN>, 160 * 1024, lim, "hipFuncSetAttribute(dcn_nhwc)")) return rc;
     dim3 grid((a.Ho * a.Wo + 63) / 64, (a.O + BN - 1) / BN, a.B);
     hipLaunchKernelGGL((dcn_nhwc_kernel<T, BN>), grid, dim3(256), LDS, s, a);
     return vd3d_check_launch("deform_conv(nhwc)");

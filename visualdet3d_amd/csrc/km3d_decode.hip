@@ -358,12 +358,9 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     int rc = vd3d_check_launch("km3d_peaks");
     if (rc) return rc;
     const int lds = q->max_peaks * 8;
-    static int attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute((const void*)km3d_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(km3d_topk)");
-        attr = lds;
-    }
+    static Vd3dLdsLimit lim;
+    rc = vd3d_raise_lds_limit((const void*)km3d_topk_kernel, lds, lim, "hipFuncSetAttribute(km3d_topk)");
+    if (rc) return rc;
     hipLaunchKernelGGL(km3d_topk_kernel, dim3(nch, q->B), dim3(kNmsThreads), lds, s, a);
     rc = vd3d_check_launch("km3d_topk");
     if (rc) return rc;

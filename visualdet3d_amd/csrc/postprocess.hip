@@ -163,8 +163,10 @@ __global__ void __launch_bounds__(kNmsThreads) head_nms_kernel(const HeadArgs p)
         const float l3 = d[11] * ms[11] + ms[10];
         float alpha = atan2f(s2, c2) / 2.0f;
         if (alpha_score < 0.5f) alpha += 3.14159265358979323846f;
-        x1 = fmaxf(x1, 0.0f); y1 = fmaxf(y1, 0.0f);
-        x2 = fminf(x2, (float)p.img_w); y2 = fminf(y2, (float)p.img_h);
+        if (p.img_w > 0) {    // ClipBoxes (networks/utils/utils.py:186-196); img_w <= 0: the reference's `img_batch is None` (no clipping)
+            x1 = fmaxf(x1, 0.0f); y1 = fmaxf(y1, 0.0f);
+            x2 = fminf(x2, (float)p.img_w); y2 = fminf(y2, (float)p.img_h);
+        }
         float* o = tbox + (int64_t)i * 11;
         o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2; o[4] = c3x; o[5] = c3y; o[6] = z; o[7] = w3; o[8] = h3; o[9] = l3; o[10] = alpha;
         p.ws.scores[cb + i] = best;
@@ -279,12 +281,9 @@ extern "C" int vd3d_head_postprocess(const vd3d_head_params* q, void* stream) {
     int rc = vd3d_check_launch("head_select");
     if (rc) return rc;
     const int lds = (int)head_nms_lds(q->max_cand);
-    static int attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute((const void*)head_nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(head_nms)");
-        attr = lds;
-    }
+    static Vd3dLdsLimit lim;
+    rc = vd3d_raise_lds_limit((const void*)head_nms_kernel, lds, lim, "hipFuncSetAttribute(head_nms)");
+    if (rc) return rc;
     hipLaunchKernelGGL(head_nms_kernel, dim3(q->B), dim3(kNmsThreads), lds, s, a);
     return vd3d_check_launch("head_nms");
 }
@@ -305,12 +304,8 @@ extern "C" int vd3d_nms(const float* boxes, const float* scores, int n, float io
         return VD3D_EINVAL;
     }
     const int lds = (int)nms_lds(n);
-    static int attr = 0;
-    if (lds > attr) {
-        if (hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(nms)");
-        attr = lds;
-    }
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)nms_kernel, lds, lim, "hipFuncSetAttribute(nms)")) return rc;
     hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(kNmsThreads), lds, s, boxes, scores, n, iou_thr, keep, count);
     return vd3d_check_launch("nms");
 }

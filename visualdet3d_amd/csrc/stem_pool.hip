@@ -198,15 +198,10 @@ extern "C" int vd3d_stem_conv_pool(const void* packed, const void* weight, const
     if (in_bytes > 0x7ffffff0ll) { vd3d_set_error("stem_conv_pool: packed image exceeds 2 GiB; split the batch"); return VD3D_ERANGE; }
     a.in_bytes = (uint32_t)in_bytes;
     a.ntiles = B * (a.Hq / kTPY) * (a.Wq / kTPX);
-    static int num_cu = 0;
-    if (!num_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return vd3d_check_launch("hipGetDeviceProperties");
-        if (hipFuncSetAttribute((const void*)stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
-            return vd3d_check_launch("hipFuncSetAttribute(stem_pool)");
-        num_cu = prop.multiProcessorCount;
-    }
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)stem_pool_kernel, kLds, lim, "hipFuncSetAttribute(stem_pool)")) return rc;
+    const int num_cu = vd3d_device_cu_count();
+    if (num_cu <= 0) return VD3D_ELAUNCH;
     const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
     hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(512), kLds, (hipStream_t)stream, a);
     return vd3d_check_launch("stem_conv_pool");

@@ -29,7 +29,7 @@ def format_result(scores, bbox_2d, bbox_3d_state_3d=None, thetas=None, obj_types
             b = bbox_2d[i]
             text += ('{} -1 -1 {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {:.6f} {} \n').format(
                 obj_types[i], st[i][-1], b[0], b[1], b[2], b[3], st[i][4], st[i][3], st[i][5], st[i][0], st[i][1], st[i][2],
-                thetas[i], scores[i])
+                thetas[i], float(scores[i]))      # the reference formats a 0-d tensor: python-float repr of the fp32 value
     return text
 
 

@@ -30,9 +30,19 @@ def gather_detections(pack, count, group=None):
     return torch.cat(packs, dim=0), torch.cat(counts, dim=0)
 
 
+def _check_counts(counts):
+    """head_postprocess marks a frame whose candidate / detection list overflowed with a NEGATIVE count; such a frame's rows
+    are undefined.  Same error as AnchorBasedDetection3DHead.unpad."""
+    bad = [i for i, n in enumerate(counts) if n < 0]
+    if bad:
+        raise RuntimeError('frame(s) %s: more candidates than max_candidates (or detections than max_det); raise '
+                           'AnchorBasedDetection3DHead.max_candidates' % bad)
+
+
 def unpack_detections(pack, count):
-    """-> list of per-frame (scores[N], boxes[N,11], labels[N] int64)."""
+    """-> list of per-frame (scores[N], boxes[N,11], labels[N] int64).  Raises on overflow-marked (negative) counts."""
     out = []
+    _check_counts(count.tolist())
     for b, n in enumerate(count.tolist()):
         out.append((pack[b, :n, 0], pack[b, :n, 1:12], pack[b, :n, 12].long()))
     return out
@@ -41,7 +51,9 @@ def unpack_detections(pack, count):
 class DetectionGather:
     """Per-step gather with ONE collective and no allocation: the per-rank pack is [B, k + 1, 13] floats, row k of every frame
     carrying the frame's detection count, all_gather'ed into a preallocated [world, B, k + 1, 13] buffer
-    (``all_gather_into_tensor``; falls back to ``all_gather`` on backends without it, e.g. gloo on CPU)."""
+    (``all_gather_into_tensor`` over RCCL; the list form of ``all_gather`` on backends without the tensor form, i.e. gloo on
+    CPU tensors in the tests).  Which of the two is used is decided ONCE, from the backend, at construction: a collective that
+    fails at run time propagates -- silently switching to a different collective on one rank would mismatch its peers."""
 
     def __init__(self, B, k, device, world=None, group=None):
         self.group = group
@@ -49,6 +61,8 @@ class DetectionGather:
         self.B, self.k = B, k
         self.pack = torch.zeros((B, k + 1, 13), dtype=torch.float32, device=device)
         self.out = torch.zeros((self.world, B, k + 1, 13), dtype=torch.float32, device=device)
+        backend = dist.get_backend(group) if dist.is_initialized() else 'none'
+        self.tensor_collective = (backend == 'nccl')
 
     def fill(self, scores, boxes, labels, count):
         """Copy one step's padded results into the send buffer (stream-ordered; no collective)."""
@@ -62,9 +76,9 @@ class DetectionGather:
     def gather(self):
         """The collective on the current stream; returns the [world, B, k + 1, 13] buffer."""
         p = self.pack
-        try:
+        if self.tensor_collective:
             dist.all_gather_into_tensor(self.out.view(-1), p.view(-1), group=self.group)
-        except (RuntimeError, NotImplementedError):
+        else:
             dist.all_gather(list(self.out.unbind(0)), p, group=self.group)
         return self.out
 
@@ -73,9 +87,12 @@ class DetectionGather:
         return self.gather()
 
     def counts(self):
-        """[world, B] int32 detection counts (clamped to k) of the last gather."""
+        """[world, B] int32 detection counts (clamped to k) of the last gather; negative = overflow marker, kept negative."""
         return torch.clamp(self.out[:, :, self.k, 0].round().to(torch.int32), max=self.k)
 
     def detections(self):
-        """-> ([world*B, k, 13], [world*B] counts) in rank order, like ``gather_detections``."""
-        return self.out[:, :, :self.k].reshape(self.world * self.B, self.k, 13), self.counts().reshape(-1)
+        """-> ([world*B, k, 13], [world*B] counts) in rank order, like ``gather_detections``.  Raises on overflow-marked
+        frames (one host sync for the counts)."""
+        c = self.counts().reshape(-1)
+        _check_counts(c.tolist())
+        return self.out[:, :, :self.k].reshape(self.world * self.B, self.k, 13), c

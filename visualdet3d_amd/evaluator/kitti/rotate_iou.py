@@ -8,7 +8,9 @@ from ...hip_ops import _p, _stream, check
 
 
 def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1):
-    dtype = boxes.dtype
+    # the reference returns float32 whatever the caller passed: `boxes` is re-bound to its float32 copy before
+    # `iou.astype(boxes.dtype)` (rotate_iou.py:307-328)
+    dtype = np.float32
     b = torch.from_numpy(np.ascontiguousarray(boxes, dtype=np.float32)).cuda()
     q = torch.from_numpy(np.ascontiguousarray(query_boxes, dtype=np.float32)).cuda()
     N, K = b.shape[0], q.shape[0]

@@ -459,8 +459,9 @@ def deform_conv_general(x, pd, offset, mask, out, layout, bias=None, scale=None,
     return out
 
 
-def deform_conv_forward_nchw(x, weight, bias, offset, mask, stride, padding, dilation, groups, deformable_groups):
-    """The reference extension's call (NCHW fp32 contiguous tensors) through vd3d_deform_conv_forward."""
+def deform_conv_forward_nchw(x, weight, bias, offset, mask, stride, padding, dilation, groups, deformable_groups, out=None):
+    """The reference extension's call (NCHW fp32 contiguous tensors) through vd3d_deform_conv_forward.  ``out``: optional
+    preallocated contiguous fp32 [B,O,Ho,Wo] written in place (the pybind surface's ``output`` argument)."""
     _require_cuda(x, weight, offset)
     x, weight, offset = x.float().contiguous(), weight.float().contiguous(), offset.float().contiguous()
     mask = mask.float().contiguous() if mask is not None else None
@@ -470,7 +471,9 @@ def deform_conv_forward_nchw(x, weight, bias, offset, mask, stride, padding, dil
     Ho = (H + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
     Wo = (W + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
     assert offset.shape == (B, deformable_groups * 2 * kh * kw, Ho, Wo), (offset.shape, (B, deformable_groups * 2 * kh * kw, Ho, Wo))
-    out = torch.empty((B, O, Ho, Wo), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((B, O, Ho, Wo), dtype=torch.float32, device=x.device)
+    assert out.shape == (B, O, Ho, Wo) and out.dtype == torch.float32 and out.is_contiguous() and out.is_cuda
     ws = torch.empty(_lib.lib().vd3d_deform_conv_workspace_bytes(O, Cc, groups, kh, kw), dtype=torch.uint8, device=x.device)
     check(_lib.lib().vd3d_deform_conv_forward(_p(x), _p(weight), _p(bias), _p(offset), _p(mask), _p(out), _p(ws), B, Cc, H, W, O, kh, kw,
                                               stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],

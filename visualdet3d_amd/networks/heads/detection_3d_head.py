@@ -152,14 +152,21 @@ class AnchorBasedDetection3DHead(nn.Module):
         return is_filtering
 
     def get_anchor(self, img_batch, P2):
+        self._last_img_hw = (int(img_batch.shape[2]), int(img_batch.shape[3]))
         anchors, useful_mask, anchor_mean_std = self.anchors(img_batch, P2, is_filtering=self._is_filtering())
         return dict(anchors=anchors, mask=useful_mask, anchor_mean_std_3d=anchor_mean_std)
 
     # ---- post-processing ------------------------------------------------------------------------------------
-    def get_bboxes_batched(self, cls_preds, reg_preds, P2s, img_hw):
+    def get_bboxes_batched(self, cls_preds, reg_preds, P2s, img_hw, clip=True):
         """Device-side ``get_bboxes`` for B samples.  Returns padded device tensors
-        (scores [B,K], boxes [B,K,11], labels [B,K] int32, anchor_idx [B,K] int32, count [B] int32); no host sync."""
+        (scores [B,K], boxes [B,K,11], labels [B,K] int32, anchor_idx [B,K] int32, count [B] int32); no host sync.
+        ``clip=False``: skip ClipBoxes (the reference's ``img_batch is None``, detection_3d_head.py:375-376)."""
+        if not getattr(self.test_cfg, 'cls_agnositc', True):     # (sic) the reference's key, detection_3d_head.py:381
+            # the reference's per-class NMS branch cannot run either (`label.float().unsqueeze()` without a dim, :388-389)
+            raise NotImplementedError('test_cfg.cls_agnositc=False (per-class NMS) is not implemented: the reference branch '
+                                      'itself raises TypeError (detection_3d_head.py:388); only class-agnostic NMS is on the path')
         dev = cls_preds.device
+        self._last_img_hw = (int(img_hw[0]), int(img_hw[1]))
         anchors, prior, A = self.anchors.device_tables(img_hw, dev)
         B = cls_preds.shape[0]
         need = ops._lib.lib().vd3d_head_workspace_bytes(B, self.max_candidates)
@@ -168,7 +175,7 @@ class AnchorBasedDetection3DHead(nn.Module):
         lo, hi = self.anchors.filter_y_threshold_min_max
         P2s = P2s.to(dev)
         padded = ops.head_postprocess(
-            cls_preds, reg_preds, anchors, prior, P2s, A, self.num_classes, len(self.anchors.obj_types), img_hw,
+            cls_preds, reg_preds, anchors, prior, P2s, A, self.num_classes, len(self.anchors.obj_types), img_hw if clip else (0, 0),
             getattr(self.test_cfg, 'score_thr', 0.5), getattr(self.test_cfg, 'nms_iou_thr', 0.5),
             use_filter=bool(self._is_filtering() and self.anchors.readConfigFile), y_min_max=(lo, hi),
             x_max=self.anchors.filter_x_threshold, max_cand=self.max_candidates, workspace=self._workspace)
@@ -192,11 +199,24 @@ class AnchorBasedDetection3DHead(nn.Module):
         return outs
 
     def get_bboxes(self, cls_scores, reg_preds, anchors, P2s, img_batch=None):
-        """Reference signature (batch 1).  ``anchors`` (the get_anchor dict) is accepted for compatibility; the device
-        kernel uses the cached tables for ``img_batch``'s shape."""
+        """Reference signature (batch 1, detection_3d_head.py:341).  Limits relative to the reference, all explicit:
+          * ``anchors`` (the ``get_anchor`` dict) is accepted for compatibility but NOT read: the kernel uses the cached anchor /
+            prior tables of the image shape and evaluates the ground filter from ``P2s`` itself, so a caller-modified
+            ``anchors['mask']`` has no effect (the reference's only caller passes ``get_anchor``'s output unchanged);
+          * ``img_batch=None`` skips ClipBoxes like the reference; the image shape (needed for the anchor grid) is then the one
+            of the last ``get_anchor`` / ``get_bboxes`` call;
+          * ``test_cfg.cls_agnositc=False`` raises NotImplementedError (see get_bboxes_batched);
+          * single pyramid level (every shipped config uses ``pyramid_levels=[4]``; ``Anchors.device_tables`` asserts it)."""
         assert cls_scores.shape[0] == 1
-        assert img_batch is not None, 'image batch (for its H, W) is required'
-        padded = self.get_bboxes_batched(cls_scores.float().contiguous(), reg_preds.float().contiguous(), P2s, img_batch.shape[2:])
+        if img_batch is not None:
+            img_hw = img_batch.shape[2:]
+        else:
+            img_hw = getattr(self, '_last_img_hw', None)
+            if img_hw is None:
+                raise RuntimeError('get_bboxes(img_batch=None): image shape unknown -- call get_anchor(img_batch, P2) first '
+                                   '(the reference flow, yolostereo3d_detector.py:90-93)')
+        padded = self.get_bboxes_batched(cls_scores.float().contiguous(), reg_preds.float().contiguous(), P2s, img_hw,
+                                         clip=img_batch is not None)
         return self.unpad(padded)[0]
 
     def _post_process(self, scores, bboxes, labels, P2s):

@@ -16,6 +16,7 @@ from torch.nn.modules.utils import _pair, _single
 
 from ..... import hip_ops as ops
 from ... import fused
+from . import deform_conv_ext
 
 
 def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1, im2col_step=64):
@@ -23,17 +24,40 @@ def deform_conv(input, offset, weight, stride=1, padding=0, dilation=1, groups=1
         raise ValueError('Expected 4D tensor as input, got {}D tensor instead.'.format(input.dim()))
     if not input.is_cuda:
         raise NotImplementedError
+    stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
     cur = min(im2col_step, input.shape[0])
     assert (input.shape[0] % cur) == 0, 'im2col step must divide batchsize'
-    return ops.deform_conv_forward_nchw(input, weight, None, offset, None, _pair(stride), _pair(padding), _pair(dilation),
-                                        groups, deformable_groups)
+    # same call as DeformConvFunction.forward (deform_conv.py:78-95): caller-allocated output, two empty scratch tensors,
+    # W-before-H argument order
+    B, _, H, W = input.shape
+    O, _, kh, kw = weight.shape
+    Ho = (H + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
+    output = input.new_empty((B, O, Ho, Wo))
+    bufs = [input.new_empty(0), input.new_empty(0)]
+    deform_conv_ext.deform_conv_forward(input, weight, offset, output, bufs[0], bufs[1], weight.size(3), weight.size(2), stride[1], stride[0],
+                                        padding[1], padding[0], dilation[1], dilation[0], groups, deformable_groups, cur)
+    return output
 
 
 def modulated_deform_conv(input, offset, mask, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
     if not input.is_cuda:
         raise NotImplementedError
-    return ops.deform_conv_forward_nchw(input, weight, bias, offset, mask, _pair(stride), _pair(padding), _pair(dilation),
-                                        groups, deformable_groups)
+    # same call as ModulatedDeformConvFunction.forward (deform_conv.py:170-186); like the reference the module-level API takes
+    # scalar stride / padding / dilation
+    with_bias = bias is not None
+    if not with_bias:
+        bias = input.new_empty(1)  # fake tensor
+    sh, sw = _pair(stride)
+    ph, pw = _pair(padding)
+    dh, dw = _pair(dilation)
+    B, _, H, W = input.shape
+    O, _, kh, kw = weight.shape
+    output = input.new_empty((B, O, (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1, (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1))
+    bufs = [input.new_empty(0), input.new_empty(0)]
+    deform_conv_ext.modulated_deform_conv_forward(input, weight, bias, bufs[0], offset, mask, output, bufs[1], kh, kw, sh, sw, ph, pw, dh, dw,
+                                                  groups, deformable_groups, with_bias)
+    return output
 
 
 class DeformConv(nn.Module):

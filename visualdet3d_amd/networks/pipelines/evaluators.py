@@ -39,7 +39,13 @@ def test_one(cfg, index, dataset, model, test_func, backprojector=None, projecto
     collated = dataset.collate_fn([data])
     scores, bbox, obj_names = test_func(collated, model, None, cfg=cfg)
     n = len(scores)
+    if n == 0:
+        # no detection in this frame: the reference still writes an (empty) result file and carries on (evaluators.py:112-129
+        # run on empty tensors; data/kitti/utils.py:186 `if len(scores) > 0`)
+        write_result_to_file(result_path, index, [], np.zeros((0, 4), np.float32), np.zeros((0, 7), np.float32), np.zeros((0,), np.float32),
+                             obj_names, bottom_center_done=True)
+        return
     counts = torch.tensor([n], dtype=torch.int32, device=bbox.device)
-    (s, rows), = postprocess_batch(scores.reshape(1, n), bbox.reshape(1, n, -1)[..., :11].contiguous(), counts,
+    (s, rows), = postprocess_batch(scores.reshape(1, n), bbox[:, :11].reshape(1, n, 11).contiguous(), counts,
                                    np.asarray(P2)[None], [data['original_P']])
     write_result_to_file(result_path, index, s, rows[:, 0:4], rows[:, 4:11], rows[:, 11], obj_names, bottom_center_done=True)
