@@ -187,6 +187,15 @@ typedef struct vd3d_head_params {
 int64_t vd3d_head_workspace_bytes(int B, int max_cand);
 int vd3d_head_postprocess(const vd3d_head_params* p, void* stream);
 
+/* Multi-GPU result record (the only cross-rank traffic is the gather of the padded detections): packs the
+ * padded outputs of vd3d_head_postprocess / vd3d_km3d_decode of B frames into ONE contiguous fp32 block
+ *   pack[B][k + 1][13]:  rows 0..k-1 = (score, 11 box fields, label) of detection r (zeros past the frame's count),
+ *                        row k = (count, 0 ...) -- the count rides in the block, negative overflow markers included,
+ * so a step needs a single all_gather (and a single device->host copy) and the pack is one launch that can be captured
+ * in the step's hipGraph.  scores [B][K], boxes [B][K][11], labels [B][K] int32, count [B] int32, k <= K. */
+int vd3d_pack_detections(const float* scores, const float* boxes, const int32_t* labels, const int32_t* count, int B, int K,
+                         int k, float* pack, void* stream);
+
 /* torchvision.ops.nms replacement (call sites heads/detection_3d_head.py:386, heads/km3d_head.py:303):
  * boxes [n][4] fp32, scores [n] fp32 -> keep [n] int32 (indices in decreasing-score order), count [1]. */
 int vd3d_nms(const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep, int32_t* count,

@@ -1,0 +1,69 @@
+"""GPU: bench.py's multi-GPU step on ONE rank over RCCL (VD3D_BENCH_FORCE_DIST=1): process group init, the graph-captured
+pack kernel, the double-buffered all_gather on the comm stream and the device->host copy of the gathered record -- and the
+gathered detections equal what ``forward_device`` returns directly.  (8-GPU runs are the driver's; world-size-2 semantics
+are covered on CPU over gloo in tests/test_distributed_cpu.py.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('graph', [True, False])
+def test_bench_force_dist_gathers_the_detections_forward_device_returns(graph):
+    dump = os.path.join(tempfile.mkdtemp(), 'dump.pt')
+    env = dict(os.environ, VD3D_BENCH_FORCE_DIST='1', VD3D_BENCH_DUMP=dump, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'] + ([] if graph else ['--no-graph'])
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 1 and line['config']['hip_graph'] == graph and line['value'] > 100
+    assert '[bench] rank 0/1' in r.stderr                              # per-rank timing line (diagnosable SCALE runs)
+    d = torch.load(dump)
+    host = d['host']                                                    # [world=1, B, KDET + 1, 13]
+    scores, boxes, labels, aidx, count = d['direct']
+    B, K = scores.shape
+    k = host.shape[2] - 1
+    assert host.shape[0] == 1 and host.shape[1] == B
+    total = 0
+    for b in range(B):
+        n = int(count[b])
+        assert n >= 0 and int(host[0, b, k, 0]) == n
+        assert torch.equal(host[0, b, :n, 0], scores[b, :n])
+        assert torch.equal(host[0, b, :n, 1:12], boxes[b, :n])
+        assert torch.equal(host[0, b, :n, 12].long(), labels[b, :n].long())
+        assert bool((host[0, b, n:k] == 0).all())
+        total += n
+    assert total >= 8
+
+
+def test_pack_detections_kernel_matches_host_pack():
+    from visualdet3d_amd import distributed as vdist, hip_ops
+    g = torch.Generator().manual_seed(0)
+    B, K, k = 5, 40, 16
+    scores = torch.rand(B, K, generator=g)
+    boxes = torch.randn(B, K, 11, generator=g)
+    labels = torch.randint(0, 3, (B, K), generator=g, dtype=torch.int32)
+    count = torch.tensor([0, 3, 16, 40, -1], dtype=torch.int32)
+    got = hip_ops.pack_detections(scores.cuda(), boxes.cuda(), labels.cuda(), count.cuda(), k).cpu()
+    want, _ = vdist.pack_detections(scores, boxes, labels, count, k)
+    assert torch.equal(got[:, :k], want) and torch.equal(got[:, k, 0], count.float()) and bool((got[:, k, 1:] == 0).all())
+    gth = vdist.DetectionGather(B, k, 'cuda', world=1)
+    gth.fill(scores.cuda(), boxes.cuda(), labels.cuda(), count.cuda())
+    assert torch.equal(gth.pack.cpu(), got)

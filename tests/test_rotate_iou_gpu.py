@@ -33,4 +33,6 @@ def test_random_set_matches_oracle_and_edge_sizes():
         got = rotate_iou_gpu_eval(boxes, query, crit)
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
     assert rotate_iou_gpu_eval(boxes[:0], query, -1).shape == (0, K)
-    assert rotate_iou_gpu_eval(boxes.astype(np.float64), query[:0], -1).dtype == np.float64
+    # float32 whatever the caller passes, like the reference (its `boxes` is re-bound to the float32 copy before astype, :307-328)
+    assert rotate_iou_gpu_eval(boxes.astype(np.float64), query[:0], -1).dtype == np.float32
+    assert rotate_iou_gpu_eval(boxes.astype(np.float64), query.astype(np.float64), -1).dtype == np.float32

@@ -169,27 +169,44 @@ def test_config2_batch8_bf16_detection_level_acceptance():
     assert e_cls < 3e-2 and e_reg < 3e-2
     # (c) detection set by anchor index, margin = observed score difference
     margin = max(2.0 * d_score, 1e-3)
-    worst = 0.0
-    unmatched = 0
+
+    def iou(a, b):
+        x1, y1, x2, y2 = max(a[0], b[0]), max(a[1], b[1]), min(a[2], b[2]), min(a[3], b[3])
+        inter = max(0.0, x2 - x1) * max(0.0, y2 - y1)
+        return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
+
+    worst, unmatched, unexplained, n_ref = 0.0, 0, 0, 0
     for b in range(B):
         k = int(count[b])
+        s_o, b_o, l_o = ref[b][0], ref[b][1], ref[b][2]
+        i_o = orc.get_bboxes(st['cls_preds'][b], st['reg_preds'][b], st['anchors'], st['mean_std'], st['mask'][b], (H, W), 2, thr, iou_thr)[3]
+        n_ref += len(s_o)
         got = {int(a): j for j, a in enumerate(aidx[b, :k].tolist())}
-        s_o, b_o, l_o, i_o = ref[b][0], ref[b][1], ref[b][2], orc.get_bboxes(
-            st['cls_preds'][b], st['reg_preds'][b], st['anchors'], st['mean_std'], st['mask'][b], (H, W), 2, thr, iou_thr)[3]
         want = {int(a): j for j, a in enumerate(i_o.tolist())}
+        scale = b_o.abs().amax(dim=0).clamp_min(1.0) if len(b_o) else 1.0
         for a, j in want.items():
             if a in got:
                 gj = got[a]
-                scale = b_o.abs().amax(dim=0).clamp_min(1.0)
                 worst = max(worst, float(((boxes[b, gj] - b_o[j]).abs() / scale).max()), abs(float(scores[b, gj] - s_o[j])))
                 assert int(labels[b, gj]) == int(l_o[j])
-            elif float(s_o[j]) > thr + margin:
+        # A detection kept on one side only is legitimate iff (i) its score sits within the margin of the threshold, or (ii) on
+        # the other side it was suppressed by a kept box: greedy NMS keeps the better-scored of two overlapping candidates, so
+        # a near-tie (|score difference| < margin) may swap which of them represents the object -- and what the winner then
+        # suppresses.  Anything else is a real disagreement.
+        for (mine, theirs, sc_m, bx_m, sc_t, bx_t) in ((want, got, s_o, b_o, scores[b], boxes[b]), (got, want, scores[b], boxes[b], s_o, b_o)):
+            for a, j in mine.items():
+                if a in theirs:
+                    continue
                 unmatched += 1
-        for a, gj in got.items():
-            if a not in want and float(scores[b, gj]) > thr + margin:
-                unmatched += 1
-    print('[C2 B=8 bf16] matched-by-anchor worst field/score difference %.3e (margin %.3e), clear-margin unmatched %d' % (worst, margin, unmatched))
-    # an unmatched clear-margin detection can only come from an NMS decision that flipped (IoU within the box difference of
-    # the threshold); allow at most 2 % of the detections for that
-    assert unmatched <= max(1, n_det // 50), unmatched
-    assert worst < 3e-2, worst
+                if float(sc_m[j]) <= thr + margin:
+                    continue
+                if not any(iou(bx_m[j, :4].tolist(), bx_t[t, :4].tolist()) > iou_thr - 0.02 and float(sc_t[t]) >= float(sc_m[j]) - margin
+                           for t in theirs.values()):
+                    unexplained += 1
+    print('[C2 B=8 bf16] oracle %d / HIP %d detections; matched-by-anchor worst field/score difference %.3e (margin %.3e); '
+          'one-sided %d, of which unexplained by threshold / NMS near-ties %d' % (n_ref, n_det, worst, margin, unmatched, unexplained))
+    assert unexplained == 0
+    assert unmatched <= max(2, n_det // 8), unmatched
+    # matched boxes: within what the logit difference explains (measured 5e-3 at 7.9e-3 logit difference; 1e-3 is met by the
+    # fp32 mode and per layer, not by two independent bf16 evaluations of a 60-layer network)
+    assert worst < 1.5e-2, worst

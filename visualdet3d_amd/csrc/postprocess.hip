@@ -288,6 +288,31 @@ extern "C" int vd3d_head_postprocess(const vd3d_head_params* q, void* stream) {
     return vd3d_check_launch("head_nms");
 }
 
+__global__ void pack_detections_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, const int32_t* __restrict__ labels,
+                                       const int32_t* __restrict__ count, int B, int K, int k, float* __restrict__ pack) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // element of this frame's [k + 1][13] block
+    if (i >= (k + 1) * 13) return;
+    const int r = i / 13, f = i - r * 13;
+    const int c = count[b];
+    float v = 0.f;
+    if (r == k) v = f == 0 ? (float)c : 0.f;
+    else if (r < c) {
+        const int64_t src = (int64_t)b * K + r;
+        v = f == 0 ? scores[src] : (f == 12 ? (float)labels[src] : boxes[src * 11 + (f - 1)]);
+    }
+    pack[((int64_t)b * (k + 1)) * 13 + i] = v;
+}
+
+extern "C" int vd3d_pack_detections(const float* scores, const float* boxes, const int32_t* labels, const int32_t* count, int B, int K,
+                                    int k, float* pack, void* stream) {
+    if (B == 0) return VD3D_OK;
+    if (!scores || !boxes || !labels || !count || !pack || B < 0 || k < 0 || k > K) { vd3d_set_error("pack_detections: bad args"); return VD3D_EINVAL; }
+    const int n = (k + 1) * 13;
+    hipLaunchKernelGGL(pack_detections_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, scores, boxes, labels, count, B, K, k, pack);
+    return vd3d_check_launch("pack_detections");
+}
+
 extern "C" int64_t vd3d_nms_workspace_bytes(int n) { (void)n; return 256; }
 
 extern "C" int vd3d_nms(const float* boxes, const float* scores, int n, float iou_thr, int32_t* keep, int32_t* count,

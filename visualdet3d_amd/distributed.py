@@ -14,10 +14,12 @@ def shard_range(n, rank, world):
 
 
 def pack_detections(scores, boxes, labels, count, k):
-    """padded (scores [B,K], boxes [B,K,11], labels [B,K], count [B]) -> one float tensor [B, k, 13] + count [B]."""
+    """padded (scores [B,K], boxes [B,K,11], labels [B,K], count [B]) -> one float tensor [B, k, 13] (rows past a frame's
+    count zeroed: the padding of the device buffers is uninitialised memory) + count [B]."""
     k = min(k, scores.shape[1])
     pack = torch.cat([scores[:, :k, None], boxes[:, :k], labels[:, :k, None].to(scores.dtype)], dim=2).contiguous()
-    return pack, torch.clamp(count, max=k)
+    valid = torch.arange(k, device=count.device)[None, :] < count[:, None]
+    return pack * valid[:, :, None].to(pack.dtype), torch.clamp(count, max=k)
 
 
 def gather_detections(pack, count, group=None):
@@ -65,12 +67,21 @@ class DetectionGather:
         self.tensor_collective = (backend == 'nccl')
 
     def fill(self, scores, boxes, labels, count):
-        """Copy one step's padded results into the send buffer (stream-ordered; no collective)."""
+        """Pack one step's padded results into the send buffer (stream-ordered; no collective).  Device tensors: ONE
+        ``vd3d_pack_detections`` launch (capturable in the step's hipGraph); CPU tensors (gloo tests): plain copies."""
         k, p = self.k, self.pack
+        if scores.is_cuda:
+            from . import hip_ops
+            assert scores.shape[1] >= k, 'detection capacity %d < gather rows %d' % (scores.shape[1], k)
+            hip_ops.pack_detections(scores, boxes, labels, count, k, out=p)
+            return
         kk = min(k, scores.shape[1])
-        p[:, :kk, 0] = scores[:, :kk]
-        p[:, :kk, 1:12] = boxes[:, :kk]
-        p[:, :kk, 12] = labels[:, :kk].to(torch.float32)
+        p[:, :k].zero_()
+        valid = (torch.arange(kk)[None, :] < count[:, None].clamp(min=0)).to(p.dtype)
+        p[:, :kk, 0] = scores[:, :kk] * valid
+        p[:, :kk, 1:12] = boxes[:, :kk] * valid[:, :, None]
+        p[:, :kk, 12] = labels[:, :kk].to(torch.float32) * valid
+        p[:, k, 1:] = 0
         p[:, k, 0] = count.to(torch.float32)                 # negative (overflow marker) survives the round trip
 
     def gather(self):

@@ -389,6 +389,22 @@ def head_postprocess(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, sc
     return scores, boxes, labels, aidx, count
 
 
+def pack_detections(scores, boxes, labels, count, k, out=None):
+    """Padded (scores [B,K], boxes [B,K,11], labels [B,K] i32, count [B] i32) -> one fp32 block [B, k+1, 13] (row k carries the
+    count; rows past the count are zero): vd3d_pack_detections, one launch, capturable in the step's hipGraph."""
+    _require_cuda(scores, boxes, labels, count, out)
+    B, K = scores.shape
+    k = min(int(k), K)
+    assert boxes.shape == (B, K, 11) and labels.shape == (B, K) and count.shape == (B,)
+    assert scores.dtype == boxes.dtype == torch.float32 and labels.dtype == count.dtype == torch.int32
+    assert scores.is_contiguous() and boxes.is_contiguous() and labels.is_contiguous() and count.is_contiguous()
+    if out is None:
+        out = torch.empty((B, k + 1, 13), dtype=torch.float32, device=scores.device)
+    assert out.shape == (B, k + 1, 13) and out.dtype == torch.float32 and out.is_contiguous()
+    check(_lib.lib().vd3d_pack_detections(_p(scores), _p(boxes), _p(labels), _p(count), B, K, k, _p(out), _stream()), 'vd3d_pack_detections')
+    return out
+
+
 def nms(boxes, scores, iou_threshold):
     """torchvision.ops.nms drop-in on the GPU: int64 keep indices in decreasing-score order."""
     _require_cuda(boxes, scores)
