@@ -66,6 +66,13 @@ typedef struct vd3d_conv_params {
     int32_t relu;          /* 1: ReLU epilogue                                                         */
     int32_t dtype;         /* VD3D_BF16 | VD3D_F32: element type of in / weight / residual             */
     int32_t out_f32;       /* 1: write `out` as fp32 even when dtype is bf16 (final head convs)        */
+    /* ABI >= 2.  Optional second copy of the SAME weights as an MFMA register image, used by the kernels that keep their
+     * weights resident in registers (3x3 / stride 1 / pad 1, bf16, Cin = 64 | 128 | 256, Cout % 32 == 0); NULL: those
+     * kernels are not selected.  Layout: [Cout/32][Cin/64][36][64 lanes][8 elements]: block (nb, kc, f = tap*4 + ks) is the
+     * 1 KiB A-operand fragment of output channels 32*nb .. +31 for k = tap*Cin + 64*kc + 16*ks .. +15: lane l holds channel
+     * 32*nb + (l & 31), k = tap*Cin + 64*kc + (2*ks + (l >> 5))*8 .. +7 -- so the once-per-launch weight load of a wave is 36
+     * (or 72) fully coalesced 1 KiB reads instead of 64 scattered 16-byte reads per instruction. */
+    const void* weight_frag;
 } vd3d_conv_params;
 
 int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream);

@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79}            # 16x16x32 bf16 MFMA tiles
+BF16_TILES = {50, 54, 76, 79, 61}        # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 87, 30, 21, 23, 27]
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 87, 30, 21, 23, 27, 61]
 
 
 class forced_tile:
@@ -92,6 +92,15 @@ def run_case(B, H, W, Cin, Cout, k=3, stride=1, pad=1, dil=1, residual=False, re
 
 def _shapes_for(cfg):
     """Small shapes that are awkward for tile `cfg` (B, H, W, Cin, Cout, kwargs)."""
+    if cfg == 61:       # register-resident weights: Cin 128 (128-channel slices) | 256 (64-channel slices, K halves added in LDS)
+        return [
+            (1, 11, 37, 128, 128, dict(residual=True)),                 # ragged tile grid, fewer tiles than CUs
+            (2, 8, 16, 256, 64, dict(residual=False, relu=False)),      # one tile per image, one slice
+            (1, 17, 50, 256, 192, dict(residual=True, in_extra=64, out_extra=64)),    # 3 slices, channel-slice views
+            (3, 40, 72, 128, 256, dict(residual=True, bn=False)),       # 2 slices, several tiles per workgroup lane
+            (16, 24, 80, 256, 256, dict(residual=True)),                # layer3 at the bench shape: 4 slices, 3.75 rounds
+            (2, 48, 160, 128, 128, dict(residual=False)),               # many tiles per workgroup (steady-state vmcnt path)
+        ]
     if cfg in HALO_TILES:
         return [
             (1, 11, 37, 64, 136, dict(residual=True)),                 # ragged patch grid, partial N tile

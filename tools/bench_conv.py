@@ -27,6 +27,8 @@ cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
 
 
 def skip(c, Cout):
+    if c == 61:
+        return False
     return (Cout <= 64 and 1 <= c < 30) or (Cout <= 64 and c >= 36 and c not in (60, 84, 85, 86, 87)) or (Cout > 64 and c in (20, 26, 28, 30, 31, 32, 34, 35)) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 40)
 
 import os
@@ -55,7 +57,7 @@ for name, B, H, W, Cin, Cout in SHAPES:
         if ref is None:
             ref = out.float()
         err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
-        if err >= 2e-2 and not (90 <= c < 100):      # 9x: timing ablations, results are wrong by construction
+        if err >= 2e-2 and not (90 <= c < 100 or c in (63, 64, 65)) or err != err and not (c in (63, 64, 65)):      # 9x, 63-65: timing ablations, results are wrong by construction
             best[c] = 'BAD(%.1e)' % err
             continue
         ok_cfgs.append(c)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libvd3d_hip_tuning.so' if os.environ.get('VD3D_T
 
 VD3D_BF16 = 0
 VD3D_F32 = 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -27,6 +27,7 @@ class ConvParams(C.Structure):
         ('out_pix_stride', C.c_int32), ('res_pix_stride', C.c_int32),
         ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32), ('dil', C.c_int32),
         ('Kpad', C.c_int32), ('CoutPad', C.c_int32), ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32),
+        ('weight_frag', c_void_p),
     ]
 
 

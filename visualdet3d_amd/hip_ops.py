@@ -65,6 +65,7 @@ class PackedConv:
         self.Cin, self.Cout, self.kh, self.kw = Cin, Cout, kh, kw
         self.stride, self.pad, self.dil = stride, pad, dil
         self.Kpad, self.CoutPad, self.dtype = Kpad, CoutPad, dtype
+        self.w_frag = None      # optional MFMA register image of the same weights (vd3d_conv_params.weight_frag)
 
 
 def fold_bn(bias, bn, cout, device):
@@ -96,7 +97,13 @@ def pack_conv(weight, bias=None, bn=None, dtype=torch.bfloat16, stride=1, pad=0,
     packed = torch.zeros((CoutPad, Kpad), dtype=dtype, device=dev)
     packed[:O, :K] = w.reshape(O, K).to(dtype)
     scale, shift = fold_bn(bias, bn, O, dev)
-    return PackedConv(packed, scale, shift, Cin, O, kh, kw, stride, pad, dil, Kpad, CoutPad, dtype)
+    pc = PackedConv(packed, scale, shift, Cin, O, kh, kw, stride, pad, dil, Kpad, CoutPad, dtype)
+    if dtype == torch.bfloat16 and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and Cin in (64, 128, 256) and O % 32 == 0:
+        # register image for the resident-weight kernels (layout: include/vd3d.h, vd3d_conv_params.weight_frag):
+        # [O/32][Cin/64][tap*4 + ks][half*32 + lr][8]  <-  w[32*nb + lr][tap][64*kc + (2*ks + half)*8 + e]
+        w7 = w.reshape(O // 32, 32, 9, Cin // 64, 4, 2, 8)                 # nb, lr, tap, kc, ks, half, e
+        pc.w_frag = w7.permute(0, 3, 2, 4, 5, 1, 6).contiguous().to(dtype)
+    return pc
 
 
 def pack_stem_conv(weight, bn, dtype):
@@ -162,6 +169,7 @@ def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
     p.kh, p.kw, p.stride, p.pad, p.dil = pc.kh, pc.kw, pc.stride, pc.pad, pc.dil
     p.Kpad, p.CoutPad, p.relu = pc.Kpad, pc.CoutPad, int(relu)
     p.dtype, p.out_f32 = dtype_code(x.dtype), int(out_f32)
+    p.weight_frag = pc.w_frag.data_ptr() if pc.w_frag is not None else None
     check(_lib.lib().vd3d_conv2d_igemm(C.byref(p), _stream()), 'vd3d_conv2d_igemm')
     return out
 
