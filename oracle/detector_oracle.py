@@ -449,7 +449,11 @@ def dcn_bn_relu(c, p, x):
     y = dcn_ref.deform_conv_forward(x, torch.cat((o1, o2), 1), torch.sigmoid(mask), c.sd[q + '.weight'], c.sd[q + '.bias'],
                                     1, 1, 1, 1, 1, rnd=(c.rnd if c.rnd is not identity else None))
     s, t = c.bn(p + '.actf.0')
-    return c.rnd(F.relu(_affine(y, s, t)))
+    out = c.rnd(F.relu(_affine(y, s, t)))
+    taps = getattr(c, 'taps', None)
+    if taps is not None:              # stage taps for teacher-forced per-layer parity (tests/test_km3d_gpu.py)
+        taps[p] = (x, out)
+    return out
 
 
 def ida_up(c, p, layers, startp, endp, up_f):
@@ -605,9 +609,12 @@ def km3d_get_bboxes(out, P2, img_hw, score_thr=0.3, nms_iou_thr=0.5, K=100, cons
     return res
 
 
-def km3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False):
-    """KM3D.test_forward (detectors/KM3D.py:61-79) with the DLA-34 + DLA-Up core, B >= 1."""
+def km3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False, taps=None):
+    """KM3D.test_forward (detectors/KM3D.py:61-79) with the DLA-34 + DLA-Up core, B >= 1.  ``taps``: optional dict that
+    receives (input, output) of every DCNv2 + BN + ReLU block of the up-path, keyed by its state_dict prefix."""
     c = Ctx(sd, rnd)
+    if taps is not None:
+        c.taps = taps
     levels = dla34(c, 'core.backbone', img.float())
     feat = dla_seg_upsample(c, 'core.deconv_layers', levels)
     heads = list(cfg.head.layer_cfg.head_dict.keys())

@@ -29,6 +29,9 @@ STEREO_CASES = {
     'stereo3d_r34_384x1280': dict(depth=34, H=384, W=1280, frames=2, wseed=1, iseed=0, score_thr=0.75, head_std=0.00042),
     'stereo3d_r50_96x320': dict(depth=50, H=96, W=320, frames=1, wseed=5, iseed=8, score_thr=0.5, head_std=0.006),
     'stereo3d_r34_384x1280_thr06': dict(depth=34, H=384, W=1280, frames=1, wseed=2, iseed=5, score_thr=0.6, head_std=0.009),
+    # BASELINE config 3 as specified: ResNet-50 stereo core + the BASE (DCNv2) head, 288 x 1280 (Stereo3D with
+    # build_head overridden to AnchorBasedDetection3DHead); the reference's CUDA-only DCN is served by oracle/dcn_ref.py
+    'stereo3d_r50_dcn_288x1280': dict(depth=50, H=288, W=1280, frames=1, wseed=6, iseed=9, score_thr=0.5, head_std=0.006, dcn_head=True),
 }
 
 
@@ -36,7 +39,18 @@ def build_reference_stereo(case, tmp):
     DD = ref_shim.detector_dict()
     cfg = syn.stereo3d_cfg(tmp, depth=case['depth'], score_thr=case['score_thr'])
     syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
-    model = DD['Stereo3D'](cfg).eval()
+    cls = DD['Stereo3D']
+    if case.get('dcn_head'):
+        import visualDet3D.networks.lib.ops.dcn.deform_conv as ref_dcn
+        from visualDet3D.networks.heads.detection_3d_head import AnchorBasedDetection3DHead as RefBaseHead
+        from oracle import dcn_ref
+        ref_dcn.modulated_deform_conv = lambda x, off, m, w, b, s, p, d, g, dg: dcn_ref.deform_conv_forward(x, off, m, w, b, s, p, d, g, dg)
+
+        class Stereo3DBaseHead(cls):          # yolostereo3d_detector.py:35-38 overridden, nothing else
+            def build_head(self, network_cfg):
+                self.bbox_head = RefBaseHead(**(network_cfg.head))
+        cls = Stereo3DBaseHead
+    model = cls(cfg).eval()
     sd = syn.seeded_state_dict(model.state_dict(), seed=case['wseed'], head_std=case['head_std'])
     model.load_state_dict(sd)
     return model, cfg, sd
@@ -131,6 +145,7 @@ def run_mono_case(name, case):
 KM3D_CASES = {
     'km3d_dla34_96x320': dict(H=96, W=320, frames=2, wseed=7, iseed=11, score_thr=0.3),
     'km3d_dla34_192x640': dict(H=192, W=640, frames=1, wseed=7, iseed=12, score_thr=0.3),
+    'km3d_dla34_512x1760': dict(H=512, W=1760, frames=1, wseed=7, iseed=13, score_thr=0.3),      # BASELINE config 5 at size
 }
 
 

@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79, 61}        # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 76, 79, 73, 61}       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 87, 30, 21, 23, 27, 61]
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61]
 
 
 class forced_tile:
@@ -167,6 +167,8 @@ BENCH_SHAPES = [
     ('layer2.0 64->128 s2', 16, 96, 320, 64, 128, dict(stride=2)),                  # 128x128
     ('layer3.0 128->256 s2', 16, 48, 160, 128, 256, dict(stride=2)),
     ('ghost 384->384', 8, 24, 80, 384, 384, dict()),
+    ('neck 288->288 + res', 8, 24, 80, 288, 288, dict(residual=True)),              # 128x144 16x16x32
+    ('cls 256->256', 8, 24, 80, 256, 256, dict(bn=False)),                          # register-resident weights, 4 slices
     ('r50 head 2176->2176', 16, 18, 80, 2176, 2176, dict(residual=True)),           # 256x272 16x16x32 strips
 ]
 

@@ -17,6 +17,8 @@ CONFIGS = {
     'C1 GroundAwareYolo3D R34 384x1280 B=16': dict(kind='mono', name='GroundAwareYolo3D', depth=34, H=384, W=1280, B=16, gf=82.10),
     'Yolo3D (DCN head) R34 384x1280 B=16': dict(kind='mono', name='Yolo3D', depth=34, H=384, W=1280, B=16, gf=None),
     'C3 Stereo3D R50 288x1280 B=16 (StereoHead)': dict(kind='stereo', depth=50, H=288, W=1280, B=16, gf=593.55),
+    'C3 Stereo3D R50 + base DCNv2 head 288x1280 B=32 (as BASELINE states it)': dict(kind='stereo', depth=50, H=288, W=1280, B=32, gf=472.0,
+                                                                                     dcn_head=True),
     'C2 Stereo3D R34 384x1280 B=8': dict(kind='stereo', depth=34, H=384, W=1280, B=8, gf=473.82),
     'C5 KM3D DLA-34 512x1760 B=16': dict(kind='km3d', H=512, W=1760, B=16, gf=326.18),
 }
@@ -32,7 +34,11 @@ def build(c):
         syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
     else:
         cfg = syn.km3d_cfg(output_w=c['W'] // 4)
-    m = DETECTOR_DICT[cfg.name](cfg)
+    if c.get('dcn_head'):
+        from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3DBaseHead
+        m = Stereo3DBaseHead(cfg)
+    else:
+        m = DETECTOR_DICT[cfg.name](cfg)
     m.load_state_dict(syn.seeded_state_dict(m.state_dict(), seed=1, head_std=0.0005))
     m = m.cuda().eval()
     m.compute_dtype = torch.bfloat16
@@ -75,7 +81,7 @@ def main():
         dt = (time.perf_counter() - t0) / n
         rate = c['B'] / dt
         extra = '  %.0f TF/s whole path (%.1f %% of 2.5 PF)' % (rate * c['gf'] / 1e3, rate * c['gf'] / 25e3) if c['gf'] else ''
-        print('%-46s %8.2f ms/step %9.1f img/s%s' % (name, dt * 1e3, rate, extra), flush=True)
+        print('%-76s %8.2f ms/step %9.1f img/s%s' % (name, dt * 1e3, rate, extra), flush=True)
         del m, g, out, inputs
         torch.cuda.empty_cache()
 

@@ -11,6 +11,9 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('km3d off 64->27', 16, 128, 440, 64, 27),
     ('dla 128->64', 16, 64, 220, 128, 64),
     ('stereo 72->72', 8, 48, 160, 72, 72),
+    ('neck 288->288', 8, 24, 80, 288, 288),
+    ('ghost 384->384', 8, 24, 80, 384, 384),
+    ('ghost 96->96', 8, 48, 160, 96, 96),
     ('down 64->128 s2', 16, 96, 320, 64, 128),
     ('layer2 128->128', 16, 48, 160, 128, 128),
     ('layer3 256->256', 16, 24, 80, 256, 256),

@@ -1213,7 +1213,9 @@ __global__ void __launch_bounds__(256) conv_regw_kernel(const ConvArgs p, int nt
         const int iy = o.ty * kResTH - 1 + hy, ix = o.tx * kResTW - 1 + hx;
         const bool v = o.tv && hr < kResHR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const int col = (2 * g + o.ph) * 64 + ((ln & 7) ^ hkey(hr)) * 8;
-        const uint32_t off = v ? (uint32_t)((int)(o.b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + col) * 2 : kOOB;
+        // always computed; an out-of-image lane gets the top bit = out of range (a select the compiler cannot turn into an
+        // exec-masked branch inside the MFMA stream; in_bytes < 2^31)
+        const uint32_t off = ((uint32_t)(o.b * (int)p.in_batch_stride + iy * p.in_row_stride + ix * p.in_pix_stride + col) * 2u) | (v ? 0u : kOOB);
         if constexpr (ABL != 2 && ABL != 3)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(smem + o.slot * UNIT + g * kRwImg + pi * 1024), 16, off, 0, 0, 0);
     };
@@ -1514,6 +1516,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 76: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16>(a, stream));
         case 43: return launch<T, 128, 192, 2, 2, true, true>(a, stream);
         case 79: VD3D_BF16_ONLY(launch<T, 256, 272, 8, 1, true, true, 16>(a, stream));
+        case 73: VD3D_BF16_ONLY(launch<T, 128, 144, 4, 1, true, true, 16>(a, stream));
         case 87: return launch<T, 256, 32, 8, 1, true, true, 32, 1>(a, stream);
         case 30: return launch<T, 128, 64, 4, 1, true>(a, stream);
         case 21: VD3D_HALO_ONLY(launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream));
@@ -1559,7 +1562,6 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 95: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 5>(a, stream));
         case 96: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 6>(a, stream));
         case 97: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 7>(a, stream));
-        case 73: VD3D_BF16_ONLY(launch<T, 128, 144, 4, 1, true, true, 16>(a, stream));
         case 74: VD3D_BF16_ONLY(launch<T, 64, 144, 2, 1, true, true, 16>(a, stream));
         case 75: VD3D_BF16_ONLY(launch<T, 128, 288, 2, 2, true, true, 16>(a, stream));
         case 71: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream));
@@ -1568,6 +1570,14 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         default: return forced_tile_error("is not a tile of this build");
     }
     if constexpr (sizeof(T) == 2) {
+        // register-resident weights (v6): Cin 128 always (+25 % over the 8x32x128 halo tile on ResNet layer2); Cin 256 only
+        // when the 128-pixel x 256-channel halo tiles would leave CUs idle (the 256 -> 256 cls conv at 8 x 24 x 80: 120 tiles;
+        // +40 % there, but -6 % on layer3 whose 240 halo tiles fill the chip)
+        if (g_force_cfg != 60 && regw_shape_ok(a)) {
+            if (a.Cin == 128) return launch_regw<128>(a, stream);
+            const int64_t halo_tiles = (int64_t)a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16) * ((a.Cout + 255) / 256);
+            if (halo_tiles * 4 < (int64_t)vd3d_device_cu_count() * 3) return launch_regw<256>(a, stream);
+        }
         if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
             a.wide_store && !a.out_f32)
             return launch_resident64(a, stream);
@@ -1624,10 +1634,14 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     if (a.Cout % 288 == 0) {
         const double r = 1455.0 * util(256, 288, 256);
         if (r > best) { best = r; pick = 3; }
-        // (the 16x16x32 variant of this tile measured +20 % on 1408 -> 576 in isolation but not inside the model, where that
-        // conv writes fp32 and competes with the cls tower: the 128x192 tiles stay)
-        const double r2 = 850.0 * util(128, 288, 256);
+        // bf16: 8 waves of 32 x 144 on 16x16x32 MFMAs: 1109 vs 929 TF/s (128x192 tiles) on the 1408 -> 576 reg output conv
+        // (only with >= 2 strips per pixel tile: on the 288 -> 288 neck convs the 120 tiles leave half the chip idle, 69 vs 55 us)
+        const double r2 = (sizeof(T) == 2 && a.Cout >= 576 ? 1200.0 : 850.0) * util(128, 288, 256);
         if (r2 > best) { best = r2; pick = 5; }
+        if (sizeof(T) == 2 && a.Cout == 288) {     // 128 x 144 tiles on 16x16x32 MFMAs, two workgroups per CU: 544 vs 484 TF/s on 288 -> 288
+            const double r3 = 1160.0 * util(128, 144, 512);
+            if (r3 > best) { best = r3; pick = 8; }
+        }
     }
     if (getenv("VD3D_CONV_DEBUG")) fprintf(stderr, "[vd3d conv] M=%d N=%d pick=%d best=%.0f\n", a.M, a.Cout, pick, best);
     switch (pick) {
@@ -1650,6 +1664,9 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 7:
             if constexpr (sizeof(T) == 2) return launch<T, 256, 272, 8, 1, true, true, 16>(a, stream);
             else return launch<T, 256, 256, 2, 4, true, true>(a, stream);
+        case 8:
+            if constexpr (sizeof(T) == 2) return launch<T, 128, 144, 4, 1, true, true, 16>(a, stream);
+            else return launch<T, 128, 128, 2, 2, true, true>(a, stream);
         default: return launch<T, 128, 128, 2, 2, true, true>(a, stream);
     }
 #undef VD3D_BF16_ONLY
@@ -1671,7 +1688,7 @@ extern "C" int vd3d_tuning_regw_stamps(unsigned long long* out, int n) {
 
 extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
     // keep in step with the "production tiles" block of dispatch()
-    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 87, 30, 21, 23, 27, 61};
+    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61};
     const int n = (int)(sizeof(kIds) / sizeof(kIds[0]));
     for (int i = 0; i < n && i < cap; ++i) ids[i] = kIds[i];
     return n;

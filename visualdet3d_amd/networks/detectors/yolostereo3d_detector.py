@@ -7,7 +7,7 @@ post-processing), with a single device->host sync at the very end."""
 import torch
 import torch.nn as nn
 
-from ..heads.detection_3d_head import StereoHead
+from ..heads.detection_3d_head import AnchorBasedDetection3DHead, StereoHead
 from ..lib import fused
 from ..utils.registry import DETECTOR_DICT
 from .yolostereo3d_core import YoloStereo3DCore
@@ -58,3 +58,13 @@ class Stereo3D(nn.Module):
         if isinstance(inputs, list) and len(inputs) >= 5:
             return self.train_forward(*inputs)
         return self.test_forward(*inputs)
+
+
+class Stereo3DBaseHead(Stereo3D):
+    """BASELINE config 3 ("YOLOStereo3D ResNet-50 + DCNv2 head"): the stereo core with the BASE anchor head, whose reg tower
+    starts with a ModulatedDeformConvPack (heads/detection_3d_head.py:69-79).  Not a shipped / registered model of the
+    reference (``StereoHead`` has no DCN); it is ``Stereo3D`` with ``build_head`` overridden
+    (yolostereo3d_detector.py:35-38) and nothing else, so it is not added to ``DETECTOR_DICT`` either."""
+
+    def build_head(self, network_cfg):
+        self.bbox_head = AnchorBasedDetection3DHead(**(network_cfg.head))
