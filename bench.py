@@ -83,6 +83,17 @@ def profile_convs(model, inputs, reps=3):
                         '%dx%d s%d %4d->%4d @ %dx%dx%d' % (pc.kh, pc.kw, pc.stride, pc.Cin, pc.Cout, B, Ho, Wo)))
         return o
 
+    # HIP-event overhead: a (start, stop) pair around NOTHING still reads ~2-4 us (event processing between the two
+    # timestamps); it is measured here and subtracted from every launch so that the sum agrees with the kernel durations a
+    # rocprofv3 --kernel-trace of `bench.py --no-overlap` reports (profiles/*_serial_roofline_check.txt)
+    pairs = []
+    for _ in range(64):
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        e0.record()
+        pairs.append((s0, e0))
+    torch.cuda.synchronize()
+    ovh_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
     ops.conv2d = timed
     overlap = model.bbox_head.overlap_towers
     overlap_neck = model.core.overlap_neck
@@ -101,11 +112,11 @@ def profile_convs(model, inputs, reps=3):
         per = len(records) // reps
         for i in range(per):
             fl = records[i][0]
-            t = sum(records[i + r * per][1].elapsed_time(records[i + r * per][2]) for r in range(reps)) / reps
+            t = sum(records[i + r * per][1].elapsed_time(records[i + r * per][2]) - ovh_ms for r in range(reps)) / reps
             print('  conv %2d  %-32s %8.2f GF  %8.1f us  %7.1f TF/s' % (i, records[i][4], fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     flops = sum(r[0] for r in records) / reps
-    secs = sum(r[1].elapsed_time(r[2]) for r in records) * 1e-3 / reps
-    return flops, secs, len(records) // reps, sum(r[3] for r in records) / reps
+    secs = sum(max(r[1].elapsed_time(r[2]) - ovh_ms, 0.0) for r in records) * 1e-3 / reps
+    return flops, secs, len(records) // reps, sum(r[3] for r in records) / reps, ovh_ms * 1e3
 
 
 def _cpu_model():
@@ -316,7 +327,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        flops, secs, nl, alg_bytes = profile_convs(model, inputs)
+        flops, secs, nl, alg_bytes, ev_us = profile_convs(model, inputs)
         traffic = None
         pmc = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
         if not os.path.exists(pmc):
@@ -337,7 +348,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 (all %d launches per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                          'traffic': traffic, 'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
-                         'algorithmic_bytes': alg_bytes,
+                         'algorithmic_bytes': alg_bytes, 'event_pair_overhead_us_subtracted_per_launch': round(ev_us, 2),
                          'whole_path_frac': round(value / world * GFLOP_PER_PAIR * (args.height * args.width) / (384 * 1280) / 1e3 / peak, 4)},
         }
         if not args.no_cpu_baseline:

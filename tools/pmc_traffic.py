@@ -7,7 +7,7 @@ import os
 import sqlite3
 import sys
 
-CONV = ('conv_igemm', 'conv_halo', 'conv_resident')
+CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw')
 
 
 def per_kernel(path, counter):

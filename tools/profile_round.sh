@@ -1,0 +1,40 @@
+#!/bin/bash
+# One GPU-box pass that produces every rocprofv3 artefact of a round (copy the summaries from gpurun_out/<tag>/ to profiles/):
+#   tools/profile_round.sh <tag>          (run from the repo root on the MI355X box)
+#  1. kernel trace of the HEADLINE configuration (hipGraph replay, side streams on)        -> <tag>_kernel_stats.csv
+#  2. kernel trace of `bench.py --no-overlap` (one stream: durations are additive)         -> <tag>_serial_kernel_stats.csv,
+#     <tag>_serial_timeline.txt, <tag>_serial_bench.json  (sum of the conv kernels == roofline.achieved of that line)
+#  3. PMC passes, each in its own run: FETCH_SIZE, WRITE_SIZE (HBM traffic of the conv launches) -> <tag>_pmc_traffic.json
+#  4. PMC pass: SQ counters of the conv families (MFMA busy, waits, LDS conflicts)         -> <tag>_sq_pmc.txt
+set -u
+TAG=${1:-r02}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+run() {  # name, rocprof args..., -- bench args
+    local name=$1; shift
+    rm -rf $OUT/$name
+    timeout 600 rocprofv3 "$@" > $OUT/$name.log 2>&1
+    echo "[$name] rc=$?"
+}
+run trace_overlap --kernel-trace --stats -d $OUT/trace_overlap -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline
+run trace_serial --kernel-trace --stats -d $OUT/trace_serial -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap
+run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline
+run pmc_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline
+run pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-overlap --no-cpu-baseline
+cd $ROOT
+db() { find $OUT/$1 -name "*.db" | sort | tail -1; }
+python tools/rocpd_stats.py $(db trace_overlap) > $OUT/${TAG}_kernel_stats.csv
+python tools/rocpd_stats.py $(db trace_serial) > $OUT/${TAG}_serial_kernel_stats.csv
+python tools/rocpd_timeline.py $(db trace_serial) > $OUT/${TAG}_serial_timeline.txt
+grep '^{' $OUT/trace_serial.log | tail -1 > $OUT/${TAG}_serial_bench.json
+grep '^{' $OUT/trace_overlap.log | tail -1 > $OUT/${TAG}_overlap_bench_under_rocprof.json
+python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json
+python tools/rocpd_pmc_table.py $OUT/pmc_sq conv_ > $OUT/${TAG}_sq_pmc.txt
+python tools/serial_roofline_check.py $OUT/${TAG}_serial_kernel_stats.csv $OUT/${TAG}_serial_bench.json > $OUT/${TAG}_serial_roofline_check.txt
+cat $OUT/${TAG}_serial_roofline_check.txt
+# the rocpd databases stay on the box (too big); only the summaries travel back
+rm -rf $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+ls -la $OUT
