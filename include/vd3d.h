@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 #define VD3D_BF16 0
+#define VD3D_F16 2   /* IEEE half storage (same kernels and MFMA rate as bf16; conv, elementwise, DCN and the KM3D head) */
 #define VD3D_F32 1
 
 #define VD3D_OK 0

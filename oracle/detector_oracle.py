@@ -30,6 +30,11 @@ def bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def fp16_round(x):
+    """rounding points of the HIP fp16 path (BASELINE config 5: KM3D in half precision)."""
+    return x.to(torch.float16).to(torch.float32)
+
+
 class Ctx:
     """state_dict + rounding policy."""
 

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79, 73, 61}       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 76, 79, 73, 61}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
 
@@ -47,7 +47,7 @@ def run_case(B, H, W, Cin, Cout, k=3, stride=1, pad=1, dil=1, residual=False, re
     x = torch.randn(B, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
     b = torch.randn(Cout, generator=g) * 0.1
-    rnd = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    rnd = (lambda t: t.to(dtype).float()) if dtype in (torch.bfloat16, torch.float16) else (lambda t: t)
     y = F.conv2d(rnd(x), rnd(w), None, stride, pad, dil)
     bnp = None
     scale, shift = torch.ones(Cout), b.clone()
@@ -83,7 +83,9 @@ def run_case(B, H, W, Cin, Cout, k=3, stride=1, pad=1, dil=1, residual=False, re
     rel = d.max().item() / sc
     if dtype == torch.bfloat16 and not out_f32:
         ulp = (d / (y.abs() * 2.0 ** -7 + 3e-5 * sc)).max().item()      # <= 1: within one bf16 ulp (+ summation noise)
-    elif dtype == torch.bfloat16:
+    elif dtype == torch.float16 and not out_f32:
+        ulp = (d / (y.abs() * 2.0 ** -10 + 3e-5 * sc)).max().item()     # <= 1: within one fp16 ulp (+ summation noise)
+    elif dtype in (torch.bfloat16, torch.float16):
         ulp = rel / 1e-4                                                  # fp32 epilogue from bf16 operands: summation noise only
     else:
         ulp = rel / 2e-5
@@ -128,6 +130,14 @@ def test_every_production_tile_bf16_vs_oracle(cfg):
     for i, (B, H, W, Cin, Cout, kw) in enumerate(_shapes_for(cfg)):
         ulp, rel = run_case(B, H, W, Cin, Cout, dtype=torch.bfloat16, seed=100 + i, cfg=cfg, **kw)
         assert ulp <= 1.0, 'tile %d shape %s: %.2f bf16 ulp (rel %.2e)' % (cfg, (B, H, W, Cin, Cout, kw), ulp, rel)
+
+
+@pytest.mark.parametrize('cfg', PRODUCTION_TILES)
+def test_every_production_tile_fp16_vs_oracle(cfg):
+    """fp16 storage (VD3D_F16, BASELINE config 5): the same tiles on v_mfma_f32_*_f16, each output within ONE fp16 ulp."""
+    for i, (B, H, W, Cin, Cout, kw) in enumerate(_shapes_for(cfg)):
+        ulp, rel = run_case(B, H, W, Cin, Cout, dtype=torch.float16, seed=300 + i, cfg=cfg, **kw)
+        assert ulp <= 1.0, 'tile %d shape %s: %.2f fp16 ulp (rel %.2e)' % (cfg, (B, H, W, Cin, Cout, kw), ulp, rel)
 
 
 @pytest.mark.parametrize('cfg', [c for c in PRODUCTION_TILES if c not in BF16_TILES])

@@ -64,7 +64,7 @@ def test_pack_module_nchw_forward():
     assert set(sd) == {'weight', 'bias', 'conv_offset.weight', 'conv_offset.bias'}
 
 
-@pytest.mark.parametrize('dtype,tol', [(torch.float32, 5e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 5e-5), (torch.bfloat16, 2e-2), (torch.float16, 2.5e-3)])
 def test_pack_module_nhwc_engine_path_with_bn_relu(dtype, tol):
     C, O = 64, 64
     m = _pack_module(C, O, 2)
@@ -74,7 +74,7 @@ def test_pack_module_nhwc_engine_path_with_bn_relu(dtype, tol):
         bn.weight.copy_(torch.rand(O, generator=g) + 0.5); bn.bias.copy_(torch.randn(O, generator=g) * 0.1)
         bn.running_mean.copy_(torch.randn(O, generator=g) * 0.1); bn.running_var.copy_(torch.rand(O, generator=g) + 0.5)
     x = torch.randn(2, C, 9, 12, generator=g)
-    rnd = (lambda t: t.to(torch.bfloat16).float()) if dtype == torch.bfloat16 else None
+    rnd = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else None
     with torch.no_grad():
         xr = rnd(x) if rnd else x
         # offsets come from the (rounded-input, rounded-weight) conv in the engine; sampling positions are fp32

@@ -150,3 +150,31 @@ def test_bf16_dcn_blocks_teacher_forced_vs_bf16_oracle():
         worst = max(worst, ulp)
         assert ulp <= 1.0, '%s: %.2f (x 2 bf16 ulp), rel %.2e' % (name, ulp, d.max().item() / sc)
     print('\n[KM3D bf16 teacher-forced DCN blocks] worst %.2f x (2 bf16 ulp + 5e-4 scale)' % worst)
+
+
+def test_fp16_mode_config5_vs_fp16_oracle_and_reference_golden():
+    """BASELINE config 5 is KM3D in fp16 (the reference's DCN dispatches half, deform_conv_cuda_kernel.cu AT_DISPATCH_..._AND_HALF).
+    ``compute_dtype = torch.float16``: every conv / DCN / pool on v_mfma_f32_*_f16 with fp16 storage, fp32 accumulation.
+    vs the oracle with fp16 rounding points, and (fp16 carries 3 more mantissa bits than bf16) vs the fp32 outputs of the
+    reference itself; detections matched one to one."""
+    g = load_golden('km3d_dla34_96x320')
+    cfg, (img, P2), winit = km3d_case_from_golden(g)
+    m, sd = _model(cfg, winit, torch.float16)
+    outs = m.test_forward_batched(img.cuda(), P2.cuda())
+    maps = m._last_raw
+    with torch.no_grad():
+        _, st = orc.km3d_forward(sd, cfg, img, P2, rnd=orc.fp16_round, return_stages=True)
+    worst_o = worst_g = 0.0
+    for h in ('hm', 'hps', 'dim', 'rot', 'wh', 'reg'):
+        got = maps[h].permute(0, 3, 1, 2).contiguous().cpu()
+        worst_o = max(worst_o, rel_err(got, st[h]))
+        for f in range(img.shape[0]):
+            worst_g = max(worst_g, rel_err(subsample(got[f:f + 1]), g['f%d_%s_sub' % (f, h)]))
+    print('\n[KM3D fp16] maps vs fp16-rounded oracle %.2e, vs fp32 reference golden %.2e' % (worst_o, worst_g))
+    assert worst_o < 3e-2 and worst_g < 3e-2
+    for f in range(img.shape[0]):
+        s, b, l = [t.cpu() for t in outs[f]]
+        # (the keypoint decode -- peaks, top-K, keypoint association, 16x3 least squares -- amplifies a 6e-3 map difference;
+        # of ~100 detections per frame a handful sit on a top-K / association threshold)
+        assert_detections_close((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=6e-2,
+                                what='fp16 frame %d' % f, allow_missing=6)

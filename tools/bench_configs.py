@@ -21,6 +21,7 @@ CONFIGS = {
                                                                                      dcn_head=True),
     'C2 Stereo3D R34 384x1280 B=8': dict(kind='stereo', depth=34, H=384, W=1280, B=8, gf=473.82),
     'C5 KM3D DLA-34 512x1760 B=16': dict(kind='km3d', H=512, W=1760, B=16, gf=326.18),
+    'C5 KM3D DLA-34 512x1760 B=16 fp16 (as BASELINE states it)': dict(kind='km3d', H=512, W=1760, B=16, gf=326.18, dtype='fp16'),
 }
 
 
@@ -41,7 +42,7 @@ def build(c):
         m = DETECTOR_DICT[cfg.name](cfg)
     m.load_state_dict(syn.seeded_state_dict(m.state_dict(), seed=1, head_std=0.0005))
     m = m.cuda().eval()
-    m.compute_dtype = torch.bfloat16
+    m.compute_dtype = torch.float16 if c.get('dtype') == 'fp16' else torch.bfloat16
     B, H, W = c['B'], c['H'], c['W']
     P2, _ = syn.kitti_calib(W, batch=B)
     if c['kind'] == 'stereo':

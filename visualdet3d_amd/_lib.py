@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libvd3d_hip_tuning.so' if os.environ.get('VD3D_T
 
 VD3D_BF16 = 0
 VD3D_F32 = 1
+VD3D_F16 = 2
 ABI_VERSION = 2
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float

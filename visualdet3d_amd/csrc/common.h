@@ -26,11 +26,73 @@ VD3D_DEV short f2bf(float f) {
     return __builtin_bit_cast(short, b);
 }
 
+// fp16 storage: `hf16` (unsigned short) is the element-type TAG of half-precision tensors, as `short` is the tag of bf16 ones
+typedef unsigned short hf16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+VD3D_DEV float h2f(hf16 v) { return (float)__builtin_bit_cast(_Float16, v); }
+VD3D_DEV hf16 f2h(float f) {
+    _Float16 h = (_Float16)f;        // v_cvt_f16_f32, round to nearest even
+    return __builtin_bit_cast(hf16, h);
+}
+
+// The two 16-bit storage formats behind one interface: pack / unpack and the MFMA flavours (same register images and
+// instruction rates: v_mfma_f32_32x32x16_{bf16,f16}, v_mfma_f32_16x16x32_{bf16,f16})
+template <typename T> struct Fmt16;
+template <> struct Fmt16<short> {
+    static VD3D_DEV int pack2(float lo, float hi) { return (int)((uint32_t)(uint16_t)f2bf(lo) | ((uint32_t)(uint16_t)f2bf(hi) << 16)); }
+    static VD3D_DEV float lo(uint32_t u) { return i2f((int)(u << 16)); }
+    static VD3D_DEV float hi(uint32_t u) { return i2f((int)(u & 0xffff0000u)); }
+    static VD3D_DEV short one(float f) { return f2bf(f); }
+    static VD3D_DEV float tof(short v) { return bf2f(v); }
+    static VD3D_DEV void mfma32(const i32x4& a, const i32x4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    static VD3D_DEV void mfma16(const i32x4& a, const i32x4& b, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    static VD3D_DEV void mfma32z(const i32x4& a, const i32x4& b, const f32x16& c, f32x16& acc) {     // acc = a x b + c (c: a constant)
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Fmt16<hf16> {
+    static VD3D_DEV int pack2(float lo, float hi) {
+        f16x2 p = {(_Float16)lo, (_Float16)hi};          // v_cvt_pk_f16_f32 (RNE)
+        return __builtin_bit_cast(int, p);
+    }
+    static VD3D_DEV float lo(uint32_t u) { return h2f((hf16)(u & 0xffffu)); }
+    static VD3D_DEV float hi(uint32_t u) { return h2f((hf16)(u >> 16)); }
+    static VD3D_DEV hf16 one(float f) { return f2h(f); }
+    static VD3D_DEV float tof(hf16 v) { return h2f(v); }
+    static VD3D_DEV void mfma32(const i32x4& a, const i32x4& b, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+    static VD3D_DEV void mfma16(const i32x4& a, const i32x4& b, f32x4& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+    static VD3D_DEV void mfma32z(const i32x4& a, const i32x4& b, const f32x16& c, f32x16& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+
+template <> struct Fmt16<float> {      // never used for arithmetic: lets 16-bit-only epilogue code compile in fp32 instantiations
+    static VD3D_DEV int pack2(float lo, float hi) { return Fmt16<short>::pack2(lo, hi); }
+    static VD3D_DEV float lo(uint32_t u) { return Fmt16<short>::lo(u); }
+    static VD3D_DEV float hi(uint32_t u) { return Fmt16<short>::hi(u); }
+    static VD3D_DEV float one(float f) { return f; }
+    static VD3D_DEV float tof(float v) { return v; }
+};
+
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<short> {  // bf16 storage
     static constexpr int kVec = 8;      // elements per 16-byte vector
     static VD3D_DEV float to_f(short v) { return bf2f(v); }
     static VD3D_DEV short from_f(float f) { return f2bf(f); }
+};
+template <> struct ElemTraits<hf16> {   // fp16 storage
+    static constexpr int kVec = 8;
+    static VD3D_DEV float to_f(hf16 v) { return h2f(v); }
+    static VD3D_DEV hf16 from_f(float f) { return f2h(f); }
 };
 template <> struct ElemTraits<float> {
     static constexpr int kVec = 4;
@@ -51,6 +113,14 @@ template <> struct Vec16<short> {
         uint32_t l = (uint16_t)f2bf(lo), h = (uint16_t)f2bf(hi);
         raw[pair] = (int)(l | (h << 16));
     }
+};
+template <> struct Vec16<hf16> {
+    i32x4 raw;
+    VD3D_DEV float get(int i) const {
+        const uint32_t w = (uint32_t)(int)raw[i >> 1];
+        return (i & 1) ? Fmt16<hf16>::hi(w) : Fmt16<hf16>::lo(w);
+    }
+    VD3D_DEV void set2(int pair, float lo, float hi) { raw[pair] = Fmt16<hf16>::pack2(lo, hi); }
 };
 template <> struct Vec16<float> {
     i32x4 raw;

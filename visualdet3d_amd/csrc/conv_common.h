@@ -1,0 +1,43 @@
+// conv_common.h -- shared between the implicit-GEMM translation units (conv_igemm.hip: tile / halo kernels and the dispatcher;
+// conv_resident.hip: the register-resident-weight kernels).
+#pragma once
+#include "common.h"
+#include <utility>
+
+namespace vd3d_conv {
+
+struct ConvArgs {
+    const char* in;
+    const char* weight;
+    const char* wfrag = nullptr;      // optional MFMA register image of the weights (vd3d_conv_params.weight_frag)
+    const float* scale;
+    const float* shift;
+    const char* residual;
+    char* out;
+    int B, H, W, Cin;
+    int in_pix_stride, in_row_stride;
+    int64_t in_batch_stride;
+    uint32_t in_bytes, w_bytes;
+    int Ho, Wo, Cout;
+    int out_pix_stride, res_pix_stride;
+    int kh, kw, stride, pad, dil;
+    int Kpad, relu, out_f32;
+    int M, tiles_m, tiles_n, ntaps, nk;
+    int vec_epilogue, wide_store, chunk_major;
+    // fused KM3D head (vd3d_km3d_head_fused): per 256-channel N tile h, a second GEMM [256 px x 256] x [256 x n_h] in the
+    // epilogue; h_w2 = packed [heads][32][256] bf16, h_b2 = [heads][32] fp32, h_out[h] = fp32 [M][h_n[h]]
+    const char* h_w2 = nullptr;
+    const float* h_b2 = nullptr;
+    float* h_out[9] = {};
+    int h_n[9] = {};
+};
+
+constexpr uint32_t kOOB = 0x80000000u;  // byte offset guaranteed >= num_records (host enforces in_bytes < 2^31)
+
+// entry points of conv_resident.hip (bf16 3x3 / stride 1 / pad 1 kernels whose weights live in registers)
+bool regw_shape_ok(const ConvArgs& a);                       // Cin 128 | 256, Cout a multiple of the channel slice, weight_frag given
+// fmt = VD3D_BF16 | VD3D_F16 (the 16-bit storage format of activations and weights)
+int launch_regw(ConvArgs& a, hipStream_t stream, int fmt, int ring = 4, int abl = 0);     // (ring / abl != defaults: tuning build only)
+int launch_resident64(ConvArgs& a, hipStream_t stream, int fmt);      // Cin = Cout = 64
+
+}  // namespace vd3d_conv

@@ -20,46 +20,17 @@
 //   * bf16: v_mfma_f32_32x32x16_bf16; fp32 validation mode: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain);
 //   * the 1-D grid is remapped so each XCD (private 4 MiB L2) walks a contiguous run of pixel tiles that
 //     share one weight panel.
-#include "common.h"
+#include "conv_common.h"
 #include <stdio.h>
 #include <stdlib.h>
-#include <utility>
+#include <type_traits>
+
+using namespace vd3d_conv;
 
 namespace {
 
-struct ConvArgs {
-    const char* in;
-    const char* weight;
-    const char* wfrag = nullptr;      // optional MFMA register image of the weights (vd3d_conv_params.weight_frag)
-    const float* scale;
-    const float* shift;
-    const char* residual;
-    char* out;
-    int B, H, W, Cin;
-    int in_pix_stride, in_row_stride;
-    int64_t in_batch_stride;
-    uint32_t in_bytes, w_bytes;
-    int Ho, Wo, Cout;
-    int out_pix_stride, res_pix_stride;
-    int kh, kw, stride, pad, dil;
-    int Kpad, relu, out_f32;
-    int M, tiles_m, tiles_n, ntaps, nk;
-    int vec_epilogue, wide_store, chunk_major;
-    // fused KM3D head (vd3d_km3d_head_fused): per 256-channel N tile h, a second GEMM [256 px x 256] x [256 x n_h] in the
-    // epilogue; h_w2 = packed [heads][32][256] bf16, h_b2 = [heads][32] fp32, h_out[h] = fp32 [M][h_n[h]]
-    const char* h_w2 = nullptr;
-    const float* h_b2 = nullptr;
-    float* h_out[9] = {};
-    int h_n[9] = {};
-};
-
-constexpr uint32_t kOOB = 0x80000000u;  // byte offset guaranteed >= num_records (host enforces in_bytes < 2^31)
-
-template <typename T> struct Mma;
-template <> struct Mma<short> {
-    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
+template <typename T> struct Mma {          // 16-bit formats: bf16 (T = short) | fp16 (T = hf16)
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) { Fmt16<T>::mfma32(a, b, acc); }
 };
 template <> struct Mma<float> {
     // lane half h holds 4 consecutive k of an 8-wide k group; MFMA j pairs k = j (h=0) with k = 4 + j (h=1):
@@ -115,10 +86,10 @@ VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int 
                             if constexpr (sizeof(T) == 2) {
                                 const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
                                 const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
-                                v[0] += i2f((int)(r0 << 16));
-                                v[1] += i2f((int)(r0 & 0xffff0000u));
-                                v[2] += i2f((int)(r1 << 16));
-                                v[3] += i2f((int)(r1 & 0xffff0000u));
+                                v[0] += Fmt16<T>::lo(r0);
+                                v[1] += Fmt16<T>::hi(r0);
+                                v[2] += Fmt16<T>::lo(r1);
+                                v[3] += Fmt16<T>::hi(r1);
                             } else {
                                 const f32x4 rr = *(const f32x4*)(p.residual + (rbase + nb) * 4);
 #pragma unroll
@@ -134,8 +105,8 @@ VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int 
                             *(f32x4*)(p.out + (obase + nb) * 4) = o;
                         }
                     }
-                    packed[g][0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-                    packed[g][1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                    packed[g][0] = Fmt16<T>::pack2(v[0], v[1]);
+                    packed[g][1] = Fmt16<T>::pack2(v[2], v[3]);
                 }
                 if (!f32_out) {
                     if (p.wide_store) {
@@ -174,7 +145,7 @@ VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int 
                         if (p.residual) x += ElemTraits<T>::to_f(((const T*)p.residual)[rbase + n]);
                         if (p.relu) x = fmaxf(x, 0.f);
                         if (f32_out) ((float*)p.out)[obase + n] = x;
-                        else ((short*)p.out)[obase + n] = f2bf(x);
+                        else ((T*)p.out)[obase + n] = Fmt16<T>::one(x);
                     }
             }
         }
@@ -186,16 +157,14 @@ template <typename T, int MS> struct MmaShape {
     typedef f32x16 acc_t;
     static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) { Mma<T>::run(a, b, acc); }
 };
-template <> struct MmaShape<short, 16> {
+template <typename T> struct MmaShape<T, 16> {
     typedef f32x4 acc_t;
-    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x4& acc) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x4& acc) { Fmt16<T>::mfma16(a, b, acc); }
 };
 
 // Epilogue for the 16x16x32 layout (weights = A operand): lane (l16, q) holds output channels 4q .. 4q+3 of pixel l16 of
 // the 16x16 block; bf16 only, 8-byte NHWC stores (vector path) or scalar stores.
-template <int TM, int TN, int WTN>
+template <typename T, int TM, int TN, int WTN>
 VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int q) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -224,10 +193,10 @@ VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int
                 if (p.residual) {
                     const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
                     const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
-                    v[0] += i2f((int)(r0 << 16));
-                    v[1] += i2f((int)(r0 & 0xffff0000u));
-                    v[2] += i2f((int)(r1 << 16));
-                    v[3] += i2f((int)(r1 & 0xffff0000u));
+                    v[0] += Fmt16<T>::lo(r0);
+                    v[1] += Fmt16<T>::hi(r0);
+                    v[2] += Fmt16<T>::lo(r1);
+                    v[3] += Fmt16<T>::hi(r1);
                 }
                 if (p.relu) {
 #pragma unroll
@@ -238,8 +207,8 @@ VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int
                     *(f32x4*)(p.out + (obase + nb) * 4) = o;
                 } else {
                     i32x2 o;
-                    o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-                    o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                    o[0] = Fmt16<T>::pack2(v[0], v[1]);
+                    o[1] = Fmt16<T>::pack2(v[2], v[3]);
                     *(i32x2*)(p.out + (obase + nb) * 2) = o;
                 }
             } else {
@@ -250,10 +219,10 @@ VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int
                     float x = v[e];
                     if (p.scale) x *= p.scale[n];
                     if (p.shift) x += p.shift[n];
-                    if (p.residual) x += bf2f(((const short*)p.residual)[rbase + n]);
+                    if (p.residual) x += Fmt16<T>::tof(((const T*)p.residual)[rbase + n]);
                     if (p.relu) x = fmaxf(x, 0.f);
                     if (p.out_f32) ((float*)p.out)[obase + n] = x;
-                    else ((short*)p.out)[obase + n] = f2bf(x);
+                    else ((T*)p.out)[obase + n] = Fmt16<T>::one(x);
                 }
             }
         }
@@ -701,8 +670,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * g + e] + sh[e], 0.f);
                     i32x2 o;
-                    o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-                    o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                    o[0] = Fmt16<T>::pack2(v[0], v[1]);
+                    o[1] = Fmt16<T>::pack2(v[2], v[3]);
                     const int slot16 = c >> 3;
                     *(i32x2*)(smem + r * 512 + ((slot16 ^ (r & 15)) << 4) + half * 8) = o;
                 }
@@ -719,7 +688,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             const int slot16 = 2 * ks + half;
             const i32x4 fa2 = *(const i32x4*)(w2row + slot16 * 16);
             const i32x4 fb2 = *(const i32x4*)(smem + r2 * 512 + ((slot16 ^ (r2 & 15)) << 4));
-            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa2), __builtin_bit_cast(bf16x8, fb2), acc2, 0, 0, 0);
+            Fmt16<T>::mfma32(fa2, fb2, acc2);
         }
         const int m2 = m0 + r2;
         const int nh = p.h_n[h];
@@ -736,7 +705,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         return;
     }
     if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
-    else conv_epilogue16<TM, TN, WTN>(p, acc, mrow, n0, wn, half);
+    else conv_epilogue16<T, TM, TN, WTN>(p, acc, mrow, n0, wn, half);
 }
 
 // =====================================================================================================
@@ -913,539 +882,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const 
     conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
 }
 
-// =====================================================================================================
-// v5 "resident weights" kernel: 3x3 / stride 1 / pad 1, 64 -> 64 channels, bf16 (ResNet layer1: six launches per forward,
-// K = 576 only).  The tile kernels above spend such a layer waiting: nine tiny K slices per tile, each a DMA round trip
-// and a barrier for 8 MFMAs per wave, and the 73 KB weight panel is re-fetched by every tile.  Here the whole weight
-// panel lives in REGISTERS (a wave owns 32 output channels: 9 taps x 4 sub-steps x 16 B = 144 VGPRs), the workgroups are
-// persistent (one per CU, tiles t = wg, wg + nwg, ...), and LDS only holds a 4-deep ring of input halos (8 x 16 pixels
-// + border, one 128-byte row per pixel) filled by LDS-DMA two to three tiles ahead.  Per tile: ONE barrier, 36 MFMAs per
-// wave each fed by one ds_read_b128 through a 4-fragment ring, epilogue fused as elsewhere.  The layer is then HBM-bound
-// (in x1.4 halo + out + residual ~= 215 MB per launch at B = 16 x 96 x 320), not latency-bound.
-constexpr int kResTH = 8, kResTW = 16, kResStages = 4;
-constexpr int kResHW2 = kResTW + 2, kResHR = (kResTH + 2) * kResHW2;       // 18, 180 halo pixels
-constexpr int kResPiecesTot = (kResHR + 7) / 8;                            // 23 pieces of 1 KiB
-constexpr int kResStageBytes = kResPiecesTot * 1024;
-constexpr int kResLds = kResStages * kResStageBytes + 512;   // + scale[64], shift[64] (fp32): epilogue reads them through
-                                                             // lgkmcnt, a global load per tile would drain the DMA queue (vmcnt)
-
-template <bool RES>
-__global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, int ntiles) {
-    constexpr int NW = 8, HP = 3;                     // waves; halo pieces per wave (23 = 7 waves x 3 + 1 wave x 2)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves: 32 pixels x 32 channels each
-    const int lr = lane & 31, half = lane >> 5;
-    const int tiles_x = (p.W + kResTW - 1) / kResTW, tiles_y = (p.H + kResTH - 1) / kResTH, tiles_img = tiles_x * tiles_y;   // ragged
-    // edges: halo rows beyond the image are zero-filled by the bounds check, pixels beyond it are computed and dropped
-
-    // ---- weights -> registers, MFMA A-operand layout: row = output channel, 16 bytes = 8 k values -----------
-    i32x4 wf[36];
-    {
-        if (p.wfrag) {      // register image: 36 coalesced 1 KiB reads per wave
-            const char* wimg = p.wfrag + ((size_t)wn * 36 * 64 + lane) * 16;
-#pragma unroll
-            for (int f = 0; f < 36; ++f) wf[f] = *(const i32x4*)(wimg + f * 1024);
-        } else {
-            const char* wrow = p.weight + (size_t)(wn * 32 + lr) * p.Kpad * 2;
-#pragma unroll
-            for (int f = 0; f < 36; ++f) wf[f] = *(const i32x4*)(wrow + ((f >> 2) * 64 + (2 * (f & 3) + half) * 8) * 2);
-        }
-    }
-    // ---- halo DMA lane state (same lane-linear image + source-side swizzle as the halo kernel) -------------------
-    const int prow = lane >> 3;
-    // swizzle key of a halo row = (pixel index hy*16 + hx) / 2 mod 8: the 32 rows a wave reads for any tap shift then carry
-    // consecutive keys, so every ds_read_b128 lane group covers all 16 bank slots (the plain (row/2)%8 key conflicts 2-way
-    // across the 18-row pitch: PMC showed 47 % of this kernel's LDS cycles as bank conflicts)
-    auto hkey = [](int row) { const int hy = row / kResHW2; return ((hy * kResTW + row - hy * kResHW2) >> 1) & 7; };
-    int h_slot[HP];
-    int h_y[HP], h_x[HP];
-    bool h_ok[HP];
-    int h_piece[HP];
-#pragma unroll
-    for (int it = 0; it < HP; ++it) {
-        int piece = wave + it * NW;
-        if (piece >= kResPiecesTot) piece -= NW;      // branch-free partial round: repeat the previous piece
-        h_piece[it] = piece;
-        const int hr = 8 * piece + prow;
-        h_y[it] = hr / kResHW2;
-        h_x[it] = hr - h_y[it] * kResHW2;
-        h_ok[it] = hr < kResHR;
-        h_slot[it] = (lane & 7) ^ hkey(hr);
-    }
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    auto issue_halo = [&](int t, int stage) {
-        const bool tv = t < ntiles;
-        const int tt = tv ? t : 0;
-        const int b = tt / tiles_img, trem = tt - b * tiles_img;
-        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        char* base = smem + stage * kResStageBytes;
-#pragma unroll
-        for (int it = 0; it < HP; ++it) {
-            const int iy = ty * kResTH - 1 + h_y[it], ix = tx * kResTW - 1 + h_x[it];
-            const bool v = tv && h_ok[it] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint32_t off = v ? (uint32_t)((int)(b * p.in_batch_stride) + iy * p.in_row_stride + ix * p.in_pix_stride + h_slot[it] * 8) * 2 : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + h_piece[it] * 1024), 16, off, 0, 0, 0);
-        }
-    };
-    // ---- fragment addressing: pixel pp of the tile, tap (dy, dx) -> halo row; byte = row*128 + ((2ks+half) ^ sw(row))*16
-    //      = A_tap ^ (ks << 5) with A_tap = row*128 + ((half ^ sw(row)) << 4), sw = hkey
-    const int pp = wm * 32 + lr;
-    const int hrow0 = (pp / kResTW) * kResHW2 + (pp & (kResTW - 1));
-    int a_tap[9];
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
-        const int row = hrow0 + (tap / 3) * kResHW2 + (tap % 3);
-        a_tap[tap] = row * 128 + ((half ^ hkey(row)) << 4);
-    }
-    auto ld_frag = [&](int stage, int f) {
-        return *(const i32x4*)(smem + stage * kResStageBytes + (a_tap[f >> 2] ^ ((f & 3) << 5)));
-    };
-
-    float* ss = (float*)(smem + kResStages * kResStageBytes);
-    if (tid < 64) {
-        ss[tid] = p.scale ? p.scale[tid] : 1.f;
-        ss[64 + tid] = p.shift ? p.shift[tid] : 0.f;
-    }
-    const int nwg = gridDim.x;
-    int t = blockIdx.x;
-#pragma unroll
-    for (int s0 = 0; s0 < kResStages; ++s0) issue_halo(t + s0 * nwg, s0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kResStages - 1) * HP) : "memory");   // the first halo has landed (per wave) ...
-    __builtin_amdgcn_s_barrier();                                        // ... for every wave
-    asm volatile("" ::: "memory");
-    i32x4 ring[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) ring[f] = ld_frag(0, f);
-
-    // Per tile k a wave issues, in order: [R(k): 4 residual loads, at the top] D(k+4): HP DMA pieces (after the barrier),
-    // S(k): 2 stores.  At tile k's barrier "at most 2*HP outstanding" leaves only R(k) / S(k-1) (and, without a residual,
-    // D(k+3)) in flight: D(k+2) and everything older -- in particular this barrier's D(k+1) -- has landed, and each halo gets
-    // at least one full tile time to arrive.  Also right for k = 0 (prologue D(0..3): D(0), D(1) landed).  gfx9 vmcnt
-    // retires loads and stores in issue order.
-    constexpr int kYounger = 2 * HP + (RES ? 4 : 0);     // RES: the 4 residual loads of this tile are younger too
-    int stage = 0;
-    for (; t < ntiles; t += nwg) {
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const int b = t / tiles_img, trem = t - b * tiles_img;
-        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        const int y = ty * kResTH + pp / kResTW, x = tx * kResTW + (pp & (kResTW - 1));
-        const bool pin = y < p.H && x < p.W;
-        const int64_t m = pin ? ((int64_t)b * p.H + y) * p.W + x : 0;
-        const int nb0 = wn * 32 + 4 * half;
-        i32x2 rr[4];
-        if constexpr (RES) {   // issued a whole tile ahead of their use in the epilogue (HBM latency hidden by the 36 MFMAs)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) rr[g] = *(const i32x2*)(p.residual + (m * p.res_pix_stride + nb0 + 8 * g) * 2);   // (pixel 0 if outside)
-        }
-        const int nstage = stage + 1 == kResStages ? 0 : stage + 1;
-#pragma unroll
-        for (int f = 0; f < 36; ++f) {
-            if (f == 32) {
-                // all reads of this tile's halo are issued (and, with lgkmcnt(0), done); the next halo must have landed
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kYounger) : "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                issue_halo(t + kResStages * nwg, stage);                 // tile k+4 into the stage just released
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[f]), __builtin_bit_cast(bf16x8, ring[f & 3]), acc, 0, 0, 0);
-            ring[f & 3] = f + 4 < 36 ? ld_frag(stage, f + 4) : ld_frag(nstage, f + 4 - 36);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        // ---- epilogue: scale/shift (+residual) (+ReLU), 2 x 16-byte NHWC stores per lane (half-wave pairing) ----
-        int pk[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nb = nb0 + 8 * g;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e];
-            if (p.scale) {
-                const f32x4 sc = *(const f32x4*)(ss + nb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= sc[e];
-            }
-            if (p.shift) {
-                const f32x4 sh = *(const f32x4*)(ss + 64 + nb);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += sh[e];
-            }
-            if constexpr (RES) {
-                const uint32_t r0 = (uint32_t)(int)rr[g][0], r1 = (uint32_t)(int)rr[g][1];
-                v[0] += i2f((int)(r0 << 16));
-                v[1] += i2f((int)(r0 & 0xffff0000u));
-                v[2] += i2f((int)(r1 << 16));
-                v[3] += i2f((int)(r1 & 0xffff0000u));
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            pk[g][0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-            pk[g][1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
-        }
-#pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-            auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-            auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-            i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
-            if (pin) *(i32x4*)(p.out + (m * p.out_pix_stride + wn * 32 + 8 * (g + half)) * 2) = o;
-        }
-        stage = nstage;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs must not land in a successor workgroup's LDS
-}
-
-// =====================================================================================================
-// v6 "register-resident weights" kernel for the mid-size 3x3 / stride 1 / pad 1 layers with 128 or 256 input channels (ResNet
-// layer2 / layer3, the 256 -> 256 cls conv, DLA levels): bf16.  The tile kernels above stream the weight panel through LDS
-// once per pixel tile; with only 128 - 256 pixels per panel pass these layers are bound by that L2 -> LDS fill (layer3:
-// 1.2 MB of weights per 128-pixel tile, ~15 B/clk/CU of LDS-DMA is all a CU gets) and by one barrier per 64-deep K slice.
-// Here the weights never touch LDS:
-//   * a workgroup is 4 waves, ONE per SIMD, 512 registers each.  A wave owns 32 output channels x 128 input channels
-//     (two 64-channel chunks x 9 taps x 4 sub-steps = 72 MFMA A-fragments = 288 registers), loaded once per launch;
-//     CIN = 128: 4 channel groups = 128 output channels per workgroup; CIN = 256: 2 channel groups x 2 K halves
-//     (input channels 0-127 / 128-255) = 64 output channels per workgroup, the K halves are added through LDS per tile;
-//   * workgroups are persistent (one per CU); the grid is (channel slice, pixel-tile lane): a CU keeps its slice's
-//     weights and walks 8 x 16-pixel tiles.  The slices of one pixel tile sit on the same XCD (shared L2 for the input);
-//   * LDS only holds input halos: one 23 KiB image (180 halo pixels x 64 channels, the resident64 layout + swizzle) per
-//     64-channel chunk, filled by LDS-DMA one to three phases ahead;  a phase = one chunk per K half = 36 fragments x 4
-//     pixel blocks = 144 MFMAs per wave between barriers, each MFMA fed by ONE ds_read_b128 through a fragment ring;
-//   * every VMEM instruction is issued unconditionally (out-of-image lanes use an out-of-range buffer offset), so the
-//     counted s_waitcnt vmcnt(N) below always sees the same queue.
-#ifdef VD3D_TUNING
-__device__ unsigned long long g_regw_dbg[64];
-#endif
-template <int V> struct IntC { static constexpr int value = V; };
-// compile-time loop: the body is instantiated once per index (a `#pragma unroll` loop this large may be left rolled, and a rolled
-// loop would index the weight registers dynamically, i.e. put them in scratch memory)
-template <int... Is, class F> VD3D_DEV void static_for_impl(F&& f, IntC<0>, std::integer_sequence<int, Is...>) { (f(IntC<Is>{}), ...); }
-template <int N, class F> VD3D_DEV void static_for(F&& f) { static_for_impl(f, IntC<0>{}, std::make_integer_sequence<int, N>{}); }
-constexpr int kRwImg = kResStageBytes;            // 23 KiB: one 64-channel halo image of an 8 x 16 tile
-
-// RWRING = pixel-fragment ring depth (ds_read_b128 issued that many MFMAs ahead); ABL != 0: timing ablations of the tuning
-// build (WRONG results): 1 = no fragment reads, 2 = no halo DMA, 3 = neither
-template <int CIN, bool RES, int RWRING = 4, int ABL = 0>
-__global__ void __launch_bounds__(256) conv_regw_kernel(const ConvArgs p, int ntiles, int nslices) {
-    constexpr int kRwRing = RWRING;
-#ifdef VD3D_TUNING
-    int dbg_n = 0;
-#define RW_STAMP() do { if (ABL == 9 && blockIdx.x == 0 && threadIdx.x == 0 && dbg_n < 64) g_regw_dbg[dbg_n++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define RW_STAMP() do { } while (0)
-#endif
-    RW_STAMP();
-    static_assert(CIN == 128 || CIN == 256, "register-resident weights: 128 or 256 input channels");
-    constexpr int KG = CIN / 128;                 // K halves (waves that share an output block)
-    constexpr int CG = 4 / KG;                    // channel groups of 32 per workgroup
-    constexpr int CSL = CG * 32;                  // output channels per workgroup (slice)
-    constexpr int NSLOT = KG == 1 ? 4 : 2;        // LDS slots of one phase unit (KG images) each
-    constexpr int UNIT = KG * kRwImg;
-    constexpr int PIECES = KG * kResPiecesTot;    // 1 KiB DMA pieces per unit
-    constexpr int P = (PIECES + 3) / 4;           // per wave (overshoot repeats the wave's previous piece)
-    constexpr int RED_OFF = NSLOT * UNIT;         // K-half reduction buffer: CG x 16 KiB (KG == 2)
-    constexpr int RB_OFF = RED_OFF + (KG == 2 ? CG * 16384 : 0);   // residual tiles: CG x 8 KiB ([128 px][32 ch] per wave)
-    constexpr int SS_OFF = RB_OFF + (RES ? CG * 8192 : 0);
-    constexpr int NR = RES ? 8 : 0, NS = 8;       // residual DMA pieces / output stores per (epilogue) wave and tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = wave % CG, kg = wave / CG;
-    const int lr = lane & 31, half = lane >> 5;
-    const int tiles_x = (p.W + kResTW - 1) / kResTW, tiles_y = (p.H + kResTH - 1) / kResTH, tiles_img = tiles_x * tiles_y;
-    // blockIdx -> (slice, tile lane): blocks b, b + 8, b + 16, ... share an XCD; consecutive ones take the slices of one tile lane
-    const int bx = blockIdx.x, xcd = bx & 7, j8 = bx >> 3;
-    const int slice = j8 % nslices;
-    const int lanes_per_xcd = (int)(gridDim.x >> 3) / nslices;
-    const int tlane = xcd * lanes_per_xcd + j8 / nslices, tstride = 8 * lanes_per_xcd;
-    const int n_base = slice * CSL + cg * 32;      // first output channel of this wave
-
-    // ---- weights -> registers (MFMA A operand: row = output channel, 16 bytes = 8 k values; k = tap * CIN + c) ----------
-    i32x4 wf[72];
-    {
-        // register image [Cout/32][CIN/64][36][64][16 B]: 72 coalesced 1 KiB reads (chunks 2 * kg, 2 * kg + 1 of this wave's block)
-        const char* wimg = p.wfrag + ((((size_t)(n_base >> 5) * (CIN / 64) + 2 * kg) * 36) * 64 + lane) * 16;
-        static_for<72>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            wf[i] = *(const i32x4*)(wimg + i * 1024);
-        });
-    }
-    auto hkey = [](int row) { const int hy = row / kResHW2; return ((hy * kResTW + row - hy * kResHW2) >> 1) & 7; };
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x80000000u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.residual : p.out), 0, 0x80000000u, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    auto tile_origin = [&](int t, int& b, int& ty, int& tx) {
-        b = t / tiles_img;
-        const int trem = t - b * tiles_img;
-        ty = trem / tiles_x;
-        tx = trem - ty * tiles_x;
-    };
-    // unit u = 2 * k + ph of this workgroup's k-th tile: the images of chunk 2 * g + ph for every K half g, P pieces per wave.
-    // The pieces of unit u + NSLOT - 1 are issued ONE AT A TIME inside phase u's MFMA stream (a piece costs 60-180 issue
-    // cycles plus ~30 VALU of address arithmetic; in one burst they stall the only wave of the SIMD), into the slot the
-    // barrier at the end of phase u - 1 released.  Everything but the lane id is recomputed per piece: keeping per-piece
-    // lane state alive would cost 2 registers per piece.
-    struct UnitOrigin { int b, ty, tx, ph, slot; bool tv; };
-    auto unit_origin = [&](int u) {
-        UnitOrigin o;
-        const int k = u >> 1;
-        const int t = tlane + k * tstride;
-        o.ph = u & 1;
-        o.tv = t < ntiles;
-        o.slot = u % NSLOT;
-        tile_origin(o.tv ? t : 0, o.b, o.ty, o.tx);
-        return o;
-    };
-    auto issue_piece = [&](const UnitOrigin& o, int it) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));               // keeps the per-piece address arithmetic out of the loop-invariant set
-        int q = wave + it * 4;
-        if (q >= PIECES) q -= 4;                   // branch-free partial round: repeat the previous piece (same data)
-        const int g = q / kResPiecesTot, pi = q - g * kResPiecesTot;
-        const int hr = 8 * pi + (ln >> 3);
-        const int hy = hr / kResHW2, hx = hr - hy * kResHW2;
-        const int iy = o.ty * kResTH - 1 + hy, ix = o.tx * kResTW - 1 + hx;
-        const bool v = o.tv && hr < kResHR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const int col = (2 * g + o.ph) * 64 + ((ln & 7) ^ hkey(hr)) * 8;
-        // always computed; an out-of-image lane gets the top bit = out of range (a select the compiler cannot turn into an
-        // exec-masked branch inside the MFMA stream; in_bytes < 2^31)
-        const uint32_t off = ((uint32_t)(o.b * (int)p.in_batch_stride + iy * p.in_row_stride + ix * p.in_pix_stride + col) * 2u) | (v ? 0u : kOOB);
-        if constexpr (ABL != 2 && ABL != 3)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(smem + o.slot * UNIT + g * kRwImg + pi * 1024), 16, off, 0, 0, 0);
-    };
-    auto issue_unit = [&](int u) {
-        const UnitOrigin o = unit_origin(u);
-#pragma unroll
-        for (int it = 0; it < P; ++it) issue_piece(o, it);
-    };
-    // Residual of a wave's own 128 px x 32 ch output block -> its private 8 KiB LDS tile [128 px][64 B], by DMA (no registers
-    // held across the MFMA phases).  16-byte slot s of pixel px sits at physical slot s ^ (px & 3) ^ ((px >> 2) & 3): the
-    // epilogue's ds_read_b64 (32 pixels x one 8-byte half slot) then conflicts 2-way at most.
-    char* rb = smem + RB_OFF + cg * 8192;
-    auto issue_residual = [&](int b, int ty, int tx) {
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int pc = 0; pc < 8; ++pc) {
-            const int px = 16 * pc + (ln >> 2);
-            const int y = ty * kResTH + px / kResTW, x = tx * kResTW + (px & (kResTW - 1));
-            const int sl = (ln & 3) ^ (px & 3) ^ ((px >> 2) & 3);
-            const bool v = y < p.H && x < p.W;
-            const uint32_t off = v ? (uint32_t)(((((int64_t)b * p.H + y) * p.W + x) * p.res_pix_stride + n_base + sl * 8) * 2) : kOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(res_rsrc, (lds_ptr_t)(rb + pc * 1024), 16, off, 0, 0, 0);
-        }
-    };
-    // ---- fragment addressing (as resident64): byte = a_tap[tap] ^ (ks << 5), + 4608 per 32-pixel block, + image base ----
-    int a_tap[9];
-    {
-        const int hrow0 = (lr / kResTW) * kResHW2 + (lr & (kResTW - 1));
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int row = hrow0 + (tap / 3) * kResHW2 + (tap % 3);
-            a_tap[tap] = row * 128 + ((half ^ hkey(row)) << 4) + kg * kRwImg;
-        }
-    }
-    auto ld_frag = [&](int u, int m) {            // m = f * 4 + j within the unit
-        const int f = m >> 2, j = m & 3;
-        return *(const i32x4*)(smem + (u % NSLOT) * UNIT + j * 4608 + (a_tap[f >> 2] ^ ((f & 3) << 5)));
-    };
-    float* ss = (float*)(smem + SS_OFF);
-    if (tid < CSL) {
-        ss[tid] = p.scale ? p.scale[slice * CSL + tid] : 1.f;
-        ss[CSL + tid] = p.shift ? p.shift[slice * CSL + tid] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < NSLOT - 1; ++u) issue_unit(u);
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NSLOT - 2) * P) : "memory");   // unit 0 has landed (this wave's pieces) ...
-    __builtin_amdgcn_s_barrier();                                               // ... for every wave (and scale / shift are in LDS)
-    asm volatile("" ::: "memory");
-    i32x4 ring[kRwRing];
-#pragma unroll
-    for (int m = 0; m < kRwRing; ++m) ring[m] = ld_frag(0, m);
-    RW_STAMP();
-
-    const bool epi = kg == 0;                     // the waves that own the epilogue (KG == 2: the other half only contributes)
-    // VMEM queue of an epilogue wave, tile k:  R(k) [NR residual pieces, top]  D(2k + NSLOT - 1) [P, spread over phase 0]
-    // D(2k + NSLOT) [P, spread over phase 1]  S(k) [NS stores].  The other K half issues the D's only.
-    constexpr int STEP = KG == 1 ? 144 / P : 72 / P;      // MFMAs between two pieces (CIN 256: all in the first half of the phase,
-    static_assert(STEP >= 2, "piece spacing");             // its unit is needed at the end of the SAME phase)
-    int k = 0;
-    for (int t = tlane; t < ntiles; t += tstride, ++k) {
-        f32x16 acc[4];             // never zeroed: the first MFMA of a block takes C = 0
-        int b, ty, tx;
-        tile_origin(t, b, ty, tx);
-        if constexpr (RES) {
-            if (epi) issue_residual(b, ty, tx);
-        }
-        // one phase = one 64-channel chunk per K half; `ph` must be a compile-time constant (it selects weight REGISTERS), so the
-        // two phases are two instantiations of this lambda rather than a loop the unroller may decline to unroll
-        auto phase = [&](auto ph_c) {
-            constexpr int ph = decltype(ph_c)::value;
-            const int u = 2 * k + ph;
-            const UnitOrigin nxt = unit_origin(u + NSLOT - 1);
-            static_for<144>([&](auto mc) {
-                constexpr int m = decltype(mc)::value;
-                if constexpr (m % STEP == 1 && m / STEP < P) issue_piece(nxt, m / STEP);
-                if constexpr (m == 144 - kRwRing) {
-                    // every read of this unit has been issued (lgkmcnt(0): and is done); the next unit, D(u + 1), must have
-                    // landed: at most the VMEM ops issued AFTER it may still be in flight (steady state; the first two
-                    // tiles simply drain the queue).
-                    //   NSLOT 4:  D(u + 1) was issued during phase u - 2; younger: D(u + 2), D(u + 3), and one S / R pair
-                    //   NSLOT 2:  D(u + 1) was issued in the first half of THIS phase; nothing is younger
-                    if (k < 2 || NSLOT == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * P + NS + NR) : "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                }
-                constexpr int f = m >> 2, j = m & 3;
-                if constexpr (ph == 0 && f == 0) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[0]), __builtin_bit_cast(bf16x8, ring[m % kRwRing]), zero, 0, 0, 0);
-                } else
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[ph * 36 + f]), __builtin_bit_cast(bf16x8, ring[m % kRwRing]), acc[j], 0, 0, 0);
-                if constexpr (ABL != 1 && ABL != 3)
-                    ring[m % kRwRing] = m + kRwRing < 144 ? ld_frag(u, m + kRwRing) : ld_frag(u + 1, m + kRwRing - 144);
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            });
-        };
-        RW_STAMP();
-        phase(IntC<0>{});
-        RW_STAMP();
-        phase(IntC<1>{});
-        RW_STAMP();
-        if constexpr (KG == 2) {
-            // K halves: the upper half parks its partial sums in LDS (16 ds_write_b128, lane-linear), the lower half adds them
-            float* red = (float*)(smem + RED_OFF + cg * 16384);
-            if (!epi) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                        *(f32x4*)(red + ((j * 4 + g) * 64 + lane) * 4) = v;
-                    }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (epi) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = *(const f32x4*)(red + ((j * 4 + g) * 64 + lane) * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[j][4 * g + e] += v[e];
-                    }
-            }
-        }
-        if (epi) {
-            // ---- epilogue: scale/shift (+residual) (+ReLU), 2 x 16-byte NHWC stores per lane and block (half-wave pairing) ----
-            if constexpr (RES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P) : "memory");    // R(k) landed (own pieces only)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int px = 32 * j + lr;
-                const int y = ty * kResTH + px / kResTW, x = tx * kResTW + (px & (kResTW - 1));
-                const bool pin = y < p.H && x < p.W;
-                const uint32_t o_off = pin ? (uint32_t)(((((int64_t)b * p.H + y) * p.W + x) * p.out_pix_stride + n_base) * 2) : kOOB;
-                int pk[4][2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int nl = cg * 32 + 4 * half + 8 * g;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * g + e];
-                    const f32x4 sc = *(const f32x4*)(ss + nl), sh = *(const f32x4*)(ss + CSL + nl);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
-                    if constexpr (RES) {
-                        const i32x2 rr = *(const i32x2*)(rb + px * 64 + ((g ^ (px & 3) ^ ((px >> 2) & 3)) << 4) + 8 * half);
-                        const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
-                        v[0] += i2f((int)(r0 << 16));
-                        v[1] += i2f((int)(r0 & 0xffff0000u));
-                        v[2] += i2f((int)(r1 << 16));
-                        v[3] += i2f((int)(r1 & 0xffff0000u));
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    pk[g][0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-                    pk[g][1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g += 2) {
-                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
-                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
-                    i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
-                    const uint32_t off = pin ? o_off + 16 * (g + half) : kOOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
-                }
-            }
-            if constexpr (RES) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the residual tile is read before R(k + 1) overwrites it
-        }
-        RW_STAMP();
-    }
-    RW_STAMP();
-#undef RW_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs must not land in a successor workgroup's LDS
-}
-
-constexpr int regw_lds(int cin, bool res) {
-    const int cg = cin == 256 ? 2 : 4;
-    return 4 * kRwImg + (cin == 256 ? cg * 16384 : 0) + (res ? cg * 8192 : 0) + 2 * cg * 32 * 4;
-}
-
-template <int CIN, int RWRING = 4, int ABL = 0>
-int launch_regw(ConvArgs& a, hipStream_t stream) {
-    constexpr int CSL = CIN == 128 ? 128 : 64;
-    constexpr int LDS_R = regw_lds(CIN, true), LDS_N = regw_lds(CIN, false);
-    static Vd3dLdsLimit lim_res, lim_nores;
-    int rc = vd3d_raise_lds_limit((const void*)conv_regw_kernel<CIN, true, RWRING, ABL>, LDS_R, lim_res, "hipFuncSetAttribute(conv_regw)");
-    if (!rc) rc = vd3d_raise_lds_limit((const void*)conv_regw_kernel<CIN, false, RWRING, ABL>, LDS_N, lim_nores, "hipFuncSetAttribute(conv_regw)");
-    if (rc) return rc;
-    const int num_cu = vd3d_device_cu_count();
-    if (num_cu <= 0) return VD3D_ELAUNCH;
-    const int nslices = a.Cout / CSL;
-    const int ntiles = a.B * ((a.H + kResTH - 1) / kResTH) * ((a.W + kResTW - 1) / kResTW);
-    // grid = 8 XCDs x lanes x slices, at most one workgroup per CU, no more tile lanes than tiles
-    int lanes = num_cu / (8 * nslices);
-    const int need = (ntiles + 7) / 8;
-    if (lanes > need) lanes = need;
-    if (lanes < 1) lanes = 1;
-    const int grid = 8 * lanes * nslices;
-    if (a.residual) hipLaunchKernelGGL((conv_regw_kernel<CIN, true, RWRING, ABL>), dim3(grid), dim3(256), LDS_R, stream, a, ntiles, nslices);
-    else hipLaunchKernelGGL((conv_regw_kernel<CIN, false, RWRING, ABL>), dim3(grid), dim3(256), LDS_N, stream, a, ntiles, nslices);
-    return vd3d_check_launch("conv_regw");
-}
-
-static bool regw_shape_ok(const ConvArgs& a) {
-    const int csl = a.Cin == 128 ? 128 : 64;
-    return (a.Cin == 128 || a.Cin == 256) && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H &&
-           a.Wo == a.W && a.Cout % csl == 0 && a.Cout / csl <= 32 && a.wide_store && !a.out_f32 && a.wfrag &&
-           (int64_t)a.M * a.out_pix_stride * 2 < 0x7ffffff0ll && (!a.residual || (int64_t)a.M * a.res_pix_stride * 2 < 0x7ffffff0ll);
-}
-
-int launch_resident64(ConvArgs& a, hipStream_t stream) {
-    static Vd3dLdsLimit lim_res, lim_nores;
-    int rc = vd3d_raise_lds_limit((const void*)conv_resident64_kernel<true>, kResLds, lim_res, "hipFuncSetAttribute(conv_resident64)");
-    if (!rc) rc = vd3d_raise_lds_limit((const void*)conv_resident64_kernel<false>, kResLds, lim_nores, "hipFuncSetAttribute(conv_resident64)");
-    if (rc) return rc;
-    const int num_cu = vd3d_device_cu_count();
-    if (num_cu <= 0) return VD3D_ELAUNCH;
-    const int ntiles = a.B * ((a.H + kResTH - 1) / kResTH) * ((a.W + kResTW - 1) / kResTW);
-    const int grid = ntiles < num_cu ? ntiles : num_cu;
-    if (a.residual) hipLaunchKernelGGL(conv_resident64_kernel<true>, dim3(grid), dim3(512), kResLds, stream, a, ntiles);
-    else hipLaunchKernelGGL(conv_resident64_kernel<false>, dim3(grid), dim3(512), kResLds, stream, a, ntiles);
-    return vd3d_check_launch("conv_resident64");
-}
 
 template <typename T, int TH, int TW, int BN, int WARPS_M, int WARPS_N, int STAGES = 4>
 int launch_halo(ConvArgs& a, hipStream_t stream) {
@@ -1497,7 +933,7 @@ static int forced_tile_error(const char* why) {
 
 template <typename T>
 int dispatch(ConvArgs& a, hipStream_t stream) {
-    constexpr bool kBf16 = sizeof(T) == 2;
+    constexpr bool kBf16 = sizeof(T) == 2;      // a 16-bit format (bf16 or fp16): the 16x16x32 tiles and the halo / resident kernels
     const bool halo_shape = a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W &&
                             a.Cin % (128 / (int)sizeof(T)) == 0;
 #define VD3D_BF16_ONLY(...) do { if constexpr (kBf16) return __VA_ARGS__; else return forced_tile_error("is a bf16-only tile"); } while (0)
@@ -1526,19 +962,19 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 61:
             if constexpr (kBf16) {
                 if (!regw_shape_ok(a)) return forced_tile_error("needs bf16 3x3 / stride 1 / pad 1, Cin 128 | 256, Cout a multiple of the channel slice");
-                return a.Cin == 128 ? launch_regw<128>(a, stream) : launch_regw<256>(a, stream);
+                return launch_regw(a, stream, std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16);
             } else return forced_tile_error("is a bf16-only tile");
 #ifdef VD3D_TUNING
         case 62: case 63: case 64: case 65: case 66: case 67:
             if constexpr (kBf16) {
                 if (!regw_shape_ok(a) || a.Cin != 128) return forced_tile_error("regw experiments: Cin 128 only");
                 switch (g_force_cfg) {
-                    case 62: return launch_regw<128, 8>(a, stream);
-                    case 63: return launch_regw<128, 4, 1>(a, stream);
-                    case 64: return launch_regw<128, 4, 2>(a, stream);
-                    case 65: return launch_regw<128, 4, 3>(a, stream);
-                    case 67: return launch_regw<128, 4, 9>(a, stream);
-                    default: return launch_regw<128, 2>(a, stream);
+                    case 62: return launch_regw(a, stream, VD3D_BF16, 8, 0);
+                    case 63: return launch_regw(a, stream, VD3D_BF16, 4, 1);
+                    case 64: return launch_regw(a, stream, VD3D_BF16, 4, 2);
+                    case 65: return launch_regw(a, stream, VD3D_BF16, 4, 3);
+                    case 67: return launch_regw(a, stream, VD3D_BF16, 4, 9);
+                    default: return launch_regw(a, stream, VD3D_BF16, 2, 0);
                 }
             } else return forced_tile_error("is a bf16-only tile");
         case 1: return launch<T, 128, 128, 2, 2>(a, stream);
@@ -1569,18 +1005,19 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
 #endif
         default: return forced_tile_error("is not a tile of this build");
     }
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, short>::value || std::is_same<T, hf16>::value) {
         // register-resident weights (v6): Cin 128 always (+25 % over the 8x32x128 halo tile on ResNet layer2); Cin 256 only
         // when the 128-pixel x 256-channel halo tiles would leave CUs idle (the 256 -> 256 cls conv at 8 x 24 x 80: 120 tiles;
         // +40 % there, but -6 % on layer3 whose 240 halo tiles fill the chip)
+        constexpr int fmt = std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16;
         if (g_force_cfg != 60 && regw_shape_ok(a)) {
-            if (a.Cin == 128) return launch_regw<128>(a, stream);
+            if (a.Cin == 128) return launch_regw(a, stream, fmt);
             const int64_t halo_tiles = (int64_t)a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16) * ((a.Cout + 255) / 256);
-            if (halo_tiles * 4 < (int64_t)vd3d_device_cu_count() * 3) return launch_regw<256>(a, stream);
+            if (halo_tiles * 4 < (int64_t)vd3d_device_cu_count() * 3) return launch_regw(a, stream, fmt);
         }
         if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
             a.wide_store && !a.out_f32)
-            return launch_resident64(a, stream);
+            return launch_resident64(a, stream, fmt);
     }
     // Cout <= 32: 8 waves of 32 pixels x 32 channels, pipelined loop (+8 % on the ghost 24 -> 24 conv, +27 % on KM3D's 64 -> 27
     // offset convs over the 4-wave barrier-per-slice version)
@@ -1680,11 +1117,6 @@ extern "C" int vd3d_conv2d_set_tuning(int cfg) {
     return VD3D_OK;
 }
 
-#ifdef VD3D_TUNING
-extern "C" int vd3d_tuning_regw_stamps(unsigned long long* out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_regw_dbg), sizeof(unsigned long long) * (n < 64 ? n : 64)) == hipSuccess ? 0 : 1;
-}
-#endif
 
 extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
     // keep in step with the "production tiles" block of dispatch()
@@ -1696,7 +1128,7 @@ extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
 
 static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     if (!p || !p->in || !p->weight || !p->out) { vd3d_set_error("conv2d_igemm: null pointer"); return VD3D_EINVAL; }
-    const int es = p->dtype == VD3D_BF16 ? 2 : (p->dtype == VD3D_F32 ? 4 : 0);
+    const int es = (p->dtype == VD3D_BF16 || p->dtype == VD3D_F16) ? 2 : (p->dtype == VD3D_F32 ? 4 : 0);
     if (!es) { vd3d_set_error("conv2d_igemm: bad dtype"); return VD3D_EINVAL; }
     const int ve = 16 / es, bke = 128 / es;
     // every 16-byte vector must start on a 16-byte boundary: normally the pixel stride is a vector multiple; the
@@ -1748,13 +1180,13 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
     const int rc = fill_conv_args(p, a);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : dispatch<float>(a, s);
+    return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : (p->dtype == VD3D_F16 ? dispatch<hf16>(a, s) : dispatch<float>(a, s));
 }
 
 extern "C" int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_packed, const float* b2, void* const* outs,
                                     const int32_t* n_out, int n_heads, void* stream) {
     if (!p || !w2_packed || !b2 || !outs || !n_out) { vd3d_set_error("km3d_head_fused: null pointer"); return VD3D_EINVAL; }
-    if (n_heads < 1 || n_heads > 9 || p->dtype != VD3D_BF16 || p->Cout != 256 * n_heads || p->kh != 3 || p->kw != 3 || p->stride != 1 ||
+    if (n_heads < 1 || n_heads > 9 || (p->dtype != VD3D_BF16 && p->dtype != VD3D_F16) || p->Cout != 256 * n_heads || p->kh != 3 || p->kw != 3 || p->stride != 1 ||
         p->pad != 1 || p->dil != 1 || p->Cin % 64 || !p->shift || p->scale || p->residual || ((uintptr_t)w2_packed & 15)) {
         vd3d_set_error("km3d_head_fused: needs bf16, 3x3/s1/p1, Cin % 64 == 0, Cout = 256 x heads (<= 9), bias only");
         return VD3D_EINVAL;
@@ -1772,5 +1204,6 @@ extern "C" int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_pa
         a.h_out[h] = (float*)outs[h];
         a.h_n[h] = n_out[h];
     }
+    if (p->dtype == VD3D_F16) return launch<hf16, 256, 256, 2, 4, true, true, 32, 0, 0, true>(a, (hipStream_t)stream);
     return launch<short, 256, 256, 2, 4, true, true, 32, 0, 0, true>(a, (hipStream_t)stream);
 }

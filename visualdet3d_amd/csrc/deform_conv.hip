@@ -37,15 +37,14 @@ struct DcnArgs {
 template <typename T> VD3D_DEV float ld(const void* p, int64_t i);
 template <> VD3D_DEV float ld<float>(const void* p, int64_t i) { return ((const float*)p)[i]; }
 template <> VD3D_DEV float ld<short>(const void* p, int64_t i) { return bf2f(((const short*)p)[i]); }
+template <> VD3D_DEV float ld<hf16>(const void* p, int64_t i) { return h2f(((const hf16*)p)[i]); }
 template <typename T> VD3D_DEV void st(void* p, int64_t i, float v);
 template <> VD3D_DEV void st<float>(void* p, int64_t i, float v) { ((float*)p)[i] = v; }
 template <> VD3D_DEV void st<short>(void* p, int64_t i, float v) { ((short*)p)[i] = f2bf(v); }
+template <> VD3D_DEV void st<hf16>(void* p, int64_t i, float v) { ((hf16*)p)[i] = f2h(v); }
 
-template <typename T> struct DMma;
-template <> struct DMma<short> {
-    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
-    }
+template <typename T> struct DMma {         // 16-bit formats (bf16 | fp16)
+    static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) { Fmt16<T>::mfma32(a, b, acc); }
 };
 template <> struct DMma<float> {
     static VD3D_DEV void run(const i32x4& a, const i32x4& b, f32x16& acc) {
@@ -425,8 +424,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
             if (oc + 3 < p.O && ((ob + oc) * ES) % (4 * ES) == 0) {
                 if constexpr (sizeof(T) == 2) {
                     i32x2 o2;
-                    o2[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
-                    o2[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
+                    o2[0] = Fmt16<T>::pack2(v[0], v[1]);
+                    o2[1] = Fmt16<T>::pack2(v[2], v[3]);
                     *(i32x2*)((char*)p.out + (ob + oc) * 2) = o2;
                 } else {
                     *(f32x4*)((char*)p.out + (ob + oc) * 4) = f32x4{v[0], v[1], v[2], v[3]};
@@ -459,14 +458,14 @@ int dispatch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
 
 int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
     if (!q || !q->in || !q->weight || !q->offset || !q->out) { vd3d_set_error("deform_conv: null pointer"); return VD3D_EINVAL; }
-    if (q->dtype != VD3D_BF16 && q->dtype != VD3D_F32) { vd3d_set_error("deform_conv: bad dtype"); return VD3D_EINVAL; }
+    if (q->dtype != VD3D_BF16 && q->dtype != VD3D_F16 && q->dtype != VD3D_F32) { vd3d_set_error("deform_conv: bad dtype"); return VD3D_EINVAL; }
     if (q->groups < 1 || q->deformable_groups < 1 || q->C % q->groups || q->O % q->groups || q->C % q->deformable_groups) {
         vd3d_set_error("deform_conv: channels must divide by groups / deformable_groups");
         return VD3D_EINVAL;
     }
     const int Og = q->O / q->groups;
     if (q->groups > 1 && Og % 64) { vd3d_set_error("deform_conv: groups > 1 needs out-channels per group to be a multiple of 64"); return VD3D_EINVAL; }
-    const int es = q->dtype == VD3D_BF16 ? 2 : 4, bke = 128 / es;
+    const int es = q->dtype == VD3D_F32 ? 4 : 2, bke = 128 / es;
     DcnArgs a;
     a.in = q->in; a.w = q->weight; a.bias = q->bias; a.scale = q->scale; a.shift = q->shift; a.offset = q->offset; a.mask = q->mask; a.out = q->out;
     a.B = q->B; a.C = q->C; a.H = q->H; a.W = q->W; a.O = q->O;
@@ -486,9 +485,10 @@ int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
     if (a.groups == 1 && a.dgroups == 1 && a.in_sc == 1 && a.out_sc == 1 && a.Cg % bke == 0 && ((uintptr_t)q->in & 15) == 0 &&
         (int64_t)a.H * a.in_sy * es < 0x7fffffffll && 64 * a.kh * a.kw * 48 + 2 * (64 + 256) * 128 <= 160 * 1024 &&
         a.in_sx % (16 / es) == 0 && a.in_sy % (16 / es) == 0 && a.in_sb % (16 / es) == 0 && !getenv("VD3D_DCN_GENERIC"))
-        return q->dtype == VD3D_BF16 ? dispatch_dcn_nhwc<short>(a, s) : dispatch_dcn_nhwc<float>(a, s);
+        return q->dtype == VD3D_BF16 ? dispatch_dcn_nhwc<short>(a, s) : (q->dtype == VD3D_F16 ? dispatch_dcn_nhwc<hf16>(a, s) : dispatch_dcn_nhwc<float>(a, s));
     dim3 grid((a.Ho * a.Wo + 63) / 64, (q->O + 63) / 64, q->B);
     if (q->dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_kernel<short>, grid, dim3(256), 0, s, a);
+    else if (q->dtype == VD3D_F16) hipLaunchKernelGGL(dcn_kernel<hf16>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(dcn_kernel<float>, grid, dim3(256), 0, s, a);
     return vd3d_check_launch("deform_conv");
 }
@@ -515,6 +515,7 @@ extern "C" int vd3d_dcn_pack_weight(const float* w_oihw, void* packed, int O, in
     const int64_t total = (int64_t)O * Kpad;
     const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_pack_weight_kernel<short>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (short*)packed, O, Cg, kh * kw, Kpad);
+    else if (dtype == VD3D_F16) hipLaunchKernelGGL(dcn_pack_weight_kernel<hf16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (hf16*)packed, O, Cg, kh * kw, Kpad);
     else if (dtype == VD3D_F32) hipLaunchKernelGGL(dcn_pack_weight_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, (float*)packed, O, Cg, kh * kw, Kpad);
     else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }
     return vd3d_check_launch("dcn_pack_weight");

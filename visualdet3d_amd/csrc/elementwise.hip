@@ -27,8 +27,8 @@ __global__ void pack_image_kernel(const float* __restrict__ in, T* __restrict__ 
         }
         if constexpr (sizeof(T) == 2) {
             i32x2 o;
-            o[0] = (int)((uint32_t)(uint16_t)f2bf(v0) | ((uint32_t)(uint16_t)f2bf(v1) << 16));
-            o[1] = (int)((uint32_t)(uint16_t)f2bf(v2));
+            o[0] = Fmt16<T>::pack2(v0, v1);
+            o[1] = Fmt16<T>::pack2(v2, 0.f);
             *(i32x2*)(out + i * 4) = o;
         } else {
             f32x4 o = {v0, v1, v2, 0.f};
@@ -197,11 +197,12 @@ inline int grid_for(int64_t total) {
     return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
 }
 inline bool vec_ok(int dtype, int C, int s1, int s2, const void* a, const void* b) {
-    const int ve = dtype == VD3D_BF16 ? 8 : 4;
+    const int ve = dtype == VD3D_F32 ? 4 : 8;
     return (C % ve == 0) && (s1 % ve == 0) && (s2 % ve == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)b & 15) == 0);
 }
 #define VD3D_DISPATCH(dtype, ...)                         \
     if ((dtype) == VD3D_BF16) { using T = short; __VA_ARGS__; } \
+    else if ((dtype) == VD3D_F16) { using T = hf16; __VA_ARGS__; } \
     else if ((dtype) == VD3D_F32) { using T = float; __VA_ARGS__; } \
     else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }
 
@@ -220,7 +221,7 @@ extern "C" int vd3d_pack_image_nhwc4(const float* in, void* out, int B, int H, i
 extern "C" int vd3d_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int ips, int ops, int dtype, void* stream) {
     if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("maxpool: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_F32 ? 4 : 8));
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(maxpool3x3s2_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, (T*)out, B, H, W, C, Ho, Wo, ips, ops));
     return vd3d_check_launch("maxpool3x3s2");
@@ -229,7 +230,7 @@ extern "C" int vd3d_maxpool3x3s2(const void* in, void* out, int B, int H, int W,
 extern "C" int vd3d_avgpool2x2(const void* in, void* out, int B, int H, int W, int C, int ips, int ops, int dtype, void* stream) {
     if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("avgpool: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
     const int Ho = H / 2, Wo = W / 2;
-    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_F32 ? 4 : 8));
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(avgpool2x2_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, (T*)out, B, H, W, C, Ho, Wo, ips, ops));
     return vd3d_check_launch("avgpool2x2");
@@ -238,7 +239,7 @@ extern "C" int vd3d_avgpool2x2(const void* in, void* out, int B, int H, int W, i
 extern "C" int vd3d_dwconv3x3(const void* in, const float* weight, const float* scale, const float* shift, void* out,
                               int B, int H, int W, int C, int ips, int ops, int relu, int dtype, void* stream) {
     if (!vec_ok(dtype, C, ips, ops, in, out) || !weight || !scale || !shift) { vd3d_set_error("dwconv3x3: bad args"); return VD3D_EINVAL; }
-    const int64_t total = (int64_t)B * H * W * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    const int64_t total = (int64_t)B * H * W * (C / (dtype == VD3D_F32 ? 4 : 8));
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(dwconv3x3_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, weight, scale, shift, (T*)out, B, H, W, C, ips, ops, relu));
     return vd3d_check_launch("dwconv3x3");
@@ -246,7 +247,7 @@ extern "C" int vd3d_dwconv3x3(const void* in, const float* weight, const float* 
 
 extern "C" int vd3d_copy_channels(const void* in, void* out, int64_t n_pix, int C, int ips, int ops, int dtype, void* stream) {
     if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("copy_channels: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
-    const int64_t total = n_pix * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    const int64_t total = n_pix * (C / (dtype == VD3D_F32 ? 4 : 8));
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(copy_channels_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, (T*)out, n_pix, C, ips, ops));
     return vd3d_check_launch("copy_channels");
@@ -327,7 +328,7 @@ __global__ void look_ground_kernel(const T* __restrict__ x, const float* __restr
 
 extern "C" int vd3d_look_ground_sample(const void* x, const float* disp, const float* P2s, void* out, int B, int H, int W,
                                        int C, int ips, int ops, float baseline, float elevation, int dtype, void* stream) {
-    const int ve = dtype == VD3D_BF16 ? 8 : 4;
+    const int ve = dtype == VD3D_F32 ? 4 : 8;
     const int Cpad = (C + 1 + ve - 1) / ve * ve;
     if (!x || !disp || !P2s || !out || C % ve || ips % ve || ops % ve || ops < Cpad || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) {
         vd3d_set_error("look_ground_sample: C, strides must be 16-byte multiples; out needs round_up(C+1) channels");
@@ -412,7 +413,7 @@ __global__ void dwconvT_kernel(const T* __restrict__ in, const float* __restrict
             if (add) {
                 Vec16<T> a; a.raw = *(const i32x4*)(add + pix * aps + c);
 #pragma unroll
-                for (int e = 0; e < VE; ++e) s[e] = bf2f(f2bf(s[e])) + a.get(e);
+                for (int e = 0; e < VE; ++e) s[e] = ElemTraits<T>::to_f(ElemTraits<T>::from_f(s[e])) + a.get(e);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) o.set2(e, s[2 * e], s[2 * e + 1]);
@@ -451,7 +452,7 @@ __global__ void pack_image_c_kernel(const float* __restrict__ in, T* __restrict_
 extern "C" int vd3d_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int ips, int ops, int dtype, void* stream) {
     if (!vec_ok(dtype, C, ips, ops, in, out)) { vd3d_set_error("maxpool2x2: channels/strides must be 16-byte multiples"); return VD3D_EINVAL; }
     const int Ho = H / 2, Wo = W / 2;
-    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_F32 ? 4 : 8));
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(maxpool2x2_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, (T*)out, B, H, W, C, Ho, Wo, ips, ops));
     return vd3d_check_launch("maxpool2x2");
@@ -459,12 +460,12 @@ extern "C" int vd3d_maxpool2x2(const void* in, void* out, int B, int H, int W, i
 
 extern "C" int vd3d_dwconv_transpose(const void* in, const float* weight, const void* add, void* out, int B, int H, int W, int C,
                                      int f, int ips, int aps, int ops, int dtype, void* stream) {
-    if (!vec_ok(dtype, C, ips, ops, in, out) || !weight || f < 1 || (add && (((uintptr_t)add & 15) || aps % (dtype == VD3D_BF16 ? 8 : 4)))) {
+    if (!vec_ok(dtype, C, ips, ops, in, out) || !weight || f < 1 || (add && (((uintptr_t)add & 15) || aps % (dtype == VD3D_F32 ? 4 : 8)))) {
         vd3d_set_error("dwconv_transpose: bad args"); return VD3D_EINVAL;
     }
     const int K = 2 * f, pad = f / 2;
     const int Ho = (H - 1) * f - 2 * pad + K, Wo = (W - 1) * f - 2 * pad + K;
-    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_BF16 ? 8 : 4));
+    const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_F32 ? 4 : 8));
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(dwconvT_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, weight, (const T*)add, (T*)out, B, H, W, C, f, K, pad, Ho, Wo, ips, aps, ops));
     return vd3d_check_launch("dwconv_transpose");
@@ -478,6 +479,8 @@ extern "C" int vd3d_pack_image_nhwc(const float* in, void* out, int B, int H, in
     hipStream_t s = (hipStream_t)stream;
     if (dtype == VD3D_BF16 && cpad == 8) hipLaunchKernelGGL((pack_image_c_kernel<short, 8>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (short*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
     else if (dtype == VD3D_BF16) hipLaunchKernelGGL((pack_image_c_kernel<short, 4>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (short*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
+    else if (dtype == VD3D_F16 && cpad == 8) hipLaunchKernelGGL((pack_image_c_kernel<hf16, 8>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (hf16*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
+    else if (dtype == VD3D_F16) hipLaunchKernelGGL((pack_image_c_kernel<hf16, 4>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (hf16*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
     else if (dtype == VD3D_F32 && cpad == 8) hipLaunchKernelGGL((pack_image_c_kernel<float, 8>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (float*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
     else if (dtype == VD3D_F32) hipLaunchKernelGGL((pack_image_c_kernel<float, 4>), dim3(grid_for(total)), dim3(kThreads), 0, s, in, (float*)out, B, H, W, pad_y0, pad_l, Hp, Wp);
     else { vd3d_set_error("bad dtype"); return VD3D_EINVAL; }

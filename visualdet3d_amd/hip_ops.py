@@ -10,15 +10,22 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import VD3D_BF16, VD3D_F32, ConvParams, HeadParams, check
+from ._lib import VD3D_BF16, VD3D_F16, VD3D_F32, ConvParams, HeadParams, check
 
 
 def dtype_code(dt):
     if dt == torch.bfloat16:
         return VD3D_BF16
+    if dt == torch.float16:
+        return VD3D_F16
     if dt == torch.float32:
         return VD3D_F32
-    raise TypeError('HIP path supports bfloat16 / float32 activations, got %s' % dt)
+    raise TypeError('HIP path supports bfloat16 / float16 / float32 activations, got %s' % dt)
+
+
+def is16(dt):
+    """bf16 or fp16: the two 16-bit storage formats (same kernels, vector widths and MFMA rate)."""
+    return dt in (torch.bfloat16, torch.float16)
 
 
 def _stream():
@@ -84,8 +91,8 @@ def pack_conv(weight, bias=None, bn=None, dtype=torch.bfloat16, stride=1, pad=0,
     buffer then has that many channels)."""
     O, I, kh, kw = weight.shape
     dev = weight.device
-    ve = 8 if dtype == torch.bfloat16 else 4
-    bke = 64 if dtype == torch.bfloat16 else 32
+    ve = 8 if is16(dtype) else 4
+    bke = 64 if is16(dtype) else 32
     Cin = cin_pad or I
     assert Cin % ve == 0, 'input channels must be a multiple of %d for %s' % (ve, dtype)
     w = weight.detach().float().permute(0, 2, 3, 1)  # O, kh, kw, I
@@ -98,7 +105,7 @@ def pack_conv(weight, bias=None, bn=None, dtype=torch.bfloat16, stride=1, pad=0,
     packed[:O, :K] = w.reshape(O, K).to(dtype)
     scale, shift = fold_bn(bias, bn, O, dev)
     pc = PackedConv(packed, scale, shift, Cin, O, kh, kw, stride, pad, dil, Kpad, CoutPad, dtype)
-    if dtype == torch.bfloat16 and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and Cin in (64, 128, 256) and O % 32 == 0:
+    if is16(dtype) and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and Cin in (64, 128, 256) and O % 32 == 0:
         # register image for the resident-weight kernels (layout: include/vd3d.h, vd3d_conv_params.weight_frag):
         # [O/32][Cin/64][tap*4 + ks][half*32 + lr][8]  <-  w[32*nb + lr][tap][64*kc + (2*ks + half)*8 + e]
         w7 = w.reshape(O // 32, 32, 9, Cin // 64, 4, 2, 8)                 # nb, lr, tap, kc, ks, half, e
@@ -117,7 +124,7 @@ def pack_stem_conv(weight, bn, dtype):
     w = torch.zeros((O, 7, 8, 4), dtype=torch.float32, device=dev)
     w[:, :, :7, :3] = weight.detach().float().permute(0, 2, 3, 1)
     K = 7 * 32
-    bke = 64 if dtype == torch.bfloat16 else 32
+    bke = 64 if is16(dtype) else 32
     Kpad = (K + bke - 1) // bke * bke
     CoutPad = (O + 127) // 128 * 128
     packed = torch.zeros((CoutPad, Kpad), dtype=dtype, device=dev)
@@ -436,7 +443,7 @@ def pack_dcn_weight(weight, dtype):
     """OIHW fp32 -> [O][Kpad] tap-major in ``dtype`` (device kernel)."""
     _require_cuda(weight)
     O, Cg, kh, kw = weight.shape
-    bke = 64 if dtype == torch.bfloat16 else 32
+    bke = 64 if is16(dtype) else 32
     Kpad = (kh * kw * Cg + bke - 1) // bke * bke
     w = weight.detach().float().contiguous()
     packed = torch.empty((O, Kpad), dtype=dtype, device=weight.device)
@@ -518,7 +525,7 @@ def pack_image_conv(weight, bn, dtype, stride, pad):
     w[:, :, :kw, :3] = weight.detach().float().permute(0, 2, 3, 1)
     row = 8 * cpad
     K = kh * row
-    bke = 64 if dtype == torch.bfloat16 else 32
+    bke = 64 if is16(dtype) else 32
     Kpad = (K + bke - 1) // bke * bke
     CoutPad = (O + 127) // 128 * 128
     packed = torch.zeros((CoutPad, Kpad), dtype=dtype, device=dev)
@@ -563,7 +570,7 @@ def image_conv(img_nchw, pc, relu=True):
 
 
 def packed_elem_size(dtype):
-    return 2 if dtype == torch.bfloat16 else 4
+    return 2 if is16(dtype) else 4
 
 
 def maxpool2x2(x):
@@ -672,8 +679,8 @@ def km3d_head_fused(x, pc_first, w2_packed, b2, n_out):
     _require_cuda(x, pc_first.w, w2_packed, b2)
     B, H, W, Cx = x.shape
     heads = len(n_out)
-    assert x.dtype == torch.bfloat16 and pc_first.dtype == torch.bfloat16 and Cx == pc_first.Cin and pc_first.Cout == 256 * heads
-    assert w2_packed.shape == (heads, 32, 256) and w2_packed.dtype == torch.bfloat16 and w2_packed.is_contiguous()
+    assert is16(x.dtype) and pc_first.dtype == x.dtype and Cx == pc_first.Cin and pc_first.Cout == 256 * heads
+    assert w2_packed.shape == (heads, 32, 256) and w2_packed.dtype == x.dtype and w2_packed.is_contiguous()
     assert b2.shape == (heads, 32) and b2.dtype == torch.float32 and b2.is_contiguous() and pc_first.scale is None
     outs = [torch.empty((B, H, W, int(n)), dtype=torch.float32, device=x.device) for n in n_out]
     ips, irs, ibs = _nhwc_strides(x)

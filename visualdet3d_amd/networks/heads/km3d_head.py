@@ -77,7 +77,7 @@ class KM3DHead(nn.Module):
         pc = self._cache.get(('first', dt), srcs, build_first)
         F_ = firsts[0].out_channels
         lasts = [self.head_layers[n][2] for n in names]
-        if (self.fuse_head and dt == torch.bfloat16 and F_ == 256 and len(names) <= 9 and x.shape[3] % 64 == 0
+        if (self.fuse_head and ops.is16(dt) and F_ == 256 and len(names) <= 9 and x.shape[3] % 64 == 0
                 and all(c.out_channels <= 32 for c in lasts)):
             # one launch: the nine 3x3 convs as a single GEMM whose epilogue applies ReLU and the head's 1x1 conv; the
             # [B,H,W,9*256] intermediate (4 GB at 16 x 128 x 440) is never written
@@ -87,7 +87,7 @@ class KM3DHead(nn.Module):
                 for i, c in enumerate(lasts):
                     w2[i, :c.out_channels] = c.weight.detach().float().reshape(c.out_channels, F_)
                     b2[i, :c.out_channels] = c.bias.detach().float()
-                return w2.to(torch.bfloat16).contiguous(), b2.contiguous()
+                return w2.to(dt).contiguous(), b2.contiguous()
 
             w2, b2 = self._cache.get(('second_fused', dt), [t for c in lasts for t in (c.weight, c.bias)], build_second)
             outs = ops.km3d_head_fused(x, pc, w2, b2, [c.out_channels for c in lasts])

@@ -11,9 +11,10 @@ _DEFAULT_DTYPE = torch.bfloat16
 
 
 def set_default_compute_dtype(dtype):
-    """bf16 (default; BASELINE configs) or fp32 (strict-tolerance validation mode)."""
+    """bf16 (default; BASELINE configs 2-4), fp16 (BASELINE config 5: KM3D and the mono detectors; the stereo-only kernels --
+    PSM cosine volume, 3-D cost-volume convs -- are bf16 / fp32) or fp32 (strict-tolerance validation mode)."""
     global _DEFAULT_DTYPE
-    assert dtype in (torch.bfloat16, torch.float32)
+    assert dtype in (torch.bfloat16, torch.float16, torch.float32)
     _DEFAULT_DTYPE = dtype
 
 

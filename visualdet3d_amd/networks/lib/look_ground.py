@@ -29,7 +29,7 @@ class LookGround(nn.Module):
         conv = self.disp_create[0]
         pcd = self._cache.get(('disp', dt), [conv.weight, conv.bias], lambda: ops.pack_conv(conv.weight, conv.bias, None, dt, 1, 1, 1))
         disp = ops.conv2d(x, pcd, relu=False, out_f32=True)  # [B,H,W,1] fp32
-        ve = 8 if dt == torch.bfloat16 else 4
+        ve = 8 if ops.is16(dt) else 4
         cpad = (Cc + 1 + ve - 1) // ve * ve
         sampled = torch.empty((B, H, W, cpad), dtype=dt, device=x.device)
         P2 = P2.to(device=x.device, dtype=torch.float32).contiguous()
