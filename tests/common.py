@@ -77,3 +77,29 @@ def mono_case_from_golden(g, name):
     img = syn.mono_image(frames, H, W, seed=iseed)
     P2, _ = syn.kitti_calib(W, batch=frames)
     return cfg, (img, P2), dict(seed=wseed, head_std=float(g['head_std']))
+
+
+def matched_fraction(got, want, rtol):
+    """Greedy ONE-TO-ONE matching of detections (same label, every box field and the score within ``rtol`` of the field's scale),
+    closest pairs first: the fraction of expected detections that found a partner.  For the reduced-precision end-to-end
+    comparisons of the keypoint detector, whose ~100 detections per frame contain near-duplicates (a positional matching with a
+    loose tolerance would pair two expected detections with the same result)."""
+    gs, gb, gl = [torch.as_tensor(np.asarray(x)) for x in got]
+    ws, wb, wl = [torch.as_tensor(np.asarray(x)) for x in want]
+    gl, wl = gl.long().reshape(-1), wl.long().reshape(-1)
+    if ws.numel() == 0:
+        return 1.0
+    if gs.numel() == 0:
+        return 0.0
+    scale = torch.cat([wb.abs().double().amax(dim=0).clamp_min(1.0), torch.ones(1, dtype=torch.double)])
+    G = torch.cat([gb.double(), gs.double().reshape(-1, 1)], dim=1) / scale
+    Wt = torch.cat([wb.double(), ws.double().reshape(-1, 1)], dim=1) / scale
+    err = (G[None, :, :] - Wt[:, None, :]).abs().amax(dim=2)          # [want, got]
+    err[wl[:, None] != gl[None, :]] = float('inf')
+    pairs = sorted((float(err[i, j]), i, j) for i in range(err.shape[0]) for j in range(err.shape[1]) if err[i, j] <= rtol)
+    used_w, used_g = set(), set()
+    for e, i, j in pairs:
+        if i not in used_w and j not in used_g:
+            used_w.add(i)
+            used_g.add(j)
+    return len(used_w) / float(err.shape[0])

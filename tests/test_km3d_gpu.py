@@ -8,7 +8,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import detector_oracle as orc
-from tests.common import assert_detections_close, load_golden, rel_err, subsample
+from tests.common import assert_detections_close, load_golden, rel_err, subsample, matched_fraction
 from tests.test_km3d_oracle_golden import km3d_case_from_golden
 from visualdet3d_amd.utils import synthetic as syn
 
@@ -176,5 +176,6 @@ def test_fp16_mode_config5_vs_fp16_oracle_and_reference_golden():
         s, b, l = [t.cpu() for t in outs[f]]
         # (the keypoint decode -- peaks, top-K, keypoint association, 16x3 least squares -- amplifies a 6e-3 map difference;
         # of ~100 detections per frame a handful sit on a top-K / association threshold)
-        assert_detections_close((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=6e-2,
-                                what='fp16 frame %d' % f, allow_missing=6)
+        frac = matched_fraction((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=3e-2)
+        print('[KM3D fp16] frame %d: %d detections (reference %d), %.0f %% matched one-to-one within 3e-2' % (f, len(s), len(g['f%d_scores' % f]), 100 * frac))
+        assert abs(len(s) - len(g['f%d_scores' % f])) <= 5 and frac >= 0.9

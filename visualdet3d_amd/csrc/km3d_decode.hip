@@ -46,10 +46,15 @@ __global__ void km3d_zero_kernel(int32_t* a, int n) {
 }
 
 // ---- 1. peaks -----------------------------------------------------------------------------------------------------
-// One (sample, channel) per blockIdx.y, consecutive pixels per lane: the append is wave-aggregated (one atomicAdd per wave and
-// channel instead of one per peak -- with many candidates, e.g. untrained weights, per-peak atomics on B x 12 counters
-// serialise the whole kernel).  The order inside a list is irrelevant: the top-K kernel sorts it.
+// One (sample, channel) per blockIdx.y; a workgroup owns kPeakSpan consecutive pixels, collects its peaks in LDS (wave-aggregated
+// LDS append) and reserves room in the channel's global list with ONE atomicAdd.  (One global atomic per wave and iteration --
+// the first version -- put ~900 atomics on each of the B x 12 counters: with many candidates, e.g. untrained weights, those
+// serialised into 0.7 ms per launch at 16 x 128 x 440.)  The order inside a list is irrelevant: the top-K kernel sorts it.
+constexpr int kPeakSpan = 1024;
 __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
+    __shared__ float s_score[kPeakSpan];
+    __shared__ int s_idx[kPeakSpan];
+    __shared__ int s_n, s_base;
     const int nch = p.n_cls + p.J;
     const int slot = blockIdx.y;                       // b * nch + ch
     const int b = slot / nch, ch = slot - b * nch;
@@ -60,8 +65,11 @@ __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
     const int HW = p.H * p.W;
     const float* mb = m + (int64_t)b * HW * C + c;
     const int lane = threadIdx.x & 63;
-    for (int base = blockIdx.x * blockDim.x; base < HW; base += gridDim.x * blockDim.x) {
-        const int pix = base + threadIdx.x;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int first = blockIdx.x * kPeakSpan;
+    for (int it = 0; it < kPeakSpan / 256; ++it) {
+        const int pix = first + it * 256 + threadIdx.x;
         bool peak = false;
         float v = 0.f;
         if (pix < HW) {
@@ -83,15 +91,26 @@ __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
         const uint64_t mask = __ballot(peak);
         if (mask) {
             int pos0 = 0;
-            if (lane == 0) pos0 = atomicAdd(p.peak_count + slot, __popcll(mask));
+            if (lane == 0) pos0 = atomicAdd(&s_n, __popcll(mask));
             pos0 = __shfl(pos0, 0);
             if (peak) {
                 const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < p.max_peaks) {
-                    p.peak_score[(int64_t)slot * p.max_peaks + pos] = v;
-                    p.peak_idx[(int64_t)slot * p.max_peaks + pos] = pix;
-                }
+                s_score[pos] = v;
+                s_idx[pos] = pix;
             }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(p.peak_count + slot, n);
+    __syncthreads();
+    const int base = s_base;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int pos = base + i;
+        if (pos < p.max_peaks) {
+            p.peak_score[(int64_t)slot * p.max_peaks + pos] = s_score[i];
+            p.peak_idx[(int64_t)slot * p.max_peaks + pos] = s_idx[i];
         }
     }
 }
@@ -352,8 +371,7 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_cls = q->out_cls; a.out_count = q->out_count;
     const int nz = (int)(((int64_t)q->B * nch * 4 + 255) / 256 * 256 + (int64_t)q->B * 4) / 4;
     hipLaunchKernelGGL(km3d_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, w.peak_count, nz);
-    int gx = (q->H * q->W + 255) / 256;
-    if (gx > 64) gx = 64;
+    const int gx = (q->H * q->W + kPeakSpan - 1) / kPeakSpan;
     hipLaunchKernelGGL(km3d_peaks_kernel, dim3((unsigned)gx, (unsigned)(q->B * nch)), dim3(256), 0, s, a);
     int rc = vd3d_check_launch("km3d_peaks");
     if (rc) return rc;
