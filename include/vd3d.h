@@ -246,6 +246,12 @@ typedef struct vd3d_dcn_params {
 } vd3d_dcn_params;
 int vd3d_dcn_pack_weight(const float* w_oihw, void* packed, int O, int Cg, int kh, int kw, int Kpad, int dtype, void* stream);
 int vd3d_deform_conv(const vd3d_dcn_params* p, void* stream);
+/* Sampling half of a deformable convolution with MANY output channels (the 2176 -> 2176 DCNv2 of the stereo base head): writes the
+ * bilinear-sampled, modulated columns ONCE, in the activation dtype (the rounding point of the fused kernel), as
+ * columns[B][Ho][Wo][kh*kw][C]; the contraction then runs as a 1x1 vd3d_conv2d_igemm over K = kh*kw*C (weight packed tap-major,
+ * bias / BN / ReLU in its epilogue).  The reference materialises the same matrix in fp32 (deform_conv_cuda.cpp:531-569).
+ * Channel-contiguous (NHWC) input, groups = deformable_groups = 1; weight / out / bias / scale / shift of `p` are ignored. */
+int vd3d_deform_columns(const vd3d_dcn_params* p, void* columns, void* stream);
 
 /* LookGround sampling (lib/look_ground.py:24-69): builds [x ; prior disparity] and bilinear-samples it
  * (grid_sample, border padding, align_corners=True) at (x, y + y_shift), y_shift = geometric prior + 0.1*tanh(disp).

@@ -160,3 +160,35 @@ def test_ext_surface_error_behaviour_and_asymmetric_geometry():
                                         1, 1, 2)
     assert ((o2.cpu() - want2).abs().max() / want2.abs().max()).item() < 1e-5
     assert ((o1.cpu() - want1).abs().max() / want1.abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize('dtype,tol', [(torch.float32, 5e-5), (torch.bfloat16, 2e-2), (torch.float16, 2.5e-3)])
+def test_pack_module_nhwc_columns_route_for_many_output_channels(dtype, tol):
+    """out_channels > 256 (the 2176 -> 2176 DCNv2 of the stereo base head): sampled columns written once (vd3d_deform_columns) +
+    1x1 strip GEMM, against the oracle and against the fused kernel forced on the same module (same rounding points)."""
+    C, O = 64, 320
+    m = _pack_module(C, O, 5)
+    bn = torch.nn.BatchNorm2d(O).eval()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(O, generator=g) + 0.5); bn.bias.copy_(torch.randn(O, generator=g) * 0.1)
+        bn.running_mean.copy_(torch.randn(O, generator=g) * 0.1); bn.running_var.copy_(torch.rand(O, generator=g) + 0.5)
+    x = torch.randn(2, C, 11, 13, generator=g)
+    rnd = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else None
+    with torch.no_grad():
+        import torch.nn.functional as F
+        xr = rnd(x) if rnd else x
+        wo = rnd(m.conv_offset.weight) if rnd else m.conv_offset.weight
+        out = F.conv2d(xr, wo, m.conv_offset.bias, 1, 1)
+        o1, o2, mask = torch.chunk(out, 3, dim=1)
+        y = dcn_ref.deform_conv_forward(xr, torch.cat((o1, o2), 1), torch.sigmoid(mask), m.weight, m.bias, 1, 1, 1, 1, 1, rnd=rnd)
+        want = torch.relu(bn(y))
+        m = m.cuda(); bn = bn.cuda()
+        xin = x.permute(0, 2, 3, 1).contiguous().cuda().to(dtype)
+        assert m.columns_above == 256
+        got = m.forward_nhwc(xin, bn=bn, relu=True)
+        m.columns_above = 10 ** 9                      # force the fused kernel
+        fused_out = m.forward_nhwc(xin, bn=bn, relu=True)
+    a = got.float().cpu().permute(0, 3, 1, 2)
+    assert ((a - want).abs().max() / want.abs().max()).item() < tol
+    assert ((got.float() - fused_out.float()).abs().max() / fused_out.float().abs().max()).item() < (1e-5 if dtype == torch.float32 else 2.0 ** -7)

@@ -96,6 +96,7 @@ SIGNATURES = {
     'vd3d_deform_conv_forward': (c_int, [c_void_p] * 7 + [c_int] * 15 + [c_void_p]),
     'vd3d_dcn_pack_weight': (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     'vd3d_deform_conv': (c_int, [C.POINTER(DcnParams), c_void_p]),
+    'vd3d_deform_columns': (c_int, [C.POINTER(DcnParams), c_void_p, c_void_p]),
     'vd3d_look_ground_sample': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_int, c_void_p]),
     'vd3d_pack_image_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
     'vd3d_maxpool2x2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),

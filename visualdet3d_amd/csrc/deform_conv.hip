@@ -438,6 +438,78 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         }
 }
 
+// ---- sampled columns in HBM (large output-channel counts) -------------------------------------------------------------
+// The fused kernel above produces a pixel tile's sampled columns once per BN <= 256 output channels: with O = 2176 (the DCNv2
+// head of BASELINE config 3) the gather + blend is repeated 9 times and the launch takes 12 ms.  For such layers the columns
+// are written once, in the storage dtype -- the very rounding point of the fused path -- as [B][Ho][Wo][tap][C], and the
+// contraction runs as a 1x1 convolution over K = taps x C on the strip tiles of conv_igemm.hip (the reference materialises
+// the same matrix, in fp32: deform_conv_cuda.cpp:531-569).  One thread = one (pixel, tap, 16-byte channel vector); identical
+// sampling arithmetic to dcn_nhwc_kernel (same fma chain, same modulation order).
+template <typename T>
+__global__ void __launch_bounds__(256) dcn_columns_kernel(const DcnArgs p, T* __restrict__ cols) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VE = 16 / ES;
+    const int KK = p.kh * p.kw;
+    const int cv = p.C / VE;
+    const int64_t total = (int64_t)p.B * p.Ho * p.Wo * KK * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        int64_t r = i / cv;
+        const int tap = (int)(r % KK);
+        r /= KK;
+        const int ox = (int)(r % p.Wo), oy = (int)((r / p.Wo) % p.Ho), b = (int)(r / ((int64_t)p.Wo * p.Ho));
+        const int ti = tap / p.kw, tj = tap - ti * p.kw;
+        const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
+        const float off_h = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
+        const float off_w = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+        float m = 1.f;
+        if (p.mask) {
+            m = p.mask[b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx + (int64_t)tap * p.msk_sc];
+            if (p.mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
+        }
+        const float h_im = (float)(oy * p.sh - p.ph + ti * p.dh) + off_h;
+        const float w_im = (float)(ox * p.sw - p.pw + tj * p.dw) + off_w;
+        float vals[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) vals[e] = 0.f;
+        if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+            const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
+            const float gw[4] = {t_ok && l_ok ? hh * hw : 0.f, t_ok && r_ok ? hh * lw : 0.f, b_ok && l_ok ? lh * hw : 0.f, b_ok && r_ok ? lh * lw : 0.f};
+            const int64_t go[4] = {h_low * p.in_sy + w_low * p.in_sx, h_low * p.in_sy + w_high * p.in_sx,
+                                   h_high * p.in_sy + w_low * p.in_sx, h_high * p.in_sy + w_high * p.in_sx};
+            const char* in_b = (const char*)p.in + ((int64_t)b * p.in_sb + c) * ES;
+            Vec16<T> cr[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                cr[k].raw = i32x4{0, 0, 0, 0};
+                if (gw[k] != 0.f) cr[k].raw = *(const i32x4*)(in_b + go[k] * ES);
+            }
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                float val;
+                if constexpr (sizeof(T) == 2)
+                    val = fmaf(gw[3], cr[3].get(e), fmaf(gw[2], cr[2].get(e), fmaf(gw[1], cr[1].get(e), gw[0] * cr[0].get(e))));
+                else
+                    val = gw[0] * cr[0].get(e) + gw[1] * cr[1].get(e) + gw[2] * cr[2].get(e) + gw[3] * cr[3].get(e);
+                vals[e] = val * m;
+            }
+        }
+        Vec16<T> o;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set(e, vals[e]);
+        }
+        *(i32x4*)((char*)cols + i * 16) = o.raw;
+    }
+}
+
 template <typename T, int BN>
 int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
     const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * 48;   // two stages + the geometry table
@@ -493,6 +565,36 @@ int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
     return vd3d_check_launch("deform_conv");
 }
 
+int launch_dcn_columns(const vd3d_dcn_params* q, void* columns, hipStream_t s) {
+    if (!q || !q->in || !q->offset || !columns) { vd3d_set_error("deform_columns: null pointer"); return VD3D_EINVAL; }
+    if (q->dtype != VD3D_BF16 && q->dtype != VD3D_F16 && q->dtype != VD3D_F32) { vd3d_set_error("deform_columns: bad dtype"); return VD3D_EINVAL; }
+    const int es = q->dtype == VD3D_F32 ? 4 : 2, ve = 16 / es;
+    if (q->groups != 1 || q->deformable_groups != 1 || q->in_strides[1] != 1 || q->C % ve || ((uintptr_t)q->in & 15) || ((uintptr_t)columns & 15) ||
+        q->in_strides[0] % ve || q->in_strides[2] % ve || q->in_strides[3] % ve) {
+        vd3d_set_error("deform_columns: needs channel-contiguous (NHWC) 16-byte aligned input, groups = deformable_groups = 1");
+        return VD3D_EINVAL;
+    }
+    DcnArgs a;
+    a.in = q->in; a.w = nullptr; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr; a.offset = q->offset; a.mask = q->mask; a.out = nullptr;
+    a.B = q->B; a.C = q->C; a.H = q->H; a.W = q->W; a.O = q->O;
+    a.kh = q->kh; a.kw = q->kw; a.sh = q->stride_h; a.sw = q->stride_w; a.ph = q->pad_h; a.pw = q->pad_w; a.dh = q->dil_h; a.dw = q->dil_w;
+    a.Ho = (q->H + 2 * q->pad_h - (q->dil_h * (q->kh - 1) + 1)) / q->stride_h + 1;
+    a.Wo = (q->W + 2 * q->pad_w - (q->dil_w * (q->kw - 1) + 1)) / q->stride_w + 1;
+    a.groups = 1; a.dgroups = 1; a.Cg = q->C; a.Og = q->O; a.Kg = q->kh * q->kw * q->C; a.Kpad = a.Kg;
+    a.in_sb = q->in_strides[0]; a.in_sc = 1; a.in_sy = q->in_strides[2]; a.in_sx = q->in_strides[3];
+    a.off_sb = q->offset_strides[0]; a.off_sc = q->offset_strides[1]; a.off_sy = q->offset_strides[2]; a.off_sx = q->offset_strides[3];
+    a.msk_sb = q->mask_strides[0]; a.msk_sc = q->mask_strides[1]; a.msk_sy = q->mask_strides[2]; a.msk_sx = q->mask_strides[3];
+    a.out_sb = a.out_sc = a.out_sy = a.out_sx = 0;
+    a.mask_sigmoid = q->mask_sigmoid; a.relu = 0;
+    if (a.Ho <= 0 || a.Wo <= 0 || q->B <= 0) { vd3d_set_error("deform_columns: empty output"); return VD3D_EINVAL; }
+    const int64_t total = (int64_t)q->B * a.Ho * a.Wo * q->kh * q->kw * (q->C / ve);
+    const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    if (q->dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_columns_kernel<short>, dim3(grid), dim3(256), 0, s, a, (short*)columns);
+    else if (q->dtype == VD3D_F16) hipLaunchKernelGGL(dcn_columns_kernel<hf16>, dim3(grid), dim3(256), 0, s, a, (hf16*)columns);
+    else hipLaunchKernelGGL(dcn_columns_kernel<float>, dim3(grid), dim3(256), 0, s, a, (float*)columns);
+    return vd3d_check_launch("deform_columns");
+}
+
 // OIHW fp32 -> packed [O][Kpad] (tap-major K) in the compute dtype
 template <typename T>
 __global__ void dcn_pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int O, int Cg, int KK, int Kpad) {
@@ -526,6 +628,10 @@ extern "C" int vd3d_deform_conv(const vd3d_dcn_params* p, void* stream) { return
 extern "C" int64_t vd3d_deform_conv_workspace_bytes(int O, int C, int groups, int kh, int kw) {
     const int Kg = kh * kw * (C / (groups > 0 ? groups : 1));
     return (int64_t)O * ((Kg + 31) / 32 * 32) * 4 + 256;
+}
+
+extern "C" int vd3d_deform_columns(const vd3d_dcn_params* p, void* columns, void* stream) {
+    return launch_dcn_columns(p, columns, (hipStream_t)stream);
 }
 
 extern "C" int vd3d_deform_conv_forward(const float* input, const float* weight, const float* bias, const float* offset,

@@ -490,6 +490,34 @@ def deform_conv_general(x, pd, offset, mask, out, layout, bias=None, scale=None,
     return out
 
 
+def deform_columns(x, offset, mask, kernel, stride=(1, 1), padding=(0, 0), dilation=(1, 1), mask_sigmoid=False, offset_layout='nhwc',
+                   mask_layout='nhwc'):
+    """Sampled, modulated DCN columns of NHWC ``x`` -> ``[B, Ho, Wo, kh*kw*C]`` in x's dtype (vd3d_deform_columns): the sampling half
+    of a deformable conv whose output-channel count is large; contract with a 1x1 ``conv2d`` over K = kh*kw*C."""
+    _require_cuda(x, offset, mask)
+    from ._lib import DcnParams
+    B, H, W, Cc = x.shape
+    kh, kw = kernel
+    Ho = (H + 2 * padding[0] - (dilation[0] * (kh - 1) + 1)) // stride[0] + 1
+    Wo = (W + 2 * padding[1] - (dilation[1] * (kw - 1) + 1)) // stride[1] + 1
+    assert offset.dtype == torch.float32 and (mask is None or mask.dtype == torch.float32) and x.stride(3) == 1
+    cols = torch.empty((B, Ho, Wo, kh * kw * Cc), dtype=x.dtype, device=x.device)
+    p = DcnParams()
+    p.in_, p.offset = x.data_ptr(), offset.data_ptr()
+    p.mask = mask.data_ptr() if mask is not None else None
+    p.B, p.C, p.H, p.W, p.O, p.kh, p.kw = B, Cc, H, W, 0, kh, kw
+    p.stride_h, p.stride_w = stride
+    p.pad_h, p.pad_w = padding
+    p.dil_h, p.dil_w = dilation
+    p.groups, p.deformable_groups, p.Kpad, p.dtype = 1, 1, kh * kw * Cc, dtype_code(x.dtype)
+    p.mask_sigmoid, p.relu = int(mask_sigmoid), 0
+    for name, t, lay in (('in_strides', x, 'nhwc'), ('offset_strides', offset, offset_layout), ('mask_strides', mask, mask_layout)):
+        s = _strides4(t, lay) if t is not None else (0, 0, 0, 0)
+        setattr(p, name, (C.c_int64 * 4)(*s))
+    check(_lib.lib().vd3d_deform_columns(C.byref(p), _p(cols), _stream()), 'vd3d_deform_columns')
+    return cols
+
+
 def deform_conv_forward_nchw(x, weight, bias, offset, mask, stride, padding, dilation, groups, deformable_groups, out=None):
     """The reference extension's call (NCHW fp32 contiguous tensors) through vd3d_deform_conv_forward.  ``out``: optional
     preallocated contiguous fp32 [B,O,Ho,Wo] written in place (the pybind surface's ``output`` argument)."""
