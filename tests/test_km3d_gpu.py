@@ -112,16 +112,18 @@ def test_fused_head_matches_unfused():
     sd = syn.seeded_state_dict({'h.' + k: v for k, v in head.state_dict().items()}, seed=9, head_std=0.02)
     head.load_state_dict({k[2:]: v for k, v in sd.items()})
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(3, 24, 80, 64, generator=g).cuda().to(torch.bfloat16)        # 3 x 1920 px: ragged last 256-pixel tile
-    with torch.no_grad():
-        head.fuse_head = True
-        fused_maps = head.forward_nhwc(x)
-        head.fuse_head = False
-        ref_maps = head.forward_nhwc(x)
-    for k in ref_maps:
-        a, b = fused_maps[k].float(), ref_maps[k].float()
-        assert a.shape == b.shape
-        assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 2e-3, k
+    # 3 x 24 x 80: ragged last 256-pixel tile; bf16 and fp16
+    for shape, dt in (((3, 24, 80), torch.bfloat16), ((2, 20, 96), torch.bfloat16), ((2, 20, 96), torch.float16)):
+        x = torch.randn(shape[0], shape[1], shape[2], 64, generator=g).cuda().to(dt)
+        with torch.no_grad():
+            head.fuse_head = True
+            fused_maps = head.forward_nhwc(x)
+            head.fuse_head = False
+            ref_maps = head.forward_nhwc(x)
+        for k in ref_maps:
+            a, b = fused_maps[k].float(), ref_maps[k].float()
+            assert a.shape == b.shape
+            assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 2e-3, (k, shape, dt)
 
 
 def test_bf16_dcn_blocks_teacher_forced_vs_bf16_oracle():

@@ -958,8 +958,6 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 21: VD3D_HALO_ONLY(launch_halo<T, 8, 32, 128, 4, 2, 4>(a, stream));
         case 23: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream));
         case 27: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream));
-        case 28: VD3D_HALO_ONLY(launch_halo<T, 8, 32, 64, 4, 2, 4>(a, stream));
-        case 29: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 64, 2, 2, 4>(a, stream));
         case 60: break;      // heuristic, but without the resident-weight kernels (A/B of those kernels)
         case 61:
             if constexpr (kBf16) {
@@ -1003,6 +1001,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 74: VD3D_BF16_ONLY(launch<T, 64, 144, 2, 1, true, true, 16>(a, stream));
         case 75: VD3D_BF16_ONLY(launch<T, 128, 288, 2, 2, true, true, 16>(a, stream));
         case 71: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream));
+        case 72: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 64, 2, 2, 4>(a, stream));
+        case 28: VD3D_HALO_ONLY(launch_halo<T, 8, 32, 64, 4, 2, 4>(a, stream));
 #endif
         default: return forced_tile_error("is not a tile of this build");
     }
