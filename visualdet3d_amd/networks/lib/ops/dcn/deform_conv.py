@@ -209,10 +209,22 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         assert self.deformable_groups == 1, 'every call site of the reference uses deformable_groups = 1 (SURVEY.md 7.3)'
         dt = x.dtype
         conv = self.conv_offset
-        pco = self._cache.get(('off', dt), [conv.weight, conv.bias],
-                              lambda: ops.pack_conv(conv.weight, conv.bias, None, dt, conv.stride[0], conv.padding[0], conv.dilation[0]))
-        logits = ops.conv2d(x, pco, relu=False, out_f32=True)          # [B,Ho,Wo,3*K] fp32: (o1 | o2 | mask) == (offsets 0:2K | mask)
         K = self.kernel_size[0] * self.kernel_size[1]
+
+        def build_offset_conv():
+            # 3*K = 27 output channels padded with zero filters to a multiple of 4 (32): 16-byte fp32 stores in the epilogue
+            # instead of 27 scalar ones per pixel; the DCN kernels read offsets / mask through strides, so the pad is free
+            O3 = conv.weight.shape[0]
+            Op = (O3 + 3) // 4 * 4 if O3 % 4 else O3
+            Op = max(Op, 32) if O3 <= 32 else Op
+            w = torch.zeros((Op,) + tuple(conv.weight.shape[1:]), dtype=torch.float32, device=conv.weight.device)
+            b = torch.zeros((Op,), dtype=torch.float32, device=conv.weight.device)
+            w[:O3] = conv.weight.detach().float()
+            b[:O3] = conv.bias.detach().float()
+            return ops.pack_conv(w, b, None, dt, conv.stride[0], conv.padding[0], conv.dilation[0])
+
+        pco = self._cache.get(('off', dt), [conv.weight, conv.bias], build_offset_conv)
+        logits = ops.conv2d(x, pco, relu=False, out_f32=True)          # [B,Ho,Wo,>=3*K] fp32: (o1 | o2 | mask) == (offsets 0:2K | mask 2K:3K | pad)
         pd = self._cache.get(('w', dt), [self.weight], lambda: ops.pack_dcn_weight(self.weight, dt))
         scale = shift = None
         if bn is not None:
@@ -221,7 +233,7 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         if self.out_channels > self.columns_above and self.groups == 1:
             # many output channels (stereo base head: 2176 -> 2176): the fused kernel would re-sample the columns once per 256
             # output channels (9 times, 12 ms at 32 x 18 x 80); write them once and contract on the strip tiles (3.9 ms)
-            cols = ops.deform_columns(x, logits[..., :2 * K], logits[..., 2 * K:], self.kernel_size, _pair(self.stride), _pair(self.padding),
+            cols = ops.deform_columns(x, logits[..., :2 * K], logits[..., 2 * K:3 * K], self.kernel_size, _pair(self.stride), _pair(self.padding),
                                       _pair(self.dilation), mask_sigmoid=True)
 
             def build_gemm():
@@ -234,7 +246,7 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
         if out is None:
             out = torch.empty((B, Ho, Wo, self.out_channels), dtype=dt, device=x.device)
         bias = self.bias.detach().float() if self.bias is not None else None
-        return ops.deform_conv_general(x, pd, logits[..., :2 * K], logits[..., 2 * K:], out, 'nhwc', bias=bias, scale=scale, shift=shift,
+        return ops.deform_conv_general(x, pd, logits[..., :2 * K], logits[..., 2 * K:3 * K], out, 'nhwc', bias=bias, scale=scale, shift=shift,
                                        stride=_pair(self.stride), padding=_pair(self.padding), dilation=_pair(self.dilation),
                                        groups=self.groups, deformable_groups=1, mask_sigmoid=True, relu=relu)
 
