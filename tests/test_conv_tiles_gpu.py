@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79, 73, 61}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 76, 79, 73, 61, 69}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61]
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 69]
 
 
 class forced_tile:
@@ -94,6 +94,17 @@ def run_case(B, H, W, Cin, Cout, k=3, stride=1, pad=1, dil=1, residual=False, re
 
 def _shapes_for(cfg):
     """Small shapes that are awkward for tile `cfg` (B, H, W, Cin, Cout, kwargs)."""
+    if cfg == 69:       # small-channel streaming kernel: Cin 16 | 32 | 64, Cout <= 32, stride 1 | 2, 16-bit or fp32 output, no residual
+        return [
+            (1, 13, 45, 16, 16, dict()),                                      # ragged tile grid
+            (2, 24, 70, 16, 32, dict(stride=2)),                              # stride 2: 12 x 35 outputs
+            (1, 17, 33, 32, 32, dict(relu=False)),
+            (2, 18, 66, 32, 16, dict(stride=2, bn=False)),
+            (1, 21, 67, 64, 32, dict(out_f32=True, bn=False, relu=False)),    # DCN offset conv (27 channels padded to 32), fp32 out
+            (1, 9, 40, 64, 28, dict(out_f32=True, relu=False)),               # Cout % 4 == 0 < 32: masked stores
+            (3, 64, 96, 16, 16, dict(in_extra=16, out_extra=16)),             # channel-slice views, many tiles per workgroup
+            (2, 32, 64, 64, 16, dict()),
+        ]
     if cfg == 61:       # register-resident weights: Cin 128 (128-channel slices) | 256 (64-channel slices, K halves added in LDS)
         return [
             (1, 11, 37, 128, 128, dict(residual=True)),                 # ragged tile grid, fewer tiles than CUs

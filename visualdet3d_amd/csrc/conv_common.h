@@ -39,5 +39,7 @@ bool regw_shape_ok(const ConvArgs& a);                       // Cin 128 | 256, C
 // fmt = VD3D_BF16 | VD3D_F16 (the 16-bit storage format of activations and weights)
 int launch_regw(ConvArgs& a, hipStream_t stream, int fmt, int ring = 4, int abl = 0);     // (ring / abl != defaults: tuning build only)
 int launch_resident64(ConvArgs& a, hipStream_t stream, int fmt);      // Cin = Cout = 64
+bool small_shape_ok(const ConvArgs& a);                                // 3x3, stride 1 | 2, Cin 16 | 32 | 64, Cout <= 32, no residual
+int launch_small(ConvArgs& a, hipStream_t stream, int fmt);           // small-channel streaming kernel
 
 }  // namespace vd3d_conv

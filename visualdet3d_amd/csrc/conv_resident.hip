@@ -494,6 +494,165 @@ __global__ void __launch_bounds__(256) conv_regw_kernel(const ConvArgs p, int nt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs must not land in a successor workgroup's LDS
 }
 
+
+// =====================================================================================================
+// "small-channel streaming" kernel: 3x3 / pad 1 / stride 1 | 2, Cin = 16 | 32 | 64, Cout <= 32 (DLA level 0 / 1 at full and half
+// resolution -- 16 -> 16 at 16 x 512 x 1760 is 0.9 GB of activations for 66 GF -- and the 64 -> 27 offset convs of the DCN blocks).
+// These layers are HBM-bound by a wide margin, but the tile kernels run them at 1.1 - 1.5 TB/s: every input pixel goes through
+// LDS-DMA nine times (once per tap) in 32-byte crumbs.  Here: persistent workgroups of 8 waves own 8 x 32 OUTPUT pixels (one
+// 32-pixel row per wave), the (8S+2) x (32S+2) input halo is staged ONCE by LDS-DMA (ring of halo stages filled one to three
+// tiles ahead), the weights (<= 36 fragments) live in registers, a tile costs 9 * Cin/16 MFMAs per wave (tap x 16-channel
+// k-step; the MFMA's 32 output-channel rows are padded with zero filters) and one barrier.  Input read once (+ halo overlap),
+// output written once.  Epilogue: scale / shift (+ReLU), 16-bit (Cout % 16 == 0) or fp32 (Cout % 4 == 0) 16-byte stores.
+template <typename T, int CIN, int S, bool OUTF32>
+__global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int ntiles) {
+    constexpr int TH = 8, TW = 32;
+    constexpr int HH = (TH - 1) * S + 3, HWD = (TW - 1) * S + 3;       // input halo of one output tile
+    constexpr int PITCH = CIN * 2;                                    // bytes per halo pixel in LDS
+    constexpr int SLOTS = PITCH / 16;                                 // 16-byte slots per pixel
+    constexpr int PXPP = 1024 / PITCH;                                // halo pixels per 1 KiB DMA piece
+    constexpr int HR = HH * HWD;
+    constexpr int PIECES = (HR + PXPP - 1) / PXPP;
+    constexpr int P = (PIECES + 7) / 8;                               // per wave (overshoot repeats the wave's previous piece)
+    constexpr int STAGE = PIECES * 1024;
+    constexpr int NST = (150 * 1024 / STAGE) >= 4 ? 4 : ((150 * 1024 / STAGE) >= 3 ? 3 : 2);
+    constexpr int KS = CIN / 16, NF = 9 * KS;                          // MFMAs (= A fragments) per tile and wave
+    constexpr int NS = OUTF32 ? 4 : 2;                                // stores per tile and wave
+    constexpr int RING = NF >= 8 ? 4 : 2;
+    static_assert(CIN == 16 || CIN == 32 || CIN == 64, "small-channel kernel: Cin 16 | 32 | 64");
+    static_assert(NST * STAGE + 512 <= 160 * 1024, "halo ring does not fit the LDS");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, half = lane >> 5;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH, tiles_img = tiles_x * tiles_y;
+
+    // ---- weights -> registers (A operand: row = output channel (zero rows beyond Cout), 16 bytes = 8 k values) ------------
+    i32x4 wf[NF];
+    {
+        const char* wrow = p.weight + (size_t)lr * p.Kpad * 2;
+        static_for<NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, tap = f / KS, ks = f % KS;
+            wf[f] = *(const i32x4*)(wrow + (tap * CIN + ks * 16 + half * 8) * 2);
+        });
+    }
+    // swizzle key of a halo row (128-byte rows only: the tile kernels' XOR on the 16-byte slot)
+    auto key = [](int row) { return PITCH == 128 ? ((row >> 1) & 7) : 0; };
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x80000000u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int in_bs = (int)p.in_batch_stride;
+    auto issue_halo = [&](int t, int stage) {
+        const bool tv = t < ntiles;
+        const int tt = tv ? t : 0;
+        const int b = tt / tiles_img, trem = tt - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int it = 0; it < P; ++it) {
+            int q = wave + it * 8;
+            if (q >= PIECES) q -= 8;                  // branch-free partial round: repeat the previous piece (same data)
+            const int hr = q * PXPP + lane / SLOTS;
+            const int hy = hr / HWD, hx = hr - hy * HWD;
+            const int iy = ty * TH * S - 1 + hy, ix = tx * TW * S - 1 + hx;
+            const bool v = tv && hr < HR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int sl = (lane % SLOTS) ^ key(hr);
+            const uint32_t off = ((uint32_t)(b * in_bs + iy * p.in_row_stride + ix * p.in_pix_stride + sl * 8) * 2u) | (v ? 0u : kOOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + q * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    // fragment f = (tap, ks): lane (lr = pixel of this wave's row, half) reads 16 bytes = channels ks*16 + half*8 .. +7 of the halo
+    // pixel at (wave * S + dy, lr * S + dx)
+    int a_tap[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int row = (wave * S + tap / 3) * HWD + lr * S + tap % 3;
+        a_tap[tap] = row * PITCH + ((half ^ key(row)) << 4);
+    }
+    auto ld_frag = [&](int stage, int f) {
+        return *(const i32x4*)(smem + stage * STAGE + (a_tap[f / KS] ^ ((f % KS) << 5)));
+    };
+    float* ss = (float*)(smem + NST * STAGE);
+    if (tid < 32) {
+        ss[tid] = (p.scale && tid < p.Cout) ? p.scale[tid] : 1.f;
+        ss[32 + tid] = (p.shift && tid < p.Cout) ? p.shift[tid] : 0.f;
+    }
+    const int nwg = gridDim.x;
+    int t = blockIdx.x;
+#pragma unroll
+    for (int s0 = 0; s0 < NST; ++s0) issue_halo(t + s0 * nwg, s0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 1) * P) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    i32x4 ring[RING];
+#pragma unroll
+    for (int f = 0; f < RING; ++f) ring[f] = ld_frag(0, f);
+
+    // VMEM queue per tile k and wave: [D(k + NST): P pieces, after the barrier] [S(k): NS stores].  At tile k's barrier D(k + 1)
+    // (issued at tile k + 1 - NST's barrier) must have landed: younger than it are (NST - 2) D's and (NST - 1) S's.
+    constexpr int kYounger = (NST - 2) * P + (NST - 1) * NS;
+    int stage = 0, k = 0;
+    for (; t < ntiles; t += nwg, ++k) {
+        f32x16 acc;
+        const int b = t / tiles_img, trem = t - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int y = ty * TH + wave, x = tx * TW + lr;
+        const bool pin = y < p.Ho && x < p.Wo;
+        const int nstage = stage + 1 == NST ? 0 : stage + 1;
+        static_for<NF>([&](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f == NF - RING) {
+                if (k < NST) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kYounger) : "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_halo(t + NST * nwg, stage);                 // tile k + NST into the stage just released
+            }
+            if constexpr (f == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                Fmt16<T>::mfma32z(wf[0], ring[0], zero, acc);
+            } else
+                Fmt16<T>::mfma32(wf[f], ring[f % RING], acc);
+            ring[f % RING] = f + RING < NF ? ld_frag(stage, f + RING) : ld_frag(nstage, f + RING - NF);
+        });
+        // ---- epilogue: lane (lr = pixel, half) holds channels 8g + 4 half + e of its pixel --------------------------------------
+        const uint32_t obase = (uint32_t)(((b * p.Ho + y) * p.Wo + x) * p.out_pix_stride);
+        const float relu_lo = p.relu ? 0.f : -3.0e38f;
+        auto chan4 = [&](int g, float (&v)[4]) {       // channels 8g + 4 half .. +3 of this lane's pixel: scale, shift, ReLU
+            const f32x4 sc = *(const f32x4*)(ss + 8 * g + 4 * half), sh = *(const f32x4*)(ss + 32 + 8 * g + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * g + e] * sc[e] + sh[e], relu_lo);
+        };
+        if constexpr (OUTF32) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4];
+                chan4(g, v);
+                const int n = 8 * g + 4 * half;
+                const uint32_t off = ((obase + n) * 4u) | (pin && n < p.Cout ? 0u : kOOB);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{v[0], v[1], v[2], v[3]}), out_rsrc, off, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                float va[4], vb[4];
+                chan4(g, va);
+                chan4(g + 1, vb);
+                const int x0 = Fmt16<T>::pack2(va[0], va[1]), x1 = Fmt16<T>::pack2(va[2], va[3]);
+                const int y0 = Fmt16<T>::pack2(vb[0], vb[1]), y1 = Fmt16<T>::pack2(vb[2], vb[3]);
+                auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
+                const int n = 8 * (g + half);
+                const uint32_t off = ((obase + n) * 2u) | (pin && n < p.Cout ? 0u : kOOB);
+                __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
+            }
+        }
+        stage = nstage;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs must not land in a successor workgroup's LDS
+}
+
 }  // namespace
 
 namespace vd3d_conv {
@@ -550,6 +709,47 @@ static int launch_resident64_t(ConvArgs& a, hipStream_t stream) {
 
 int launch_resident64(ConvArgs& a, hipStream_t stream, int fmt) {
     return fmt == VD3D_F16 ? launch_resident64_t<hf16>(a, stream) : launch_resident64_t<short>(a, stream);
+}
+
+
+bool small_shape_ok(const ConvArgs& a) {
+    const bool out16 = !a.out_f32;
+    return (a.Cin == 16 || a.Cin == 32 || a.Cin == 64) && a.kh == 3 && a.kw == 3 && (a.stride == 1 || a.stride == 2) && a.pad == 1 && a.dil == 1 &&
+           a.Cout <= 32 && a.Cout % (out16 ? 16 : 4) == 0 && !a.residual && a.in_pix_stride % 8 == 0 && a.out_pix_stride % (out16 ? 8 : 4) == 0 &&
+           (!a.scale || ((uintptr_t)a.scale & 15) == 0) && (!a.shift || ((uintptr_t)a.shift & 15) == 0) &&
+           ((uintptr_t)a.out & 15) == 0 && (int64_t)a.M * a.out_pix_stride * (out16 ? 2 : 4) < 0x7ffffff0ll &&
+           !(a.stride == 2 && a.Cin == 64);
+}
+
+template <typename T, int CIN, int S, bool OUTF32>
+static int launch_small_t(ConvArgs& a, hipStream_t stream) {
+    constexpr int HR = ((8 - 1) * S + 3) * ((32 - 1) * S + 3), PXPP = 1024 / (CIN * 2), STAGE = ((HR + PXPP - 1) / PXPP) * 1024;
+    constexpr int NST = (150 * 1024 / STAGE) >= 4 ? 4 : ((150 * 1024 / STAGE) >= 3 ? 3 : 2);
+    constexpr int LDS = NST * STAGE + 512;
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)conv_small_kernel<T, CIN, S, OUTF32>, LDS, lim, "hipFuncSetAttribute(conv_small)")) return rc;
+    const int num_cu = vd3d_device_cu_count();
+    if (num_cu <= 0) return VD3D_ELAUNCH;
+    const int ntiles = a.B * ((a.Ho + 7) / 8) * ((a.Wo + 31) / 32);
+    // small halo stages leave room for two workgroups per CU (16 waves hide the DMA latency of these short tiles better)
+    const int per_cu = LDS <= 72 * 1024 ? 2 : 1;
+    const int grid = ntiles < num_cu * per_cu ? ntiles : num_cu * per_cu;
+    hipLaunchKernelGGL((conv_small_kernel<T, CIN, S, OUTF32>), dim3(grid), dim3(512), LDS, stream, a, ntiles);
+    return vd3d_check_launch("conv_small");
+}
+
+template <typename T>
+static int launch_small_f(ConvArgs& a, hipStream_t stream) {
+#define VD3D_SMALL(CIN, S) \
+    if (a.Cin == CIN && a.stride == S) return a.out_f32 ? launch_small_t<T, CIN, S, true>(a, stream) : launch_small_t<T, CIN, S, false>(a, stream);
+    VD3D_SMALL(16, 1) VD3D_SMALL(32, 1) VD3D_SMALL(64, 1) VD3D_SMALL(16, 2) VD3D_SMALL(32, 2)
+#undef VD3D_SMALL
+    vd3d_set_error("conv_small: unsupported (Cin, stride)");
+    return VD3D_EINVAL;
+}
+
+int launch_small(ConvArgs& a, hipStream_t stream, int fmt) {
+    return fmt == VD3D_F16 ? launch_small_f<hf16>(a, stream) : launch_small_f<short>(a, stream);
 }
 
 int launch_regw(ConvArgs& a, hipStream_t stream, int fmt, int ring, int abl) {
