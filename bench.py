@@ -83,17 +83,6 @@ def profile_convs(model, inputs, reps=3):
                         '%dx%d s%d %4d->%4d @ %dx%dx%d' % (pc.kh, pc.kw, pc.stride, pc.Cin, pc.Cout, B, Ho, Wo)))
         return o
 
-    # HIP-event overhead: a (start, stop) pair around NOTHING still reads ~2-4 us (event processing between the two
-    # timestamps); it is measured here and subtracted from every launch so that the sum agrees with the kernel durations a
-    # rocprofv3 --kernel-trace of `bench.py --no-overlap` reports (profiles/*_serial_roofline_check.txt)
-    pairs = []
-    for _ in range(64):
-        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        e0.record()
-        pairs.append((s0, e0))
-    torch.cuda.synchronize()
-    ovh_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
     ops.conv2d = timed
     overlap = model.bbox_head.overlap_towers
     overlap_neck = model.core.overlap_neck
@@ -108,6 +97,11 @@ def profile_convs(model, inputs, reps=3):
         ops.conv2d = orig
         model.bbox_head.overlap_towers = overlap
         model.core.overlap_neck = overlap_neck
+    # No event-overhead correction: per-launch HIP events were compared with the kernel durations of a rocprofv3 --kernel-trace
+    # of this very command (`bench.py --no-overlap`, tools/profile_round.sh -> profiles/*_serial_roofline_check.txt): the raw
+    # event sums agree with the profiler within ~1 % (an empty event pair reads 5-6 us, but around a kernel that cost is not
+    # inside the reading: subtracting it made the bench read 3.5-8 % short of the profiler).
+    ovh_ms = 0.0
     if os.environ.get('VD3D_BENCH_LAYERS'):
         per = len(records) // reps
         for i in range(per):
@@ -116,7 +110,17 @@ def profile_convs(model, inputs, reps=3):
             print('  conv %2d  %-32s %8.2f GF  %8.1f us  %7.1f TF/s' % (i, records[i][4], fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     flops = sum(r[0] for r in records) / reps
     secs = sum(max(r[1].elapsed_time(r[2]) - ovh_ms, 0.0) for r in records) * 1e-3 / reps
-    return flops, secs, len(records) // reps, sum(r[3] for r in records) / reps, ovh_ms * 1e3
+    # the single most expensive layer shape of the family (its launches all run the same kernel): reported next to the family figure
+    by_shape = {}
+    for r in records:
+        d = by_shape.setdefault(r[4], [0.0, 0.0, 0])
+        d[0] += r[0]
+        d[1] += max(r[1].elapsed_time(r[2]) - ovh_ms, 0.0) * 1e-3
+        d[2] += 1
+    name, (fl, tt, n) = max(by_shape.items(), key=lambda kv: kv[1][1])
+    dominant = dict(layer=name, launches_per_step=n // reps, share_of_family_time=round(tt / (secs * reps), 4),
+                    avg_launch_us=round(tt / n * 1e6, 1), achieved=round(fl / tt / 1e12, 1))
+    return flops, secs, len(records) // reps, sum(r[3] for r in records) / reps, ovh_ms * 1e3, dominant
 
 
 def _cpu_model():
@@ -327,7 +331,7 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        flops, secs, nl, alg_bytes, ev_us = profile_convs(model, inputs)
+        flops, secs, nl, alg_bytes, ev_us, dominant = profile_convs(model, inputs)
         traffic = None
         pmc = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
         if not os.path.exists(pmc):
@@ -345,10 +349,11 @@ def main():
                                    % (args.height, args.width, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
                        'side_streams': not args.no_overlap, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world)},
-            'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 (all %d launches per step)' % nl,
+            'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw (all %d launches per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                          'traffic': traffic, 'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
-                         'algorithmic_bytes': alg_bytes, 'event_pair_overhead_us_subtracted_per_launch': round(ev_us, 2),
+                         'algorithmic_bytes': alg_bytes,
+                         'dominant_layer': dict(dominant, unit='TFLOP/s', frac=round(dominant['achieved'] / peak, 4)),
                          'whole_path_frac': round(value / world * GFLOP_PER_PAIR * (args.height * args.width) / (384 * 1280) / 1e3 / peak, 4)},
         }
         if not args.no_cpu_baseline:
