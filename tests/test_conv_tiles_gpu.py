@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79, 73, 61, 69}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 76, 79, 73, 61, 68, 69}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 69]
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69]
 
 
 class forced_tile:
@@ -94,6 +94,14 @@ def run_case(B, H, W, Cin, Cout, k=3, stride=1, pad=1, dil=1, residual=False, re
 
 def _shapes_for(cfg):
     """Small shapes that are awkward for tile `cfg` (B, H, W, Cin, Cout, kwargs)."""
+    if cfg == 68:       # K-split resident weights: Cin 256, 64-channel slices, 8 x 8-pixel tiles, rotating epilogue owner
+        return [
+            (1, 11, 21, 256, 64, dict(residual=True)),                  # ragged tile grid, one slice
+            (2, 8, 8, 256, 128, dict(residual=False, relu=False)),      # one tile per image, two slices
+            (1, 17, 26, 256, 192, dict(residual=True, in_extra=64, out_extra=64)),
+            (16, 24, 80, 256, 256, dict(residual=True)),                # layer3 at the bench shape: 4 slices, 7.5 tiles per workgroup
+            (3, 40, 72, 256, 256, dict(residual=False, bn=False)),
+        ]
     if cfg == 69:       # small-channel streaming kernel: Cin 16 | 32 | 64, Cout <= 32, stride 1 | 2, 16-bit or fp32 output, no residual
         return [
             (1, 13, 45, 16, 16, dict()),                                      # ragged tile grid

@@ -39,6 +39,8 @@ bool regw_shape_ok(const ConvArgs& a);                       // Cin 128 | 256, C
 // fmt = VD3D_BF16 | VD3D_F16 (the 16-bit storage format of activations and weights)
 int launch_regw(ConvArgs& a, hipStream_t stream, int fmt, int ring = 4, int abl = 0);     // (ring / abl != defaults: tuning build only)
 int launch_resident64(ConvArgs& a, hipStream_t stream, int fmt);      // Cin = Cout = 64
+bool ksplit_shape_ok(const ConvArgs& a);                               // Cin 256 3x3 / s1 / p1, Cout % 64 == 0, weight_frag given
+int launch_ksplit(ConvArgs& a, hipStream_t stream, int fmt);          // 8-wave K-split resident-weight kernel (layer3)
 bool small_shape_ok(const ConvArgs& a);                                // 3x3, stride 1 | 2, Cin 16 | 32 | 64, Cout <= 32, no residual
 int launch_small(ConvArgs& a, hipStream_t stream, int fmt);           // small-channel streaming kernel
 

@@ -959,6 +959,11 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 23: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream));
         case 27: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream));
         case 60: break;      // heuristic, but without the resident-weight kernels (A/B of those kernels)
+        case 68:
+            if constexpr (kBf16) {
+                if (!ksplit_shape_ok(a)) return forced_tile_error("needs a 16-bit 3x3 / stride 1 / pad 1 conv with Cin 256, Cout a multiple of 64");
+                return launch_ksplit(a, stream, std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16);
+            } else return forced_tile_error("is a 16-bit-only tile");
         case 69:
             if constexpr (kBf16) {
                 if (!small_shape_ok(a)) return forced_tile_error("needs a 16-bit 3x3 / stride 1 | 2 conv with Cin 16 | 32 | 64, Cout <= 32, no residual");
@@ -1012,15 +1017,12 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         default: return forced_tile_error("is not a tile of this build");
     }
     if constexpr (std::is_same<T, short>::value || std::is_same<T, hf16>::value) {
-        // register-resident weights (v6): Cin 128 always (+25 % over the 8x32x128 halo tile on ResNet layer2); Cin 256 only
-        // when the 128-pixel x 256-channel halo tiles would leave CUs idle (the 256 -> 256 cls conv at 8 x 24 x 80: 120 tiles;
-        // +40 % there, but -6 % on layer3 whose 240 halo tiles fill the chip)
+        // register-resident weights (v6), Cin 128: +25 % over the 8x32x128 halo tile on ResNet layer2
         constexpr int fmt = std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16;
-        if (g_force_cfg != 60 && regw_shape_ok(a)) {
-            if (a.Cin == 128) return launch_regw(a, stream, fmt);
-            const int64_t halo_tiles = (int64_t)a.B * ((a.H + 7) / 8) * ((a.W + 15) / 16) * ((a.Cout + 255) / 256);
-            if (halo_tiles * 4 < (int64_t)vd3d_device_cu_count() * 3) return launch_regw(a, stream, fmt);
-        }
+        if (g_force_cfg != 60 && a.Cin == 128 && regw_shape_ok(a)) return launch_regw(a, stream, fmt);
+        // Cin 256: the 8-wave K-split resident kernel (v7): +3.5 % over the 8x16x256 halo tiles on layer3 (781 vs 754 TF/s), +50 % on
+        // the 256 -> 256 cls conv whose 120 halo tiles leave half the chip idle (690 vs 441; the 4-wave v6 kernel: 641 - 704)
+        if (g_force_cfg != 60 && ksplit_shape_ok(a)) return launch_ksplit(a, stream, fmt);
         // small-channel streaming kernel (DLA level 0 / 1, DCN offset convs): input staged once, HBM-bound instead of LDS-fill-bound
         if (g_force_cfg != 60 && small_shape_ok(a)) return launch_small(a, stream, fmt);
         if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
@@ -1128,7 +1130,7 @@ extern "C" int vd3d_conv2d_set_tuning(int cfg) {
 
 extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
     // keep in step with the "production tiles" block of dispatch()
-    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 69};
+    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69};
     const int n = (int)(sizeof(kIds) / sizeof(kIds[0]));
     for (int i = 0; i < n && i < cap; ++i) ids[i] = kIds[i];
     return n;

@@ -97,7 +97,9 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
         a_tap[tap] = row * 128 + ((half ^ hkey(row)) << 4);
     }
     auto ld_frag = [&](int stage, int f) {
-        return *(const i32x4*)(smem + stage * kResStageBytes + (a_tap[f >> 2] ^ ((f & 3) << 5)));
+        int base = a_tap[f >> 2];
+        asm volatile("" : "+v"(base));            // keeps the 36 (tap, ks) addresses from being hoisted out of the tile loop (they spilled)
+        return *(const i32x4*)(smem + stage * kResStageBytes + (base ^ ((f & 3) << 5)));
     };
 
     float* ss = (float*)(smem + kResStages * kResStageBytes);
@@ -548,15 +550,17 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int n
         const int b = tt / tiles_img, trem = tt - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
         char* base = smem + stage * STAGE;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));               // per-piece lane arithmetic is recomputed here, not kept in registers across the tile
 #pragma unroll
         for (int it = 0; it < P; ++it) {
             int q = wave + it * 8;
             if (q >= PIECES) q -= 8;                  // branch-free partial round: repeat the previous piece (same data)
-            const int hr = q * PXPP + lane / SLOTS;
+            const int hr = q * PXPP + ln / SLOTS;
             const int hy = hr / HWD, hx = hr - hy * HWD;
             const int iy = ty * TH * S - 1 + hy, ix = tx * TW * S - 1 + hx;
             const bool v = tv && hr < HR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const int sl = (lane % SLOTS) ^ key(hr);
+            const int sl = (ln % SLOTS) ^ key(hr);
             const uint32_t off = ((uint32_t)(b * in_bs + iy * p.in_row_stride + ix * p.in_pix_stride + sl * 8) * 2u) | (v ? 0u : kOOB);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + q * 1024), 16, off, 0, 0, 0);
         }
@@ -651,6 +655,217 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int n
         stage = nstage;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs must not land in a successor workgroup's LDS
+}
+
+
+// =====================================================================================================
+// v7 "K-split resident weights" kernel for Cin = 256 (ResNet layer3, DLA 256 -> 256; 3x3 / stride 1 / pad 1, 16-bit).
+// The 1.18 MB weight panel of a 256 -> 256 conv does not fit one CU; the 4-wave register-resident kernel above handles it as 2
+// channel groups x 2 K halves with ONE wave per SIMD, where nothing hides a wave's DMA issue, reduction and epilogue.  Here a
+// workgroup is 8 waves, two per SIMD: wave (cg, kq) owns 32 output channels x ONE 64-channel input chunk (36 A-fragments = 144
+// registers, as in conv_resident64), 2 channel groups x 4 chunks = 64 output channels per workgroup.  A tile is 8 x 8 output
+// pixels (two 32-pixel MFMA blocks per wave, 72 MFMAs); its four 13 KiB chunk halos (10 x 10 pixels x 128 B) are staged by
+// LDS-DMA one tile ahead (two stages).  The four K partial sums of a channel group meet in LDS: three waves park their
+// accumulators (8 KiB each), the fourth -- the tile's OWNER, rotating with the tile index so that every wave pays the reduction
+// and the epilogue on one tile in four -- adds them and runs the fused epilogue while the others already work on the next tile.
+constexpr int kKsTH = 8, kKsTW = 8, kKsHW = kKsTW + 2, kKsHR = (kKsTH + 2) * kKsHW;       // 10 x 10 halo pixels
+constexpr int kKsImgPieces = (kKsHR + 7) / 8, kKsImg = kKsImgPieces * 1024;                 // 13 pieces = 13 KiB per chunk image
+constexpr int kKsStage = 4 * kKsImg, kKsNst = 2;
+constexpr int kKsRedOff = kKsNst * kKsStage;                                                // 2 channel groups x 3 partials x 8 KiB
+constexpr int kKsSsOff = kKsRedOff + 2 * 3 * 8192;
+constexpr int kKsLds = kKsSsOff + 512;
+
+template <typename T, bool RES>
+__global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, int ntiles, int nslices) {
+    constexpr int PIECES = 4 * kKsImgPieces;       // 52 per stage
+    constexpr int P = (PIECES + 7) / 8;            // 7 per wave (overshoot repeats the wave's previous piece)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 1, kq = wave >> 1;
+    const int lr = lane & 31, half = lane >> 5;
+    const int tiles_x = (p.W + kKsTW - 1) / kKsTW, tiles_y = (p.H + kKsTH - 1) / kKsTH, tiles_img = tiles_x * tiles_y;
+    const int bx = blockIdx.x, xcd = bx & 7, j8 = bx >> 3;
+    const int slice = j8 % nslices;
+    const int lanes_per_xcd = (int)(gridDim.x >> 3) / nslices;
+    const int tlane = xcd * lanes_per_xcd + j8 / nslices, tstride = 8 * lanes_per_xcd;
+    const int n_base = slice * 64 + cg * 32;
+
+    i32x4 wf[36];
+    {
+        const char* wimg = p.wfrag + ((((size_t)(n_base >> 5) * 4 + kq) * 36) * 64 + lane) * 16;
+        static_for<36>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            wf[i] = *(const i32x4*)(wimg + i * 1024);
+        });
+    }
+    // swizzle key of a halo row: pixel index (hy * 8 + hx) / 2 mod 8 -- the rows a wave reads for any tap shift then carry
+    // consecutive keys (cf. conv_resident64)
+    auto hkey = [](int row) { const int hy = row / kKsHW; return ((hy * kKsTW + row - hy * kKsHW) >> 1) & 7; };
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.residual : p.out), 0, 0x80000000u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int in_bs = (int)p.in_batch_stride;
+    auto tile_origin = [&](int t, int& b, int& ty, int& tx) {
+        b = t / tiles_img;
+        const int trem = t - b * tiles_img;
+        ty = trem / tiles_x;
+        tx = trem - ty * tiles_x;
+    };
+    auto issue_halo = [&](int t, int stage) {
+        const bool tv = t < ntiles;
+        int b, ty, tx;
+        tile_origin(tv ? t : 0, b, ty, tx);
+        char* base = smem + stage * kKsStage;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));               // per-piece lane arithmetic is recomputed here (72 MFMAs apart), not kept in registers
+#pragma unroll
+        for (int it = 0; it < P; ++it) {
+            int q = wave + it * 8;
+            if (q >= PIECES) q -= 8;
+            const int g = q / kKsImgPieces, pi = q - g * kKsImgPieces;
+            const int hr = 8 * pi + (ln >> 3);
+            const int hy = hr / kKsHW, hx = hr - hy * kKsHW;
+            const int iy = ty * kKsTH - 1 + hy, ix = tx * kKsTW - 1 + hx;
+            const bool v = tv && hr < kKsHR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const int col = g * 64 + ((ln & 7) ^ hkey(hr)) * 8;
+            const uint32_t off = ((uint32_t)(b * in_bs + iy * p.in_row_stride + ix * p.in_pix_stride + col) * 2u) | (v ? 0u : kOOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + g * kKsImg + pi * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    // fragment (tap, ks) of block j: lane (lr, half) reads halo row (4j + lr / 8 + dy, lr % 8 + dx) of THIS wave's chunk image
+    int a_tap[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int row = (lr / kKsTW + tap / 3) * kKsHW + (lr & (kKsTW - 1)) + tap % 3;
+        a_tap[tap] = kq * kKsImg + row * 128 + ((half ^ hkey(row)) << 4);
+    }
+    auto ld_frag = [&](int stage, int m) {        // m = f * 2 + j
+        const int f = m >> 1, j = m & 1;
+        int base = a_tap[f >> 2];
+        asm volatile("" : "+v"(base));            // keeps the 36 (tap, ks) addresses from being hoisted out of the tile loop (they spill)
+        return *(const i32x4*)(smem + stage * kKsStage + j * (4 * kKsHW * 128) + (base ^ ((f & 3) << 5)));
+    };
+    float* ss = (float*)(smem + kKsSsOff);
+    if (tid < 64) {
+        ss[tid] = p.scale ? p.scale[slice * 64 + tid] : 1.f;
+        ss[64 + tid] = p.shift ? p.shift[slice * 64 + tid] : 0.f;
+    }
+    int t = tlane;
+    issue_halo(t, 0);
+    issue_halo(t + tstride, 1);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    constexpr int RING = 2;                        // (registers: 144 weights + 32 accumulators leave room for a 2-deep ring; 4 spills and measured slower)
+    i32x4 ring[RING];
+#pragma unroll
+    for (int m = 0; m < RING; ++m) ring[m] = ld_frag(0, m);
+    const float relu_lo = p.relu ? 0.f : -3.0e38f;
+
+    int k = 0;
+    for (; t < ntiles; t += tstride, ++k) {
+        const int stage = k & 1;
+        const int owner = k & 3;                   // the K quarter whose waves finish this tile
+        const bool own = kq == owner;
+        f32x16 acc[2];
+        int b, ty, tx;
+        tile_origin(t, b, ty, tx);
+        static_for<72>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m == 72 - RING) {
+                // all reads of this stage are issued (and, with lgkmcnt(0), done); the next tile's halos (issued one tile ago) must
+                // have landed.  The queue differs per wave (residual loads / stores of the owners): drain it.
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_halo(t + 2 * tstride, stage);
+            }
+            constexpr int f = m >> 1, j = m & 1;
+            if constexpr (f == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                Fmt16<T>::mfma32z(wf[0], ring[m % RING], zero, acc[j]);
+            } else
+                Fmt16<T>::mfma32(wf[f], ring[m % RING], acc[j]);
+            ring[m % RING] = m + RING < 72 ? ld_frag(stage, m + RING) : ld_frag(stage ^ 1, m + RING - 72);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+        // ---- the four K partial sums of a channel group meet in LDS: 3 writers, the owner adds --------------------------------
+        char* red = smem + kKsRedOff + cg * (3 * 8192);
+        // the owner's output offsets and residual (8-byte loads, in flight across the reduction barrier; loading them at the top
+        // of the tile would hold 16 registers through the MFMA loop and spill)
+        uint32_t o_off[2];
+        i32x2 rr[2][4];
+        if (own) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = ty * kKsTH + 4 * j + lr / kKsTW, x = tx * kKsTW + (lr & (kKsTW - 1));
+                const bool pin = y < p.H && x < p.W;
+                const int mpix = (b * p.H + y) * p.W + x;
+                o_off[j] = ((uint32_t)(mpix * p.out_pix_stride + n_base) * 2u) | (pin ? 0u : kOOB);
+                if constexpr (RES) {
+                    const uint32_t r_off = ((uint32_t)(mpix * p.res_pix_stride + n_base + 4 * half) * 2u) | (pin ? 0u : kOOB);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        rr[j][g] = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(res_rsrc, r_off + 16 * g, 0, 0));
+                }
+            }
+        }
+        if (!own) {
+            char* mine = red + ((kq - owner - 1) & 3) * 8192;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                    *(f32x4*)(mine + ((j * 4 + g) * 64 + lane) * 16) = v;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (own) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int pk[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) {
+                        const f32x4 q = *(const f32x4*)(red + w * 8192 + ((j * 4 + g) * 64 + lane) * 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += q[e];
+                    }
+                    const int nl = cg * 32 + 4 * half + 8 * g;
+                    const f32x4 sc = *(const f32x4*)(ss + nl), sh = *(const f32x4*)(ss + 64 + nl);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+                    if constexpr (RES) {
+                        const uint32_t r0 = (uint32_t)(int)rr[j][g][0], r1 = (uint32_t)(int)rr[j][g][1];
+                        v[0] += Fmt16<T>::lo(r0);
+                        v[1] += Fmt16<T>::hi(r0);
+                        v[2] += Fmt16<T>::lo(r1);
+                        v[3] += Fmt16<T>::hi(r1);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+                    pk[g][0] = Fmt16<T>::pack2(v[0], v[1]);
+                    pk[g][1] = Fmt16<T>::pack2(v[2], v[3]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    auto r0 = __builtin_amdgcn_permlane32_swap(pk[g][0], pk[g + 1][0], false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(pk[g][1], pk[g + 1][1], false, false);
+                    i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, o_off[j] + 16 * (g + half), 0, 0);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 }  // namespace
@@ -750,6 +965,37 @@ static int launch_small_f(ConvArgs& a, hipStream_t stream) {
 
 int launch_small(ConvArgs& a, hipStream_t stream, int fmt) {
     return fmt == VD3D_F16 ? launch_small_f<hf16>(a, stream) : launch_small_f<short>(a, stream);
+}
+
+
+bool ksplit_shape_ok(const ConvArgs& a) {
+    return a.Cin == 256 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W &&
+           a.Cout % 64 == 0 && a.Cout / 64 <= 32 && a.wide_store && !a.out_f32 && a.wfrag &&
+           (int64_t)a.M * a.out_pix_stride * 2 < 0x7ffffff0ll && (!a.residual || (int64_t)a.M * a.res_pix_stride * 2 < 0x7ffffff0ll);
+}
+
+template <typename T>
+static int launch_ksplit_t(ConvArgs& a, hipStream_t stream) {
+    static Vd3dLdsLimit lim_res, lim_nores;
+    int rc = vd3d_raise_lds_limit((const void*)conv_ksplit256_kernel<T, true>, kKsLds, lim_res, "hipFuncSetAttribute(conv_ksplit256)");
+    if (!rc) rc = vd3d_raise_lds_limit((const void*)conv_ksplit256_kernel<T, false>, kKsLds, lim_nores, "hipFuncSetAttribute(conv_ksplit256)");
+    if (rc) return rc;
+    const int num_cu = vd3d_device_cu_count();
+    if (num_cu <= 0) return VD3D_ELAUNCH;
+    const int nslices = a.Cout / 64;
+    const int ntiles = a.B * ((a.H + kKsTH - 1) / kKsTH) * ((a.W + kKsTW - 1) / kKsTW);
+    int lanes = num_cu / (8 * nslices);
+    const int need = (ntiles + 7) / 8;
+    if (lanes > need) lanes = need;
+    if (lanes < 1) lanes = 1;
+    const int grid = 8 * lanes * nslices;
+    if (a.residual) hipLaunchKernelGGL((conv_ksplit256_kernel<T, true>), dim3(grid), dim3(512), kKsLds, stream, a, ntiles, nslices);
+    else hipLaunchKernelGGL((conv_ksplit256_kernel<T, false>), dim3(grid), dim3(512), kKsLds, stream, a, ntiles, nslices);
+    return vd3d_check_launch("conv_ksplit256");
+}
+
+int launch_ksplit(ConvArgs& a, hipStream_t stream, int fmt) {
+    return fmt == VD3D_F16 ? launch_ksplit_t<hf16>(a, stream) : launch_ksplit_t<short>(a, stream);
 }
 
 int launch_regw(ConvArgs& a, hipStream_t stream, int fmt, int ring, int abl) {
