@@ -614,14 +614,36 @@ def km3d_get_bboxes(out, P2, img_hw, score_thr=0.3, nms_iou_thr=0.5, K=100, cons
     return res
 
 
+def deconv_bn_relu(c, p, i, x):
+    """ConvTranspose2d(4x4, stride 2, padding 1, no bias) + BatchNorm2d + ReLU (detectors/KM3D_core.py:37-47); one fused HIP layer,
+    output rounded once.  ``F.conv_transpose2d`` is the reference's own operator."""
+    w = c.w('%s.%d.weight' % (p, 3 * i))                       # [Cin, Cout, 4, 4]
+    y = F.conv_transpose2d(x, w, None, stride=2, padding=1)
+    s, t = c.bn('%s.%d' % (p, 3 * i + 1))
+    return c.rnd(F.relu(_affine(y, s, t)))
+
+
+def km3d_resnet_neck(c, p, x):
+    for i in range(3):
+        x = deconv_bn_relu(c, p, i, x)
+    return x
+
+
 def km3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False, taps=None):
-    """KM3D.test_forward (detectors/KM3D.py:61-79) with the DLA-34 + DLA-Up core, B >= 1.  ``taps``: optional dict that
+    """KM3D.test_forward (detectors/KM3D.py:61-79), B >= 1, with either core of KM3D_core.py: DLA-34 + DLA-Up, or (when the
+    state_dict holds ``core.deconv_layers.0.weight``) ResNet + three transposed convolutions.  ``taps``: optional dict that
     receives (input, output) of every DCNv2 + BN + ReLU block of the up-path, keyed by its state_dict prefix."""
     c = Ctx(sd, rnd)
     if taps is not None:
         c.taps = taps
-    levels = dla34(c, 'core.backbone', img.float())
-    feat = dla_seg_upsample(c, 'core.deconv_layers', levels)
+    if c.has('core.deconv_layers.0.weight'):
+        bb = cfg.backbone
+        last = resnet(c, 'core.backbone', img.float(), depth=bb.depth, num_stages=getattr(bb, 'num_stages', 4),
+                      out_indices=tuple(getattr(bb, 'out_indices', (3,))), dilations=tuple(getattr(bb, 'dilations', (1, 1, 1, 1))))[-1]
+        feat = km3d_resnet_neck(c, 'core.deconv_layers', last)
+    else:
+        levels = dla34(c, 'core.backbone', img.float())
+        feat = dla_seg_upsample(c, 'core.deconv_layers', levels)
     heads = list(cfg.head.layer_cfg.head_dict.keys())
     out = km3d_heads(c, feat, heads)
     tc = cfg.head.test_cfg

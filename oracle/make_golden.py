@@ -146,6 +146,7 @@ KM3D_CASES = {
     'km3d_dla34_96x320': dict(H=96, W=320, frames=2, wseed=7, iseed=11, score_thr=0.3),
     'km3d_dla34_192x640': dict(H=192, W=640, frames=1, wseed=7, iseed=12, score_thr=0.3),
     'km3d_dla34_512x1760': dict(H=512, W=1760, frames=1, wseed=7, iseed=13, score_thr=0.3),      # BASELINE config 5 at size
+    'km3d_res18_192x640': dict(H=192, W=640, frames=2, wseed=9, iseed=14, score_thr=0.3, resnet=18, head_gain=0.3),   # config/KM3D_example's core
 }
 
 
@@ -156,9 +157,14 @@ def build_reference_km3d(case, tmp):
     from oracle import dcn_ref
     ref_dcn.modulated_deform_conv = lambda x, off, m, w, b, s, p, d, g, dg: dcn_ref.deform_conv_forward(x, off, m, w, b, s, p, d, g, dg)
     ref_dla.DLA.load_pretrained_model = lambda self, *a, **k: None
-    cfg = syn.km3d_cfg(score_thr=case['score_thr'], output_w=case['W'] // 4)
+    if case.get('resnet'):
+        cfg = syn.km3d_resnet_cfg(score_thr=case['score_thr'], output_w=case['W'] // 4, depth=case['resnet'])
+    else:
+        cfg = syn.km3d_cfg(score_thr=case['score_thr'], output_w=case['W'] // 4)
     model = DD['KM3D'](cfg).eval()
     sd = syn.seeded_state_dict(model.state_dict(), seed=case['wseed'])
+    if case.get('head_gain'):
+        syn.scale_km3d_head(sd, case['head_gain'])
     model.load_state_dict(sd)
     return model, cfg, sd
 
@@ -184,8 +190,9 @@ def run_km3d_case(name, case):
             out['f%d_labels' % f] = labels.numpy()
             out['f%d_features_sub' % f] = subsample(feats).numpy()
             print(name, 'frame', f, 'detections', len(scores), 'hm max', float(torch.sigmoid(maps['hm']).max()), 'feat std', float(feats.std()))
-    out['meta'] = np.array([34, case['H'], case['W'], case['frames'], case['wseed'], case['iseed']])
+    out['meta'] = np.array([case.get('resnet', 34), case['H'], case['W'], case['frames'], case['wseed'], case['iseed']])
     out['score_thr'] = np.float32(case['score_thr'])
+    out['head_gain'] = np.float64(case.get('head_gain', 1.0))
     np.savez_compressed(os.path.join(GOLDEN_DIR, name + '.npz'), **out)
 
 

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 
 from oracle import detector_oracle as orc
 from tests.common import assert_detections_close, load_golden, rel_err, subsample, matched_fraction
-from tests.test_km3d_oracle_golden import km3d_case_from_golden
+from tests.test_km3d_oracle_golden import km3d_case_from_golden, km3d_state_dict
 from visualdet3d_amd.utils import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -86,6 +86,43 @@ def test_fp32_mode_matches_reference_golden(name):
         s, b, l = [t.cpu() for t in outs[f]]
         assert_detections_close((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=2e-3,
                                 what='%s frame %d' % (name, f))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_resnet18_convtranspose_core_matches_golden_and_oracle(dtype):
+    """config/KM3D_example's core (ResNet-18 + 3 x ConvTranspose2d 4x4/s2 + BN + ReLU, KM3D_core.py:34-47): the transposed
+    convolutions run as one 3x3 implicit GEMM with 4*Cout channels + pixel shuffle.  fp32 against the reference's golden outputs;
+    bf16 / fp16 against the oracle with the same rounding points (no DCN here: ResNet-path tolerances)."""
+    from visualdet3d_amd.networks.detectors import KM3D
+    name = 'km3d_res18_192x640'
+    g = load_golden(name)
+    cfg, (img, P2), winit = km3d_case_from_golden(g)
+    m = KM3D(cfg)
+    sd = km3d_state_dict(m, g, winit)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    outs = m.test_forward_batched(img.cuda(), P2.cuda())
+    maps = m._last_raw
+    if dtype == torch.float32:
+        for f in range(img.shape[0]):
+            for h in orc.KM3D_HEADS:
+                got = maps[h][f:f + 1].permute(0, 3, 1, 2).contiguous().cpu()
+                assert rel_err(subsample(got), g['f%d_%s_sub' % (f, h)]) < 1e-3, h
+            s, b, l = [t.cpu() for t in outs[f]]
+            assert_detections_close((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=2e-3,
+                                    what='%s frame %d' % (name, f))
+        return
+    rnd = orc.bf16_round if dtype == torch.bfloat16 else orc.fp16_round
+    with torch.no_grad():
+        dets, st = orc.km3d_forward(sd, cfg, img, P2, rnd=rnd, return_stages=True)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    for h in orc.KM3D_HEADS:
+        assert rel_err(maps[h].permute(0, 3, 1, 2).cpu(), st[h]) < tol, h
+    for f in range(img.shape[0]):
+        s, b, l = [t.cpu() for t in outs[f]]
+        assert abs(len(s) - len(dets[f][0])) <= 5
+        assert matched_fraction((s, b, l), dets[f], rtol=3e-2) >= 0.9
 
 
 def test_bf16_mode_close_to_bf16_oracle():

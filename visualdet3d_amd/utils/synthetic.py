@@ -100,6 +100,26 @@ def km3d_cfg(obj_types=('Car', 'Pedestrian', 'Cyclist'), score_thr=0.3, output_w
     return det
 
 
+def km3d_resnet_cfg(obj_types=('Car', 'Pedestrian', 'Cyclist'), score_thr=0.3, output_w=320, depth=18):
+    """``cfg.detector`` of config/KM3D_example:126-167 as shipped: ResNet-18 backbone + ConvTranspose neck, head 256 -> 64
+    (``name`` added: KM3DCore reads ``backbone['name']``, KM3D_core.py:17)."""
+    det = km3d_cfg(obj_types, score_thr, output_w)
+    det.backbone = EasyDict(name='resnet', depth=depth, pretrained=False, frozen_stages=-1, num_stages=4, out_indices=(3,),
+                            norm_eval=False, dilations=(1, 1, 1, 1))
+    det.head.layer_cfg.input_features = 256
+    det.head.layer_cfg.head_features = 64
+    return det
+
+
+def scale_km3d_head(sd, gain):
+    """Scale the last (1x1) conv of every KM3D head branch in place: with head_features < input_features the fan-out init of
+    ``seeded_state_dict`` saturates the heat-map (sigmoid ~ 1 everywhere -> tied scores); parity cases want spread-out scores."""
+    for k in sd:
+        if k.startswith('bbox_head.head_layers.') and k.endswith('.2.weight'):
+            sd[k] = sd[k] * gain
+    return sd
+
+
 # --------------------------------------------------------------------------------------------- priors
 def write_synthetic_priors(preprocessed_path, obj_types, n_ratios, n_scales=16):
     """Write ``anchor_{mean,std}_{type}.npy`` under ``<preprocessed_path>/training``.
