@@ -6,8 +6,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VD3D_TUNING_LIB=1 (tools/bench_conv.py only): the -DVD3D_TUNING build with the experimental tiles / timing ablations
-LIB_PATH = os.path.join(_HERE, 'libvd3d_hip_tuning.so' if os.environ.get('VD3D_TUNING_LIB') else 'libvd3d_hip.so')
+# VD3D_TUNING_LIB=1 (tools/ only): the -DVD3D_TUNING build with the experimental tiles / timing ablations; a value ending in
+# .so names an A/B build of the library next to this file
+_T = os.environ.get('VD3D_TUNING_LIB', '')
+LIB_PATH = os.path.join(_HERE, _T if _T.endswith('.so') else ('libvd3d_hip_tuning.so' if _T else 'libvd3d_hip.so'))
 
 VD3D_BF16 = 0
 VD3D_F32 = 1

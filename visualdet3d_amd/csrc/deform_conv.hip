@@ -18,6 +18,7 @@
 #pragma clang fp contract(off)
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -210,6 +211,8 @@ __global__ void __launch_bounds__(256) dcn_kernel(const DcnArgs p) {
         }
 }
 
+template <typename T> constexpr int kDcnGeoBytes = sizeof(T) == 2 ? 32 : 48;   // LDS bytes per (pixel, tap) geometry entry
+
 // ---- NHWC fast path --------------------------------------------------------------------------------------------------
 // Channel-contiguous input / output (the engine's activations), groups == deformable_groups == 1, Cg a multiple of the
 // 128-byte K slice.  Differences from the generic kernel above, which gathers element by element through arbitrary strides
@@ -220,14 +223,27 @@ __global__ void __launch_bounds__(256) dcn_kernel(const DcnArgs p) {
 //     output channels instead of once per 64-channel tile;
 //   * column and weight tiles are double buffered in LDS: sampling of slice k+1 overlaps the MFMAs of slice k, one barrier
 //     per slice.
+// v_fma_mix_f32: fp32 fma whose first operand is the low / high fp16 half of a dword -- the unpack costs no instruction
+VD3D_DEV float mix_mul_lo(int x, float w) { float d; asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(w)); return d; }
+VD3D_DEV float mix_mul_hi(int x, float w) { float d; asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(w)); return d; }
+VD3D_DEV float mix_fma_lo(int x, float w, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(w), "v"(c)); return d; }
+VD3D_DEV float mix_fma_hi(int x, float w, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(w), "v"(c)); return d; }
+
 template <typename T, int BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ? 2 : 4, 8))) dcn_nhwc_kernel(const DcnArgs p) {
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES, BKE = 128 / ES;
     constexpr int TN = BN / 64;                      // 32-channel MFMA blocks per wave (2 x 2 waves: 32 px x BN/2 ch)
     constexpr int STAGE = (64 + BN) * 128;
+    // geometry entry: int32 off[4] (byte offset of the corner's channel run; kDcnOOB = corner outside the image: the buffer load
+    // returns zeros without a branch) + float w[4].  16-bit formats: w already carries the modulation (the blended value is
+    // rounded to 16 bits next, so (sum w x) m and sum (w m) x agree except on rounding ties); fp32 keeps the reference order
+    // with m in a 9th word.
+    constexpr bool FOLD = ES == 2;
+    constexpr int GE = kDcnGeoBytes<T>;
+    constexpr uint32_t kDcnOOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* geo_tab = smem + 2 * STAGE;                // [tap][64 pixels] x { int32 off[4]; float w[4] (already x modulation) }
+    char* geo_tab = smem + 2 * STAGE;                // [tap][64 pixels] x entry
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z;
@@ -238,14 +254,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     // Sampling map: 8 consecutive lanes fetch the 8 16-byte vectors of ONE pixel's 128-byte channel run, so a corner load of a
     // wave touches 8 cache lines (one per pixel) instead of 64; a thread handles pixels prow0 and prow0 + 32, vector vslot.
     const int prow0 = tid >> 3, vslot = tid & 7;
-    const int srow = tid & 63;                       // (pixel of this lane for the phase-0 / bounds bookkeeping below)
-    const int mypix = pix0 + srow;
-    const bool pvalid = mypix < HoWo;
-    const int ho = pvalid ? mypix / p.Wo : 0, wo = pvalid ? mypix - (mypix / p.Wo) * p.Wo : 0;
-    const int h_in = ho * p.sh - p.ph, w_in = wo * p.sw - p.pw;
-    const int64_t off_base = b * p.off_sb + ho * p.off_sy + wo * p.off_sx;
-    const int64_t msk_base = b * p.msk_sb + ho * p.msk_sy + wo * p.msk_sx;
-    const char* in_b = (const char*)p.in + (int64_t)b * p.in_sb * ES;
+    // one image / one BN-row weight panel per workgroup: 32-bit offsets, out-of-range rows read as zeros
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in + (int64_t)b * p.in_sb * ES), 0, 0x7fffffff, 0x00020000);
+    const int wrows = p.O - o0 < BN ? p.O - o0 : BN;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.w + (int64_t)o0 * p.Kpad * ES), 0, wrows * p.Kpad * ES, 0x00020000);
     const int chunks = p.Cg / BKE;                   // K slices per tap
     const int nk = KK * chunks;
 
@@ -255,57 +267,64 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     for (int it = tid; it < 64 * KK; it += 256) {
         const int tap = it >> 6, px = it & 63;
         const int pix = pix0 + px;
-        int32_t go[4] = {0, 0, 0, 0};
+        uint32_t go[4] = {kDcnOOB, kDcnOOB, kDcnOOB, kDcnOOB};
         float gw[4] = {0.f, 0.f, 0.f, 0.f};
+        float m = 0.f;
         if (pix < HoWo) {
             const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
             const int ti = tap / p.kw, tj = tap - ti * p.kw;
             const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
             const float off_h = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
             const float off_w = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
-            float m = 1.f;
-            if (p.mask) {
-                m = p.mask[b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx + (int64_t)tap * p.msk_sc];
-                if (p.mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
-            }
             const float h_im = (float)(oy * p.sh - p.ph + ti * p.dh) + off_h;
             const float w_im = (float)(ox * p.sw - p.pw + tj * p.dw) + off_w;
             if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                m = 1.f;
+                if (p.mask) {
+                    m = p.mask[b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx + (int64_t)tap * p.msk_sc];
+                    if (p.mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
+                }
                 const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
                 const int h_high = h_low + 1, w_high = w_low + 1;
                 const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
                 const float hh = 1.f - lh, hw = 1.f - lw;
                 const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
-                if (t_ok && l_ok) { gw[0] = hh * hw; go[0] = (int32_t)((h_low * p.in_sy + w_low * p.in_sx) * ES); }
-                if (t_ok && r_ok) { gw[1] = hh * lw; go[1] = (int32_t)((h_low * p.in_sy + w_high * p.in_sx) * ES); }
-                if (b_ok && l_ok) { gw[2] = lh * hw; go[2] = (int32_t)((h_high * p.in_sy + w_low * p.in_sx) * ES); }
-                if (b_ok && r_ok) { gw[3] = lh * lw; go[3] = (int32_t)((h_high * p.in_sy + w_high * p.in_sx) * ES); }
-                // weights stay unmodulated: the modulation multiplies the blended value (reference order)
-                *(float*)(geo_tab + (size_t)it * 48 + 32) = m;
-            } else {
-                *(float*)(geo_tab + (size_t)it * 48 + 32) = 0.f;
+                if (t_ok && l_ok) { gw[0] = hh * hw; go[0] = (uint32_t)((h_low * p.in_sy + w_low * p.in_sx) * ES); }
+                if (t_ok && r_ok) { gw[1] = hh * lw; go[1] = (uint32_t)((h_low * p.in_sy + w_high * p.in_sx) * ES); }
+                if (b_ok && l_ok) { gw[2] = lh * hw; go[2] = (uint32_t)((h_high * p.in_sy + w_low * p.in_sx) * ES); }
+                if (b_ok && r_ok) { gw[3] = lh * lw; go[3] = (uint32_t)((h_high * p.in_sy + w_high * p.in_sx) * ES); }
             }
-        } else {
-            *(float*)(geo_tab + (size_t)it * 48 + 32) = 0.f;
         }
-        *(i32x4*)(geo_tab + (size_t)it * 48) = i32x4{go[0], go[1], go[2], go[3]};
-        *(f32x4*)(geo_tab + (size_t)it * 48 + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gw[c] *= m;
+        } else {
+            *(float*)(geo_tab + (size_t)it * GE + 32) = m;   // weights stay unmodulated: the modulation multiplies the blended value
+        }
+        *(i32x4*)(geo_tab + (size_t)it * GE) = i32x4{(int)go[0], (int)go[1], (int)go[2], (int)go[3]};
+        *(f32x4*)(geo_tab + (size_t)it * GE + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
     }
     __syncthreads();
 
     struct Geo { int32_t o[4]; float w[4]; float m; };
     auto geometry = [&](int tap, int prow) {
         Geo g;
-        const char* e = geo_tab + (size_t)(tap * 64 + prow) * 48;
+        const char* e = geo_tab + (size_t)(tap * 64 + prow) * GE;
         const i32x4 go = *(const i32x4*)e;
         const f32x4 gw = *(const f32x4*)(e + 16);
 #pragma unroll
         for (int c = 0; c < 4; ++c) { g.o[c] = go[c]; g.w[c] = gw[c]; }
-        g.m = *(const float*)(e + 32);
+        g.m = FOLD ? 1.f : *(const float*)(e + 32);
         return g;
     };
     // global -> registers for slice kt (sampled column vectors + this thread's share of the weight tile)
     constexpr int WV = BN * 8 / 256;                 // 16-byte weight vectors per thread per slice
+    int w_voff[WV];
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+        const int v = tid + 256 * i;
+        w_voff[i] = ((v >> 3) * p.Kpad + (v & 7) * VE) * ES;
+    }
     Geo geo[2] = {geometry(0, prow0), geometry(0, prow0 + 32)};
     int geo_tap = 0;
     auto fetch = [&](int kt, i32x4 (&cv)[2][4], i32x4 (&wv)[WV]) {
@@ -313,19 +332,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         if (tap != geo_tap) { geo[0] = geometry(tap, prow0); geo[1] = geometry(tap, prow0 + 32); geo_tap = tap; }
         const int coff = (c0 + vslot * VE) * ES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                cv[i][c] = i32x4{0, 0, 0, 0};
-                if (geo[i].w[c] != 0.f) cv[i][c] = *(const i32x4*)(in_b + geo[i].o[c] + coff);
-            }
-        }
+            for (int c = 0; c < 4; ++c)
+                cv[i][c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, geo[i].o[c] + coff, 0, 0));
 #pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int v = tid + 256 * i, row = v >> 3, slot = v & 7;
-            wv[i] = i32x4{0, 0, 0, 0};
-            if (o0 + row < p.O) wv[i] = *(const i32x4*)((const char*)p.w + ((int64_t)(o0 + row) * p.Kpad + kt * BKE + slot * VE) * ES);
-        }
+        for (int i = 0; i < WV; ++i)
+            wv[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], kt * (BKE * ES), 0));
     };
     // registers -> LDS stage: blend the four corners in fp32 (reference order), modulate, round, store swizzled
     auto stash = [&](int st, const i32x4 (&cv)[2][4], const i32x4 (&wv)[WV]) {
@@ -336,16 +349,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
             Vec16<T> c1, c2, c3, c4, o;
             c1.raw = cv[i][0]; c2.raw = cv[i][1]; c3.raw = cv[i][2]; c4.raw = cv[i][3];
             float vals[VE];
+            if constexpr (std::is_same<T, hf16>::value) {
+                // fp16: the four-term fma chain on v_fma_mix_f32 (fp16 operand read in place, fp32 weight and accumulator)
 #pragma unroll
-            for (int e = 0; e < VE; ++e) {
-                float val;
-                if constexpr (sizeof(T) == 2) {
-                    // bf16 mode: the result is rounded to bf16 anyway -- fused multiply-adds (4 ops instead of 7)
-                    val = fmaf(geo[i].w[3], c4.get(e), fmaf(geo[i].w[2], c3.get(e), fmaf(geo[i].w[1], c2.get(e), geo[i].w[0] * c1.get(e))));
-                } else {
-                    val = geo[i].w[0] * c1.get(e) + geo[i].w[1] * c2.get(e) + geo[i].w[2] * c3.get(e) + geo[i].w[3] * c4.get(e);
+                for (int d = 0; d < 4; ++d) {
+                    vals[2 * d] = mix_fma_lo(cv[i][3][d], geo[i].w[3], mix_fma_lo(cv[i][2][d], geo[i].w[2], mix_fma_lo(cv[i][1][d], geo[i].w[1], mix_mul_lo(cv[i][0][d], geo[i].w[0]))));
+                    vals[2 * d + 1] = mix_fma_hi(cv[i][3][d], geo[i].w[3], mix_fma_hi(cv[i][2][d], geo[i].w[2], mix_fma_hi(cv[i][1][d], geo[i].w[1], mix_mul_hi(cv[i][0][d], geo[i].w[0]))));
                 }
-                vals[e] = val * geo[i].m;
+            } else {
+#pragma unroll
+                for (int e = 0; e < VE; ++e) {
+                    if constexpr (sizeof(T) == 2) {
+                        // bf16 mode: the result is rounded to bf16 anyway -- fused multiply-adds (4 ops instead of 7)
+                        vals[e] = fmaf(geo[i].w[3], c4.get(e), fmaf(geo[i].w[2], c3.get(e), fmaf(geo[i].w[1], c2.get(e), geo[i].w[0] * c1.get(e))));
+                    } else {
+                        vals[e] = (geo[i].w[0] * c1.get(e) + geo[i].w[1] * c2.get(e) + geo[i].w[2] * c3.get(e) + geo[i].w[3] * c4.get(e)) * geo[i].m;
+                    }
+                }
             }
             if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -512,7 +532,7 @@ __global__ void __launch_bounds__(256) dcn_columns_kernel(const DcnArgs p, T* __
 
 template <typename T, int BN>
 int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
-    const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * 48;   // two stages + the geometry table
+    const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * kDcnGeoBytes<T>;   // two stages + the geometry table
     if (LDS > 160 * 1024) { vd3d_set_error("deform_conv: kernel window too large for the NHWC path"); return VD3D_EINVAL; }
     static Vd3dLdsLimit lim;
     if (const int rc = vd3d_raise_lds_limit((const void*)dcn_nhwc_kernel<T, BN>, 160 * 1024, lim, "hipFuncSetAttribute(dcn_nhwc)")) return rc;
