@@ -102,6 +102,14 @@ int vd3d_preprocess_image(const uint8_t* src_hwc, int Hs, int Ws, int crop_top, 
 int vd3d_pack_image_nhwc4(const float* in_nchw, void* out, int B, int H, int W,
                           int pad_y, int pad_l, int pad_r, int dtype, void* stream);
 
+/* 7x7 / stride 1 / pad 3 convolution of a 3-channel fp32 NCHW image to Cout <= 16 channels + folded BN + ReLU, 16-bit NHWC
+ * output: the DLA base layer (backbones/dla.py:116-117) without a packed copy of the image (the halo is converted in LDS).
+ * weight_frag: [7][64][8] elements of `dtype` (VD3D_BF16 | VD3D_F16), the MFMA operand image
+ *   weight_frag[ky][l][e] = w[o = l & 15][c = e & 3][ky][kx = 2 * (l >> 4) + (e >> 2)]   (0 where c = 3, kx = 7 or o >= Cout).
+ * out: [B][H][W][out_pix_stride] (out_pix_stride % 4 == 0, 8-byte aligned); scale / shift: fp32[Cout] or NULL. */
+int vd3d_image_conv7x7(const float* img_nchw, const void* weight_frag, const float* scale, const float* shift, void* out,
+                       int B, int H, int W, int Cout, int out_pix_stride, int relu, int dtype, void* stream);
+
 /* General form of the image packer: `cpad` = 4 or 8 channels per pixel (3 real + zeros), independent borders.
  * Used by DLA's 7x7 stride-1 base layer (backbones/dla.py:247-251): with 8-channel bf16 pixels every pixel is 16 bytes,
  * so a kernel row (8 px x 8 ch = 64 elements) is a 16-byte aligned run for any output column. */

@@ -46,6 +46,30 @@ def test_dla_helper_kernels():
             assert rel_err(got2, want + addr) < 2 * tol
 
 
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,W,O', [(2, 21, 100, 16), (1, 64, 192, 16), (1, 9, 70, 12)])
+def test_image_conv7x7_base_layer_kernel(dtype, B, H, W, O):
+    """vd3d_image_conv7x7 (DLA base layer, backbones/dla.py:116-117: 7x7 / s1 / p3 conv + BN + ReLU on the fp32 image) against
+    torch fp32 on the image / weights rounded to the compute dtype, ragged tile edges included, and against the generic
+    implicit-GEMM path it replaces (same rounding points: equal up to the fp32 summation order)."""
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    img = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(O, 3, 7, 7, generator=g) * 0.1
+    bn = (torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g) * 0.1, torch.randn(O, generator=g) * 0.1, torch.rand(O, generator=g) + 0.5, 1e-5)
+    pc = ops.pack_image_conv(w.cuda(), tuple(t.cuda() if torch.is_tensor(t) else t for t in bn), dtype, 1, 3)
+    assert pc.w_frag7 is not None
+    got = ops.image_conv(img.cuda(), pc, relu=True).float().cpu().permute(0, 3, 1, 2)
+    scale = bn[0] / torch.sqrt(bn[3] + bn[4])
+    shift = bn[1] - bn[2] * scale
+    want = F.relu(F.conv2d(img.to(dtype).float(), w.to(dtype).float(), None, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    assert got.shape == want.shape
+    assert rel_err(got, want.to(dtype).float()) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+    pc.w_frag7 = None                                   # the generic path
+    old = ops.image_conv(img.cuda(), pc, relu=True).float().cpu().permute(0, 3, 1, 2)
+    assert rel_err(got, old) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
 @pytest.mark.parametrize('H,W,B,seed', [(24, 80, 2, 0), (48, 160, 3, 1)])
 def test_decode_matches_oracle_on_identical_maps(H, W, B, seed):
     from visualdet3d_amd.networks.heads.km3d_head import KM3DHead

@@ -101,6 +101,7 @@ SIGNATURES = {
     'vd3d_deform_columns': (c_int, [C.POINTER(DcnParams), c_void_p, c_void_p]),
     'vd3d_look_ground_sample': (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_float, c_float, c_int, c_void_p]),
     'vd3d_pack_image_nhwc': (c_int, [c_void_p, c_void_p] + [c_int] * 9 + [c_void_p]),
+    'vd3d_image_conv7x7': (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     'vd3d_maxpool2x2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_dwconv_transpose': (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     'vd3d_km3d_workspace_bytes': (c_int64, [c_int] * 5),

@@ -264,16 +264,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     // ---- phase 0: the sampling geometry of every (pixel, tap) of the tile, once, into LDS.  In the K loop a thread then
     // needs no dependent global load (offset -> address -> corner): the corner loads of slice k+1 are issued straight away
     // and overlap the MFMAs of slice k.
-    for (int it = tid; it < 64 * KK; it += 256) {
-        const int tap = it >> 6, px = it & 63;
-        const int pix = pix0 + px;
+    // a thread owns ONE pixel (lane) and every fourth tap (wave): the pixel's row / column is divided out once and the tap's
+    // (ti, tj) is wave-uniform (scalar)
+    {
+    const int px = lane, pix = pix0 + px;
+    const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
+    const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
+    const int64_t mb = b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx;
+    for (int tap = wave; tap < KK; tap += 4) {
+        const int it = tap * 64 + px;
         uint32_t go[4] = {kDcnOOB, kDcnOOB, kDcnOOB, kDcnOOB};
         float gw[4] = {0.f, 0.f, 0.f, 0.f};
         float m = 0.f;
         if (pix < HoWo) {
-            const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
             const int ti = tap / p.kw, tj = tap - ti * p.kw;
-            const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
             const float off_h = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
             const float off_w = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
             const float h_im = (float)(oy * p.sh - p.ph + ti * p.dh) + off_h;
@@ -281,8 +285,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
             if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
                 m = 1.f;
                 if (p.mask) {
-                    m = p.mask[b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx + (int64_t)tap * p.msk_sc];
-                    if (p.mask_sigmoid) m = 1.0f / (1.0f + expf(-m));
+                    m = p.mask[mb + (int64_t)tap * p.msk_sc];
+                    // 16-bit formats: v_exp / v_rcp (1 ulp each; the blended value is rounded to 11 / 8 bits next)
+                    if (p.mask_sigmoid) m = FOLD ? __frcp_rn(1.0f + __expf(-m)) : 1.0f / (1.0f + expf(-m));
                 }
                 const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
                 const int h_high = h_low + 1, w_high = w_low + 1;
@@ -303,6 +308,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         }
         *(i32x4*)(geo_tab + (size_t)it * GE) = i32x4{(int)go[0], (int)go[1], (int)go[2], (int)go[3]};
         *(f32x4*)(geo_tab + (size_t)it * GE + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
+    }
     }
     __syncthreads();
 
@@ -429,17 +435,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         for (int g = 0; g < 4; ++g) {
             const int oc = o0 + wn * (BN / 2) + i * 32 + 8 * g + 4 * half;
             float v[4];
+            if (oc + 3 < p.O) {                      // the quad's per-channel constants as three 16-byte loads
+                const f32x4 bz = p.bias ? *(const f32x4*)(p.bias + oc) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 sc = p.scale ? *(const f32x4*)(p.scale + oc) : f32x4{1.f, 1.f, 1.f, 1.f};
+                const f32x4 sh = p.shift ? *(const f32x4*)(p.shift + oc) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = oc + e;
-                float x = acc[i][4 * g + e];
-                if (o < p.O) {
-                    if (p.bias) x += p.bias[o];
-                    if (p.scale) x = x * p.scale[o];
-                    if (p.shift) x = x + p.shift[o];
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[i][4 * g + e];
+                    if (p.bias) x += bz[e];
+                    if (p.scale) x = x * sc[e];
+                    if (p.shift) x = x + sh[e];
                     if (p.relu) x = fmaxf(x, 0.f);
+                    v[e] = x;
                 }
-                v[e] = x;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = oc + e;
+                    float x = acc[i][4 * g + e];
+                    if (o < p.O) {
+                        if (p.bias) x += p.bias[o];
+                        if (p.scale) x = x * p.scale[o];
+                        if (p.shift) x = x + p.shift[o];
+                        if (p.relu) x = fmaxf(x, 0.f);
+                    }
+                    v[e] = x;
+                }
             }
             if (oc + 3 < p.O && ((ob + oc) * ES) % (4 * ES) == 0) {
                 if constexpr (sizeof(T) == 2) {

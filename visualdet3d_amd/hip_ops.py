@@ -561,6 +561,12 @@ def pack_image_conv(weight, bn, dtype, stride, pad):
     scale, shift = fold_bn(None, bn, O, dev)
     pc = PackedConv(packed, scale, shift, row, O, kh, 1, stride, 0, 1, Kpad, CoutPad, dtype)
     pc.cpad, pc.k, pc.img_pad = cpad, kh, pad
+    pc.w_frag7 = None
+    if is16(dtype) and (kh, stride, pad) == (7, 1, 3) and O <= 16:
+        # operand image of vd3d_image_conv7x7 (layout: include/vd3d.h): [ky][lane][e] <- w[o = l & 15][c = e & 3][ky][kx = 2 (l >> 4) + (e >> 2)]
+        wf = torch.zeros((16, 4, 7, 8), dtype=torch.float32, device=dev)          # o, c, ky, kx (kx = 7 and c = 3 stay zero)
+        wf[:O, :3, :, :7] = weight.detach().float()
+        pc.w_frag7 = wf.reshape(16, 4, 7, 4, 2).permute(2, 3, 0, 4, 1).contiguous().to(dtype)   # ky, kq, o, kx & 1, c  ==  [7][64][8]
     return pc
 
 
@@ -570,6 +576,12 @@ def image_conv(img_nchw, pc, relu=True):
     assert Cc == 3 and img_nchw.dtype == torch.float32 and img_nchw.is_contiguous()
     dtype, k, s, p, cpad = pc.dtype, pc.k, pc.stride, pc.img_pad, pc.cpad
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    if getattr(pc, 'w_frag7', None) is not None and pc.Cout % 4 == 0:
+        # full-resolution 7x7 base layer: dedicated streaming kernel, no packed copy of the image
+        out = torch.empty((B, H, W, pc.Cout), dtype=dtype, device=img_nchw.device)
+        check(_lib.lib().vd3d_image_conv7x7(_p(img_nchw), _p(pc.w_frag7), _p(pc.scale) if pc.scale is not None else None, _p(pc.shift), _p(out),
+                                            B, H, W, pc.Cout, pc.Cout, int(relu), dtype_code(dtype), _stream()), 'vd3d_image_conv7x7')
+        return out
     pad_r = max(p, (Wo - 1) * s + 8 - W - p)
     Wp = W + p + pad_r
     if (Wp * cpad * packed_elem_size(dtype)) % 16:
