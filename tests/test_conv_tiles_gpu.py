@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79, 73, 61, 68, 69}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 76, 79, 73, 61, 68, 69, 58}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69]
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58]
 
 
 class forced_tile:
@@ -101,6 +101,15 @@ def _shapes_for(cfg):
             (1, 17, 26, 256, 192, dict(residual=True, in_extra=64, out_extra=64)),
             (16, 24, 80, 256, 256, dict(residual=True)),                # layer3 at the bench shape: 4 slices, 7.5 tiles per workgroup
             (3, 40, 72, 256, 256, dict(residual=False, bn=False)),
+        ]
+    if cfg == 58:       # point-wise expansion streaming kernel: 1x1 / s1, Cin 64 | 128, 256-channel slices, 32-pixel blocks, no LDS
+        return [
+            (1, 7, 13, 64, 256, dict(k=1, pad=0, residual=True)),                        # M = 91: ragged last block, fewer blocks than waves
+            (2, 9, 31, 128, 512, dict(k=1, pad=0, residual=True, bn=False)),             # two slices, two K chunks
+            (1, 16, 32, 64, 512, dict(k=1, pad=0, residual=False, relu=False)),          # no residual (down-sample branch)
+            (1, 10, 18, 128, 256, dict(k=1, pad=0, residual=True, in_extra=64, out_extra=64)),   # channel-slice views
+            (8, 36, 160, 64, 256, dict(k=1, pad=0, residual=True)),                      # many blocks per workgroup (steady-state prefetch path)
+            (4, 18, 80, 128, 1024, dict(k=1, pad=0, residual=False)),                    # four slices
         ]
     if cfg == 69:       # small-channel streaming kernel: Cin 16 | 32 | 64, Cout <= 32, stride 1 | 2, 16-bit or fp32 output, no residual
         return [

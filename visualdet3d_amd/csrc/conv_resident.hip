@@ -868,6 +868,149 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// =====================================================================================================
+// Point-wise (1x1 / stride 1) expansion convolutions with few input channels (ResNet-50 bottleneck conv3 and the first
+// stage's down-sample branch: 64 -> 256 at 64 x 72 x 320, 128 -> 512): K is one or two 64-deep slices, the layer moves
+// 0.9 - 1.7 GB (output + residual dominate) and the tile kernels -- one workgroup per CU, load -> MFMA -> epilogue in
+// sequence, nothing in flight across tiles -- reach 2.1 - 2.8 TB/s of the ~5 TB/s a mixed read / write stream gets here.
+//   * no LDS, no barriers: a wave keeps its 64 output channels x CIN weights in registers (MFMA A operand, 32 | 64 VGPRs)
+//     and walks 32-pixel blocks; the pixel operand is loaded straight into the MFMA B layout (lane = pixel, 16 bytes = 8
+//     consecutive input channels: the four sub-step loads of a 64-channel chunk cover the pixel's 128-byte line);
+//   * the four waves of a workgroup take the same pixel block and four different 64-channel groups (256 channels per
+//     workgroup; the slices of one block sequence sit on the same XCD), so the block's input is fetched once per CU;
+//   * the next block's pixel fragments and residual quads are requested before the current block's MFMAs: plain loads, the
+//     compiler's own vmcnt bookkeeping; 3 - 4 workgroups per CU keep > 200 KB in flight per CU.
+constexpr int kPwRow = 144;      // bytes per pixel row of the output staging tile (128 + pad: 16-byte aligned rows, 2-way bank conflicts)
+template <typename T, int CIN, bool RES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN == 64 ? 4 : 2, 8))) conv_pw_kernel(const ConvArgs p, int nblk, int nslices) {
+    constexpr int NCH = CIN / 64;
+    __shared__ __attribute__((aligned(16))) float ss[512];     // this slice's folded BN scale | shift
+    __shared__ __attribute__((aligned(16))) char otile[4][32 * kPwRow];   // per wave: one block's outputs, [pixel][64 channels] (+ pad)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, half = lane >> 5;
+    // blockIdx -> (slice, block lane): blocks b, b + 8, ... share an XCD; consecutive ones take the slices of one block lane
+    const int bx = blockIdx.x, xcd = bx & 7, j8 = bx >> 3;
+    const int slice = j8 % nslices;
+    const int lanes_per_xcd = (int)(gridDim.x >> 3) / nslices;
+    const int blane = xcd * lanes_per_xcd + j8 / nslices, bstride = 8 * lanes_per_xcd;
+    const int n_base = slice * 256 + wave * 64;                // first output channel of this wave
+
+    i32x4 wf[2][NCH][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                wf[cb][c][ks] = *(const i32x4*)(p.wfrag + ((((size_t)((n_base >> 5) + cb) * NCH + c) * 4 + ks) * 64 + lane) * 16);
+    ss[tid] = p.scale ? p.scale[slice * 256 + tid] : 1.f;
+    ss[256 + tid] = p.shift ? p.shift[slice * 256 + tid] : 0.f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x80000000u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.residual : p.out), 0, 0x80000000u, 0x00020000);
+
+    struct Blk { i32x4 b[NCH][4]; };                  // pixel fragments of one 32-pixel block
+    auto request = [&](int blk, Blk& q) {
+        const int m = blk * 32 + lr;
+        const bool ok = blk < nblk && m < p.M;
+        const uint32_t boff = ok ? (uint32_t)(m * p.in_pix_stride * 2 + half * 16) : kOOB;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                q.b[c][ks] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, boff, c * 128 + ks * 32, 0));
+    };
+    auto finish = [&](int blk, const Blk& q) {
+        const int m = blk * 32 + lr;
+        // residual in the STORE layout (16 bytes = channels 16 j + 8 half .. + 7), requested ahead of the block's MFMAs (a whole block
+        // ahead costs 16 more live registers: spills at 3 waves per SIMD)
+        i32x4 rs[2][2];
+        if constexpr (RES) {
+            const uint32_t roff = m < p.M ? (uint32_t)((m * p.res_pix_stride + n_base + 8 * half) * 2) : kOOB;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    rs[cb][j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, roff, (cb * 32 + 16 * j) * 2, 0));
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) Fmt16<T>::mfma32(wf[cb][c][ks], q.b[c][ks], acc[cb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            int pk[4][2];
+            int rq[4][2];                              // residual back in the accumulator layout (the store pairing is an involution)
+            if constexpr (RES) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    auto a0 = __builtin_amdgcn_permlane32_swap(rs[cb][j][0], rs[cb][j][2], false, false);
+                    auto a1 = __builtin_amdgcn_permlane32_swap(rs[cb][j][1], rs[cb][j][3], false, false);
+                    rq[2 * j][0] = (int)a0[0]; rq[2 * j + 1][0] = (int)a0[1];
+                    rq[2 * j][1] = (int)a1[0]; rq[2 * j + 1][1] = (int)a1[1];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int nl = wave * 64 + cb * 32 + 8 * g + 4 * half;                // channel inside the slice
+                asm volatile("" : "+v"(nl));           // (opaque: else the 16 constant vectors are hoisted out of the block loop -- 64 registers)
+                const f32x4 sc = *(const f32x4*)(ss + nl), sh = *(const f32x4*)(ss + 256 + nl);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[cb][4 * g + e] * sc[e] + sh[e];
+                if constexpr (RES) {
+                    const uint32_t r0 = (uint32_t)rq[g][0], r1 = (uint32_t)rq[g][1];
+                    v[0] += Fmt16<T>::lo(r0);
+                    v[1] += Fmt16<T>::hi(r0);
+                    v[2] += Fmt16<T>::lo(r1);
+                    v[3] += Fmt16<T>::hi(r1);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                pk[g][0] = Fmt16<T>::pack2(v[0], v[1]);
+                pk[g][1] = Fmt16<T>::pack2(v[2], v[3]);
+            }
+            // through the wave's LDS tile: the MFMA layout gives a lane 8 bytes of one pixel; stored from there an instruction
+            // writes 32 bytes into each of 32 lines.  Re-read row-major, a store instruction covers 8 pixels x 128 bytes: whole lines
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(i32x2*)(otile[wave] + lr * kPwRow + (cb * 32 + 8 * g + 4 * half) * 2) = i32x2{pk[g][0], pk[g][1]};
+        }
+        {
+            const int prow = lane >> 3, pslot = lane & 7;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int mm = blk * 32 + it * 8 + prow;
+                const i32x4 o = *(const i32x4*)(otile[wave] + (it * 8 + prow) * kPwRow + pslot * 16);
+                const uint32_t off = mm < p.M ? (uint32_t)((mm * p.out_pix_stride + n_base) * 2 + pslot * 16) : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
+            }
+        }
+    };
+    Blk q0, q1;
+    int blk = blane;
+    request(blk, q0);
+    for (; blk < nblk; blk += 2 * bstride) {
+        request(blk + bstride, q1);
+        finish(blk, q0);
+        if (blk + bstride >= nblk) break;
+        request(blk + 2 * bstride, q0);
+        finish(blk + bstride, q1);
+    }
+}
+
 }  // namespace
 
 namespace vd3d_conv {
@@ -965,6 +1108,38 @@ static int launch_small_f(ConvArgs& a, hipStream_t stream) {
 
 int launch_small(ConvArgs& a, hipStream_t stream, int fmt) {
     return fmt == VD3D_F16 ? launch_small_f<hf16>(a, stream) : launch_small_f<short>(a, stream);
+}
+
+
+bool pw_shape_ok(const ConvArgs& a) {
+    return (a.Cin == 64 || a.Cin == 128) && a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W &&
+           a.Cout % 256 == 0 && a.Cout / 256 <= 16 && a.wide_store && !a.out_f32 && a.wfrag && a.in_pix_stride % 8 == 0 &&
+           a.in_row_stride == a.W * a.in_pix_stride && a.in_batch_stride == (int64_t)a.H * a.in_row_stride && a.in_bytes < 0x7ffffff0u &&
+           (int64_t)a.M * a.in_pix_stride * 2 < 0x7ffffff0ll && (int64_t)a.M * a.out_pix_stride * 2 < 0x7ffffff0ll &&
+           (!a.residual || ((int64_t)a.M * a.res_pix_stride * 2 < 0x7ffffff0ll && a.res_pix_stride % 4 == 0 && ((uintptr_t)a.residual & 7) == 0));
+}
+
+template <typename T, int CIN>
+static int launch_pw_t(ConvArgs& a, hipStream_t stream) {
+    const int num_cu = vd3d_device_cu_count();
+    if (num_cu <= 0) return VD3D_ELAUNCH;
+    const int nslices = a.Cout / 256;
+    const int nblk = (a.M + 31) / 32;
+    // grid = 8 XCDs x block lanes x slices; CIN 64: <= 128 VGPRs -> 4 workgroups per CU, CIN 128: 2
+    const int per_cu = CIN == 64 ? 4 : 2;
+    int lanes = num_cu * per_cu / (8 * nslices);
+    const int need = (nblk + 7) / 8;
+    if (lanes > need) lanes = need;
+    if (lanes < 1) lanes = 1;
+    const int grid = 8 * lanes * nslices;
+    if (a.residual) hipLaunchKernelGGL((conv_pw_kernel<T, CIN, true>), dim3(grid), dim3(256), 0, stream, a, nblk, nslices);
+    else hipLaunchKernelGGL((conv_pw_kernel<T, CIN, false>), dim3(grid), dim3(256), 0, stream, a, nblk, nslices);
+    return vd3d_check_launch("conv_pw");
+}
+
+int launch_pw(ConvArgs& a, hipStream_t stream, int fmt) {
+    if (a.Cin == 64) return fmt == VD3D_F16 ? launch_pw_t<hf16, 64>(a, stream) : launch_pw_t<short, 64>(a, stream);
+    return fmt == VD3D_F16 ? launch_pw_t<hf16, 128>(a, stream) : launch_pw_t<short, 128>(a, stream);
 }
 
 
