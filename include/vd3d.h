@@ -73,7 +73,7 @@ typedef struct vd3d_conv_params {
      * 1 KiB A-operand fragment of output channels 32*nb .. +31 for k = tap*Cin + 64*kc + 16*ks .. +15: lane l holds channel
      * 32*nb + (l & 31), k = tap*Cin + 64*kc + (2*ks + (l >> 5))*8 .. +7 -- so the once-per-launch weight load of a wave is 36
      * (or 72) fully coalesced 1 KiB reads instead of 64 scattered 16-byte reads per instruction.
-     * 1x1 / stride 1 / pad 0 convolutions with Cin = 64 | 128 and Cout % 256 == 0 (point-wise streaming kernel) take the same
+     * 1x1 / stride 1 / pad 0 convolutions with Cin = 64 | 128 | 256 and Cout % 256 == 0 (point-wise streaming kernel) take the same
      * image with ONE tap: [Cout/32][Cin/64][4][64 lanes][8 elements]. */
     const void* weight_frag;
 } vd3d_conv_params;

@@ -110,6 +110,8 @@ def _shapes_for(cfg):
             (1, 10, 18, 128, 256, dict(k=1, pad=0, residual=True, in_extra=64, out_extra=64)),   # channel-slice views
             (8, 36, 160, 64, 256, dict(k=1, pad=0, residual=True)),                      # many blocks per workgroup (steady-state prefetch path)
             (4, 18, 80, 128, 1024, dict(k=1, pad=0, residual=False)),                    # four slices
+            (2, 18, 80, 256, 1024, dict(k=1, pad=0, residual=True)),                     # Cin 256 (one wave per SIMD), four slices
+            (1, 5, 9, 256, 256, dict(k=1, pad=0, residual=False, relu=False)),
         ]
     if cfg == 69:       # small-channel streaming kernel: Cin 16 | 32 | 64, Cout <= 32, stride 1 | 2, 16-bit or fp32 output, no residual
         return [

@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
 //     compiler's own vmcnt bookkeeping; 3 - 4 workgroups per CU keep > 200 KB in flight per CU.
 constexpr int kPwRow = 144;      // bytes per pixel row of the output staging tile (128 + pad: 16-byte aligned rows, 2-way bank conflicts)
 template <typename T, int CIN, bool RES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN == 64 ? 4 : 2, 8))) conv_pw_kernel(const ConvArgs p, int nblk, int nslices) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN == 64 ? 4 : (CIN == 128 ? 2 : 1), 8))) conv_pw_kernel(const ConvArgs p, int nblk, int nslices) {
     constexpr int NCH = CIN / 64;
     __shared__ __attribute__((aligned(16))) float ss[512];     // this slice's folded BN scale | shift
     __shared__ __attribute__((aligned(16))) char otile[4][32 * kPwRow];   // per wave: one block's outputs, [pixel][64 channels] (+ pad)
@@ -923,19 +923,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN ==
             for (int ks = 0; ks < 4; ++ks)
                 q.b[c][ks] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, boff, c * 128 + ks * 32, 0));
     };
-    auto finish = [&](int blk, const Blk& q) {
-        const int m = blk * 32 + lr;
-        // residual in the STORE layout (16 bytes = channels 16 j + 8 half .. + 7), requested ahead of the block's MFMAs (a whole block
-        // ahead costs 16 more live registers: spills at 3 waves per SIMD)
-        i32x4 rs[2][2];
+    // residual in the STORE layout (16 bytes = channels 16 j + 8 half .. + 7).  Requested BEFORE the next block's pixel fragments:
+    // loads return in order, so the epilogue's wait for these four leaves the sixteen younger fragment loads in flight
+    struct Res { i32x4 v[2][2]; };
+    auto request_res = [&](int blk, Res& rs) {
         if constexpr (RES) {
-            const uint32_t roff = m < p.M ? (uint32_t)((m * p.res_pix_stride + n_base + 8 * half) * 2) : kOOB;
+            const int m = blk * 32 + lr;
+            const uint32_t roff = (blk < nblk && m < p.M) ? (uint32_t)((m * p.res_pix_stride + n_base + 8 * half) * 2) : kOOB;
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    rs[cb][j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, roff, (cb * 32 + 16 * j) * 2, 0));
+                    rs.v[cb][j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, roff, (cb * 32 + 16 * j) * 2, 0));
         }
+    };
+    auto finish = [&](int blk, const Blk& q, const Res& rs) {
         f32x16 acc[2];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
@@ -954,8 +956,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN ==
             if constexpr (RES) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    auto a0 = __builtin_amdgcn_permlane32_swap(rs[cb][j][0], rs[cb][j][2], false, false);
-                    auto a1 = __builtin_amdgcn_permlane32_swap(rs[cb][j][1], rs[cb][j][3], false, false);
+                    auto a0 = __builtin_amdgcn_permlane32_swap(rs.v[cb][j][0], rs.v[cb][j][2], false, false);
+                    auto a1 = __builtin_amdgcn_permlane32_swap(rs.v[cb][j][1], rs.v[cb][j][3], false, false);
                     rq[2 * j][0] = (int)a0[0]; rq[2 * j + 1][0] = (int)a0[1];
                     rq[2 * j][1] = (int)a1[0]; rq[2 * j + 1][1] = (int)a1[1];
                 }
@@ -1000,14 +1002,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN ==
         }
     };
     Blk q0, q1;
+    Res rs;
     int blk = blane;
     request(blk, q0);
     for (; blk < nblk; blk += 2 * bstride) {
+        request_res(blk, rs);
         request(blk + bstride, q1);
-        finish(blk, q0);
+        finish(blk, q0, rs);
         if (blk + bstride >= nblk) break;
+        request_res(blk + bstride, rs);
         request(blk + 2 * bstride, q0);
-        finish(blk + bstride, q1);
+        finish(blk + bstride, q1, rs);
     }
 }
 
@@ -1112,7 +1117,7 @@ int launch_small(ConvArgs& a, hipStream_t stream, int fmt) {
 
 
 bool pw_shape_ok(const ConvArgs& a) {
-    return (a.Cin == 64 || a.Cin == 128) && a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W &&
+    return (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W &&
            a.Cout % 256 == 0 && a.Cout / 256 <= 16 && a.wide_store && !a.out_f32 && a.wfrag && a.in_pix_stride % 8 == 0 &&
            a.in_row_stride == a.W * a.in_pix_stride && a.in_batch_stride == (int64_t)a.H * a.in_row_stride && a.in_bytes < 0x7ffffff0u &&
            (int64_t)a.M * a.in_pix_stride * 2 < 0x7ffffff0ll && (int64_t)a.M * a.out_pix_stride * 2 < 0x7ffffff0ll &&
@@ -1125,8 +1130,8 @@ static int launch_pw_t(ConvArgs& a, hipStream_t stream) {
     if (num_cu <= 0) return VD3D_ELAUNCH;
     const int nslices = a.Cout / 256;
     const int nblk = (a.M + 31) / 32;
-    // grid = 8 XCDs x block lanes x slices; CIN 64: <= 128 VGPRs -> 4 workgroups per CU, CIN 128: 2
-    const int per_cu = CIN == 64 ? 4 : 2;
+    // grid = 8 XCDs x block lanes x slices; CIN 64: <= 128 VGPRs -> 4 workgroups per CU, CIN 128: 2, CIN 256: 1 (128 weight + 2 x 64 pixel registers)
+    const int per_cu = CIN == 64 ? 4 : (CIN == 128 ? 2 : 1);
     int lanes = num_cu * per_cu / (8 * nslices);
     const int need = (nblk + 7) / 8;
     if (lanes > need) lanes = need;
@@ -1139,7 +1144,8 @@ static int launch_pw_t(ConvArgs& a, hipStream_t stream) {
 
 int launch_pw(ConvArgs& a, hipStream_t stream, int fmt) {
     if (a.Cin == 64) return fmt == VD3D_F16 ? launch_pw_t<hf16, 64>(a, stream) : launch_pw_t<short, 64>(a, stream);
-    return fmt == VD3D_F16 ? launch_pw_t<hf16, 128>(a, stream) : launch_pw_t<short, 128>(a, stream);
+    if (a.Cin == 128) return fmt == VD3D_F16 ? launch_pw_t<hf16, 128>(a, stream) : launch_pw_t<short, 128>(a, stream);
+    return fmt == VD3D_F16 ? launch_pw_t<hf16, 256>(a, stream) : launch_pw_t<short, 256>(a, stream);
 }
 
 

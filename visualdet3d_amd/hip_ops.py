@@ -110,7 +110,7 @@ def pack_conv(weight, bias=None, bn=None, dtype=torch.bfloat16, stride=1, pad=0,
         # [O/32][Cin/64][tap*4 + ks][half*32 + lr][8]  <-  w[32*nb + lr][tap][64*kc + (2*ks + half)*8 + e]
         w7 = w.reshape(O // 32, 32, 9, Cin // 64, 4, 2, 8)                 # nb, lr, tap, kc, ks, half, e
         pc.w_frag = w7.permute(0, 3, 2, 4, 5, 1, 6).contiguous().to(dtype)
-    elif is16(dtype) and (kh, kw, stride, pad) == (1, 1, 1, 0) and Cin in (64, 128) and O % 256 == 0:
+    elif is16(dtype) and (kh, kw, stride, pad) == (1, 1, 1, 0) and Cin in (64, 128, 256) and O % 256 == 0:
         # the same register image with one tap, for the point-wise streaming kernel: [O/32][Cin/64][ks][half*32 + lr][8]
         w7 = w.reshape(O // 32, 32, 1, Cin // 64, 4, 2, 8)
         pc.w_frag = w7.permute(0, 3, 2, 4, 5, 1, 6).contiguous().to(dtype)
