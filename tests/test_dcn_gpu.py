@@ -192,3 +192,33 @@ def test_pack_module_nhwc_columns_route_for_many_output_channels(dtype, tol):
     a = got.float().cpu().permute(0, 3, 1, 2)
     assert ((a - want).abs().max() / want.abs().max()).item() < tol
     assert ((got.float() - fused_out.float()).abs().max() / fused_out.float().abs().max()).item() < (1e-5 if dtype == torch.float32 else 2.0 ** -7)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+def test_deform_columns_wave_kernel_matches_thread_per_vector_kernel(dtype):
+    """vd3d_deform_columns has two kernels: wave-per-sample (inputs < 2 GiB; geometry once per (pixel, tap)) and the generic
+    thread-per-vector one (VD3D_DCN_COLUMNS_GENERIC=1 forces it).  Same sampling arithmetic: fp32 equal to round-off, the 16-bit
+    formats equal except where the folded modulation (sum (w m) x vs (sum w x) m) flips a rounding tie (<= 1 ulp, rare).
+    Odd sizes: C = 72 channels (ragged last channel sweep), 7 x 9 pixels x 9 taps = 567 samples (ragged last wave)."""
+    import os
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W, C = 2, 7, 9, 72
+    x = torch.randn(B, H, W, C, generator=g).cuda().to(dtype)
+    logits = (torch.randn(B, H, W, 32, generator=g) * 2.0).cuda()
+    logits[0, 0, 0, :18] = 40.0                       # samples far outside the image -> zero columns
+    cols = ops.deform_columns(x, logits[..., :18], logits[..., 18:27], (3, 3), (1, 1), (1, 1), (1, 1), mask_sigmoid=True)
+    os.environ['VD3D_DCN_COLUMNS_GENERIC'] = '1'
+    try:
+        ref = ops.deform_columns(x, logits[..., :18], logits[..., 18:27], (3, 3), (1, 1), (1, 1), (1, 1), mask_sigmoid=True)
+    finally:
+        del os.environ['VD3D_DCN_COLUMNS_GENERIC']
+    torch.cuda.synchronize()
+    assert cols.shape == ref.shape and bool((cols[0, 0, 0] == 0).all())
+    d = (cols.float() - ref.float()).abs()
+    if dtype == torch.float32:
+        assert (d.max() / ref.float().abs().max()).item() < 1e-6
+    else:
+        ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+        assert bool((d <= ref.float().abs() * ulp + 1e-6).all())
+        assert (d > 0).float().mean().item() < 0.02

@@ -551,6 +551,114 @@ __global__ void __launch_bounds__(256) dcn_columns_kernel(const DcnArgs p, T* __
     }
 }
 
+// Wave-per-sample variant of the columns kernel (inputs below 2 GiB: 32-bit offsets): a lane computes the geometry of ONE (pixel,
+// tap) sample, then the wave walks its 64 samples: the sample's four corner offsets and weights are broadcast (v_readlane) and
+// the 64 lanes sweep the channel run -- four 1 KiB corner loads, the fp32 blend, one 1 KiB store per 512 | 256 channels.
+// The thread-per-vector kernel above recomputes the geometry (three strided logit loads, sigmoid, floor, 64-bit index
+// divisions) for every 8 channels: at C = 2176 that is 272 times per sample, twice the blend work itself.
+template <typename T>
+__global__ void __launch_bounds__(256) dcn_columns_wave_kernel(const DcnArgs p, T* __restrict__ cols, uint32_t in_bytes) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VE = 16 / ES;
+    constexpr bool FOLD = ES == 2;                   // (16-bit formats: modulation folded into the weights, as in dcn_nhwc_kernel)
+    constexpr uint32_t kDcnOOB = 0x80000000u;
+    const int KK = p.kh * p.kw;
+    const int lane = threadIdx.x & 63;
+    const int64_t nsamp = (int64_t)p.B * p.Ho * p.Wo * KK;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (int64_t)gridDim.x * 4;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, in_bytes, 0x00020000);
+    const int cbytes = p.C * ES;
+    // work item = (64 samples, one 1 KiB channel step): the wave keeps ONE channel step and walks its samples, so the corner runs
+    // of neighbouring taps / pixels (the same few input lines) are re-read while they are still in L1 -- sweeping all channels
+    // of a sample before the next sample streams 17 KB per sample through a 32 KB L1 and re-fetches the input 36 times from
+    // beyond L2 (measured: 6 TB/s of reads, 1.19 ms at 32 x 18 x 80 x 2176)
+    const int nsteps = (cbytes + 1023) / 1024;
+    const int64_t nitems = ((nsamp + 63) / 64) * nsteps;
+    for (int64_t item = wave0; item < nitems; item += nwave) {
+        const int64_t base = (item / nsteps) * 64;
+        const int cb = (int)(item % nsteps) * 1024 + lane * 16;
+        uint32_t go[4] = {kDcnOOB, kDcnOOB, kDcnOOB, kDcnOOB};
+        float gw[4] = {0.f, 0.f, 0.f, 0.f};
+        float m = 0.f;
+        const int64_t sidx = base + lane;
+        if (sidx < nsamp) {
+            const int tap = (int)(sidx % KK);
+            const int64_t r = sidx / KK;
+            const int ox = (int)(r % p.Wo), oy = (int)((r / p.Wo) % p.Ho), b = (int)(r / ((int64_t)p.Wo * p.Ho));
+            const int ti = tap / p.kw, tj = tap - ti * p.kw;
+            const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
+            const float off_h = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
+            const float off_w = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+            const float h_im = (float)(oy * p.sh - p.ph + ti * p.dh) + off_h;
+            const float w_im = (float)(ox * p.sw - p.pw + tj * p.dw) + off_w;
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                m = 1.f;
+                if (p.mask) {
+                    m = p.mask[b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx + (int64_t)tap * p.msk_sc];
+                    if (p.mask_sigmoid) m = FOLD ? __frcp_rn(1.0f + __expf(-m)) : 1.0f / (1.0f + expf(-m));
+                }
+                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool t_ok = h_low >= 0, b_ok = h_high <= p.H - 1, l_ok = w_low >= 0, r_ok = w_high <= p.W - 1;
+                const int64_t ib = (int64_t)b * p.in_sb;
+                if (t_ok && l_ok) { gw[0] = hh * hw; go[0] = (uint32_t)((ib + h_low * p.in_sy + w_low * p.in_sx) * ES); }
+                if (t_ok && r_ok) { gw[1] = hh * lw; go[1] = (uint32_t)((ib + h_low * p.in_sy + w_high * p.in_sx) * ES); }
+                if (b_ok && l_ok) { gw[2] = lh * hw; go[2] = (uint32_t)((ib + h_high * p.in_sy + w_low * p.in_sx) * ES); }
+                if (b_ok && r_ok) { gw[3] = lh * lw; go[3] = (uint32_t)((ib + h_high * p.in_sy + w_high * p.in_sx) * ES); }
+            }
+        }
+        if constexpr (FOLD) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gw[c] *= m;
+        }
+        const int nj = nsamp - base < 64 ? (int)(nsamp - base) : 64;
+#pragma unroll 4
+        for (int j = 0; j < nj; ++j) {
+            uint32_t o[4];
+            float w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                o[c] = (uint32_t)__builtin_amdgcn_readlane((int)go[c], j);
+                w[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gw[c]), j));
+            }
+            const float mj = FOLD ? 1.f : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, m), j));
+            char* dst = (char*)cols + (base + j) * cbytes;
+            {
+                i32x4 cv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cv[c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, cb < cbytes ? o[c] + cb : kDcnOOB, 0, 0));
+                float vals[VE];
+                if constexpr (std::is_same<T, hf16>::value) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        vals[2 * d] = mix_fma_lo(cv[3][d], w[3], mix_fma_lo(cv[2][d], w[2], mix_fma_lo(cv[1][d], w[1], mix_mul_lo(cv[0][d], w[0]))));
+                        vals[2 * d + 1] = mix_fma_hi(cv[3][d], w[3], mix_fma_hi(cv[2][d], w[2], mix_fma_hi(cv[1][d], w[1], mix_mul_hi(cv[0][d], w[0]))));
+                    }
+                } else {
+                    Vec16<T> c1, c2, c3, c4;
+                    c1.raw = cv[0]; c2.raw = cv[1]; c3.raw = cv[2]; c4.raw = cv[3];
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        if constexpr (sizeof(T) == 2) vals[e] = fmaf(w[3], c4.get(e), fmaf(w[2], c3.get(e), fmaf(w[1], c2.get(e), w[0] * c1.get(e))));
+                        else vals[e] = (w[0] * c1.get(e) + w[1] * c2.get(e) + w[2] * c3.get(e) + w[3] * c4.get(e)) * mj;
+                    }
+                }
+                Vec16<T> ov;
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov.set2(e, vals[2 * e], vals[2 * e + 1]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov.set(e, vals[e]);
+                }
+                if (cb < cbytes) *(i32x4*)(dst + cb) = ov.raw;
+            }
+        }
+    }
+}
+
 template <typename T, int BN>
 int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
     const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * kDcnGeoBytes<T>;   // two stages + the geometry table
@@ -628,6 +736,20 @@ int launch_dcn_columns(const vd3d_dcn_params* q, void* columns, hipStream_t s) {
     a.out_sb = a.out_sc = a.out_sy = a.out_sx = 0;
     a.mask_sigmoid = q->mask_sigmoid; a.relu = 0;
     if (a.Ho <= 0 || a.Wo <= 0 || q->B <= 0) { vd3d_set_error("deform_columns: empty output"); return VD3D_EINVAL; }
+    const int64_t in_span = ((int64_t)(q->B - 1) * a.in_sb + (int64_t)(q->H - 1) * a.in_sy + (int64_t)(q->W - 1) * a.in_sx + q->C) * es;
+    if (in_span < 0x7ffffff0ll && !getenv("VD3D_DCN_COLUMNS_GENERIC")) {
+        // wave-per-sample kernel: geometry once per (pixel, tap) instead of once per 16-byte vector
+        const int64_t nsamp = (int64_t)q->B * a.Ho * a.Wo * q->kh * q->kw;
+        const int64_t nitems = ((nsamp + 63) / 64) * (((int64_t)q->C * es + 1023) / 1024);   // (64 samples, 1 KiB channel step) per wave
+        const int64_t want = (nitems + 3) / 4;
+        const int cus = vd3d_device_cu_count();
+        const int gridw = (int)(want < (int64_t)cus * 8 ? want : (int64_t)cus * 8);
+        if (gridw <= 0) return VD3D_ELAUNCH;
+        if (q->dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_columns_wave_kernel<short>, dim3(gridw), dim3(256), 0, s, a, (short*)columns, (uint32_t)in_span);
+        else if (q->dtype == VD3D_F16) hipLaunchKernelGGL(dcn_columns_wave_kernel<hf16>, dim3(gridw), dim3(256), 0, s, a, (hf16*)columns, (uint32_t)in_span);
+        else hipLaunchKernelGGL(dcn_columns_wave_kernel<float>, dim3(gridw), dim3(256), 0, s, a, (float*)columns, (uint32_t)in_span);
+        return vd3d_check_launch("deform_columns");
+    }
     const int64_t total = (int64_t)q->B * a.Ho * a.Wo * q->kh * q->kw * (q->C / ve);
     const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     if (q->dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_columns_kernel<short>, dim3(grid), dim3(256), 0, s, a, (short*)columns);
