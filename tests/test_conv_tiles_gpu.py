@@ -219,3 +219,35 @@ def test_bench_shapes_natural_dispatch_bf16_vs_oracle(case):
     torch.set_num_threads(min(64, torch.get_num_threads()))
     ulp, rel = run_case(B, H, W, Cin, Cout, dtype=torch.bfloat16, seed=7, cfg=0, **kw)
     assert ulp <= 1.0, '%s: %.2f bf16 ulp (rel %.2e)' % (name, ulp, rel)
+
+
+@pytest.mark.parametrize('cfg', [44, 42, 30])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_whole_line_epilogue_of_the_tile_kernels(cfg, dtype):
+    """conv_epilogue_lines: short-K layers with Cout % 64 == 0 re-lay their 16-bit outputs through LDS so that store
+    instructions cover whole 128-byte lines (ConvArgs::line_store).  Against the oracle, and bit-identical to the accumulator-layout
+    stores it replaces (VD3D_NO_LINE_STORE=1): same arithmetic, only the store shape differs."""
+    import os
+    cases = [
+        (2, 9, 31, 256, 128, dict(k=1, pad=0, residual=True)),                    # ragged M (558 pixels), two 64-channel strips
+        (1, 13, 27, 64, 192, dict(residual=True, out_extra=64)),                  # 3x3, channel-slice view (pixel stride 256)
+        (3, 16, 32, 128, 64, dict(k=1, pad=0, residual=False, relu=False)),       # one strip: the other waves of the N tile idle
+        (1, 7, 45, 512, 256, dict(k=1, pad=0, stride=2, residual=False)),         # strided 1x1 (down-sample branch)
+    ]
+    for i, (B, H, W, Cin, Cout, kw) in enumerate(cases):
+        ulp, rel = run_case(B, H, W, Cin, Cout, dtype=dtype, seed=400 + i, cfg=cfg, **kw)
+        assert ulp <= 1.0, 'tile %d shape %s: %.2f ulp (rel %.2e)' % (cfg, (B, H, W, Cin, Cout, kw), ulp, rel)
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 9, 31, 256, generator=g).cuda().to(dtype)
+    w = (torch.randn(128, 256, 1, 1, generator=g) * 0.1).cuda()
+    res = torch.randn(2, 9, 31, 128, generator=g).cuda().to(dtype)
+    pc = ops.pack_conv(w, None, None, dtype, 1, 0, 1)
+    with forced_tile(cfg):
+        a = ops.conv2d(x, pc, residual=res, relu=True)
+        os.environ['VD3D_NO_LINE_STORE'] = '1'
+        try:
+            b = ops.conv2d(x, pc, residual=res, relu=True)
+        finally:
+            del os.environ['VD3D_NO_LINE_STORE']
+    assert torch.equal(a, b)

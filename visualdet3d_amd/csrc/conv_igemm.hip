@@ -377,6 +377,65 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
     conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
 }
 
+// ---- whole-line epilogue (16-bit output, 64 channels per wave) --------------------------------------------------------
+// In the accumulator layout a store instruction writes 32 bytes into each of 32 different 128-byte lines; a stream of such
+// partial-line writes tops out near 2 TB/s (the point-wise expansion kernel: 2.65 -> 4.7 TB/s once its stores covered whole
+// lines).  Here a wave parks each 32-pixel x 64-channel block of its tile in LDS ([pixel][128 B + pad], the operand stages are
+// free by now) and re-reads it row-major: one store instruction = 8 pixels x 128 contiguous bytes.  Residual reads stay in
+// the accumulator layout.  Selected by the host for the layers whose output stream matters (ConvArgs::line_store).
+constexpr int kLineRow = 144;                  // bytes per pixel row of the parking tile (16-byte aligned, 2-way bank conflicts at most)
+template <typename T, int TM>
+VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const int (&mrow)[TM], int mblock0, int nw, int half, int lr, int lane,
+                                  char* tile) {
+    const int prow = lane >> 3, pslot = lane & 7;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = mrow[j];
+        const bool mvalid = m >= 0;
+        const int64_t rbase = (int64_t)(mvalid ? m : 0) * p.res_pix_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nb = nw + i * 32 + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                if (p.scale) {
+                    const f32x4 sc = *(const f32x4*)(p.scale + nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= sc[e];
+                }
+                if (p.shift) {
+                    const f32x4 sh = *(const f32x4*)(p.shift + nb);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += sh[e];
+                }
+                if (p.residual && mvalid) {
+                    const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
+                    const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
+                    v[0] += Fmt16<T>::lo(r0);
+                    v[1] += Fmt16<T>::hi(r0);
+                    v[2] += Fmt16<T>::lo(r1);
+                    v[3] += Fmt16<T>::hi(r1);
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *(i32x2*)(tile + lr * kLineRow + (i * 32 + 8 * g + 4 * half) * 2) = i32x2{Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3])};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = it * 8 + prow;
+            const i32x4 o = *(const i32x4*)(tile + r * kLineRow + pslot * 16);
+            const int mm = mblock0 + j * 32 + r;
+            if (mm < p.M) *(i32x4*)(p.out + ((int64_t)mm * p.out_pix_stride + nw) * 2 + pslot * 16) = o;
+        }
+    }
+}
+
 // =====================================================================================================
 // v2: same tile math, but both operand tiles go global -> LDS by DMA (buffer_load_dwordx4 ... lds): no VGPR
 // staging, no ds_write pass.  An LDS-DMA instruction writes wave-uniform-base + lane*16, i.e. the LDS image is
@@ -703,6 +762,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                 }
         }
         return;
+    }
+    if constexpr (MS == 32 && WTN == 64 && sizeof(T) == 2) {
+        if (p.line_store) {          // (host: 16-bit output, Cout % 64 == 0, aligned rows -- every wave's 64-channel strip is whole)
+            __syncthreads();         // every wave is done with the operand stages
+            if (n0 + wn * WTN < p.Cout)
+                conv_epilogue_lines<T, TM>(p, acc, mrow, m0 + wm * WTM, n0 + wn * WTN, half, lr, lane, smem + wave * (32 * kLineRow));
+            return;
+        }
     }
     if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
     else conv_epilogue16<T, TM, TN, WTN>(p, acc, mrow, n0, wn, half);
@@ -1189,6 +1256,10 @@ static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     // 16-byte bf16 stores (half-wave pairing) need 16-channel groups inside Cout and 16-byte aligned rows
     a.wide_store = a.vec_epilogue && oes == 2 && (p->Cout % 16 == 0) && (p->out_pix_stride % 8 == 0) && (((uintptr_t)p->out & 15) == 0);
     a.chunk_major = (a.ntaps > 1) && (p->Cin % bke == 0);
+    // whole-line stores through LDS (conv_epilogue_lines): worth it where the output stream is a large share of the layer's bytes,
+    // i.e. short K (1x1 convolutions and small-Cin 3x3): K <= 1152
+    a.line_store = a.wide_store && !p->out_f32 && p->Cout % 64 == 0 && (p->out_pix_stride % 64 == 0) && (((uintptr_t)p->out & 127) == 0) &&
+                   (int64_t)p->kh * p->kw * p->Cin <= 1152 && !getenv("VD3D_NO_LINE_STORE");
     return VD3D_OK;
 }
 
