@@ -349,7 +349,7 @@ def main():
                                    % (args.height, args.width, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
                        'side_streams': not args.no_overlap, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world)},
-            'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw / conv_ksplit256 / conv_small (all %d launches per step)' % nl,
+            'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw / conv_ksplit256 / conv_small / conv_pw (all %d launches per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                          'traffic': traffic, 'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
                          'algorithmic_bytes': alg_bytes,

@@ -7,7 +7,7 @@ import os
 import sqlite3
 import sys
 
-CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small')
+CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small', 'conv_pw')
 
 
 def per_kernel(path, counter):

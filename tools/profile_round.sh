@@ -6,12 +6,15 @@
 #     <tag>_serial_timeline.txt, <tag>_serial_bench.json  (sum of the conv kernels == roofline.achieved of that line)
 #  3. PMC passes, each in its own run: FETCH_SIZE, WRITE_SIZE (HBM traffic of the conv launches) -> <tag>_pmc_traffic.json
 #  4. PMC pass: SQ counters of the conv families (MFMA busy, waits, LDS conflicts)         -> <tag>_sq_pmc.txt
+#  5. kernel traces + per-launch conv tables of BASELINE configs 3 and 5 as stated (tools/bench_configs.py, tools/layer_table.py)
+#     -> <tag>_c3_kernel_stats.csv, <tag>_c3_conv_layers.txt, <tag>_c5_km3d_kernel_stats.csv, <tag>_c5_km3d_conv_layers.txt
 set -u
 TAG=${1:-r02}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+export PYTHONPATH=$ROOT
 cd /tmp
 run() {  # name, rocprof args..., -- bench args
     local name=$1; shift
@@ -24,6 +27,8 @@ run trace_serial --kernel-trace --stats -d $OUT/trace_serial -- python $ROOT/ben
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline
 run pmc_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline
 run pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-overlap --no-cpu-baseline
+run trace_c3 --kernel-trace --stats -d $OUT/trace_c3 -- python $ROOT/tools/bench_configs.py "C3 Stereo3D R50 +"
+run trace_c5 --kernel-trace --stats -d $OUT/trace_c5 -- python $ROOT/tools/bench_configs.py "fp16 (as BASELINE"
 cd $ROOT
 db() { find $OUT/$1 -name "*.db" | sort | tail -1; }
 python tools/rocpd_stats.py $(db trace_overlap) > $OUT/${TAG}_kernel_stats.csv
@@ -35,6 +40,12 @@ python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffi
 python tools/rocpd_pmc_table.py $OUT/pmc_sq conv_ > $OUT/${TAG}_sq_pmc.txt
 python tools/serial_roofline_check.py $OUT/${TAG}_serial_kernel_stats.csv $OUT/${TAG}_serial_bench.json > $OUT/${TAG}_serial_roofline_check.txt
 cat $OUT/${TAG}_serial_roofline_check.txt
+python tools/rocpd_stats.py $(db trace_c3) > $OUT/${TAG}_c3_kernel_stats.csv
+python tools/rocpd_stats.py $(db trace_c5) > $OUT/${TAG}_c5_km3d_kernel_stats.csv
+grep 'img/s' $OUT/trace_c3.log $OUT/trace_c5.log > $OUT/${TAG}_c3_c5_under_rocprof.txt
+python tools/layer_table.py "C3 Stereo3D R50 +" 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_c3_conv_layers.txt
+python tools/layer_table.py "fp16 (as BASELINE" 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_c5_km3d_conv_layers.txt
+python tools/bench_configs.py 2>/dev/null | grep 'img/s' > $OUT/${TAG}_bench_configs.txt
 # the rocpd databases stay on the box (too big); only the summaries travel back
-rm -rf $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+rm -rf $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5
 ls -la $OUT
