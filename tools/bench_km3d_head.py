@@ -1,6 +1,5 @@
-"""Fused KM3D head in isolation (16 x 128 x 440 x 64 features, nine branches): resident-weight kernel vs the 256x256-tile GEMM
-(VD3D_HEAD_TILES=1).   python tools/bench_km3d_head.py [fp16|bf16]"""
-import os
+"""Fused KM3D head (vd3d_km3d_head_fused) in isolation: 16 x 128 x 440 x 64 features, nine branches.
+    python tools/bench_km3d_head.py [fp16|bf16]"""
 import sys
 
 import torch
@@ -14,9 +13,7 @@ cfg = syn.km3d_cfg(output_w=440)
 head = KM3DHead(**cfg.head).cuda().eval()
 x = torch.randn(16, 128, 440, 64, device='cuda').to(dt)
 fl = 2.0 * 16 * 128 * 440 * (2304 * 576 + 9 * 256 * 32)
-for name, env in (('resident weights', None), ('256x256 tiles', '1')):
-    if env:
-        os.environ['VD3D_HEAD_TILES'] = env
+for name in ('fused head',):
     with torch.no_grad():
         head.forward_nhwc(x)
         torch.cuda.synchronize()
