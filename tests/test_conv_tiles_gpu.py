@@ -251,3 +251,27 @@ def test_whole_line_epilogue_of_the_tile_kernels(cfg, dtype):
         finally:
             del os.environ['VD3D_NO_LINE_STORE']
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('cfg', [79, 42, 44])
+def test_grouped_tile_order_of_huge_1x1_gemms(cfg):
+    """ConvArgs::group_m (1x1 GEMMs whose pixel matrix exceeds the on-die caches: the DCN column GEMM of BASELINE config 3) only
+    permutes which workgroup computes which tile: forced on small shapes (VD3D_FORCE_GROUP_M=1), results must equal the plain order
+    bit for bit -- tile counts that are and are not multiples of the group (4 pixel tiles), one and several N tiles."""
+    import os
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(21)
+    for (B, H, W, Cin, Cout) in [(2, 18, 40, 192, 544), (1, 23, 31, 128, 272), (3, 16, 32, 64, 1088)]:
+        x = torch.randn(B, H, W, Cin, generator=g).cuda().to(torch.bfloat16)
+        w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1).cuda()
+        pc = ops.pack_conv(w, None, None, torch.bfloat16, 1, 0, 1)
+        with forced_tile(cfg):
+            a = ops.conv2d(x, pc, relu=True)
+            os.environ['VD3D_FORCE_GROUP_M'] = '1'
+            try:
+                b = ops.conv2d(x, pc, relu=True)
+            finally:
+                del os.environ['VD3D_FORCE_GROUP_M']
+        assert torch.equal(a, b), (cfg, B, H, W, Cin, Cout)
+    ulp, rel = run_case(2, 18, 40, 192, 544, k=1, pad=0, residual=True, dtype=torch.bfloat16, seed=77, cfg=cfg)
+    assert ulp <= 1.0

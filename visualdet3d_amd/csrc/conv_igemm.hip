@@ -467,7 +467,16 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
+    if (p.group_m > 0) {
+        // pixel matrix far larger than L2 + Infinity Cache (the 1.8 GB DCN column matrix of BASELINE config 3): N-major order makes
+        // every N tile re-stream it from HBM (8 x 1.8 GB).  Grouped order: group_m pixel tiles x ALL N tiles run back to back on
+        // one XCD, so a pixel slice is fetched once per group and a weight slice once per group_m pixel tiles.
+        const int per = p.group_m * p.tiles_n, g = tile / per, rr = tile - g * per;
+        const int gm = p.tiles_m - g * p.group_m < p.group_m ? p.tiles_m - g * p.group_m : p.group_m;      // (last group may be short)
+        tile_n = rr / gm;
+        tile_m = g * p.group_m + rr - tile_n * gm;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = threadIdx.x;
@@ -1256,6 +1265,8 @@ static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     // 16-byte bf16 stores (half-wave pairing) need 16-channel groups inside Cout and 16-byte aligned rows
     a.wide_store = a.vec_epilogue && oes == 2 && (p->Cout % 16 == 0) && (p->out_pix_stride % 8 == 0) && (((uintptr_t)p->out & 15) == 0);
     a.chunk_major = (a.ntaps > 1) && (p->Cin % bke == 0);
+    // grouped tile order for 1x1 GEMMs whose pixel matrix exceeds the on-die caches (> 512 MB)
+    a.group_m = (a.ntaps == 1 && ((int64_t)a.M * p->Cin * es > (512ll << 20) || getenv("VD3D_FORCE_GROUP_M")) && !getenv("VD3D_NO_GROUP_M")) ? 4 : 0;
     // whole-line stores through LDS (conv_epilogue_lines): worth it where the output stream is a large share of the layer's bytes,
     // i.e. short K (1x1 convolutions and small-Cin 3x3): K <= 1152
     a.line_store = a.wide_store && !p->out_f32 && p->Cout % 64 == 0 && (p->out_pix_stride % 64 == 0) && (((uintptr_t)p->out & 127) == 0) &&
