@@ -47,6 +47,6 @@ for name, B, H, W, Cin, Cout, res in SHAPES:
         e.record()
         torch.cuda.synchronize()
         t = s.elapsed_time(e) * 1e-4
-        line += '  cfg%-2d %6.1f us %4.2f TB/s' % (c, t * 1e3 * 1e3 / 1e3, by / t / 1e9 / 1e3)
+        line += '  cfg%-2d %6.1f us %4.2f TB/s' % (c, t * 1e6, by / t / 1e12)
     _lib.lib().vd3d_conv2d_set_tuning(0)
     print(line, flush=True)
