@@ -883,7 +883,7 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
 //     compiler's own vmcnt bookkeeping; 3 - 4 workgroups per CU keep > 200 KB in flight per CU.
 constexpr int kPwRow = 144;      // bytes per pixel row of the output staging tile (128 + pad: 16-byte aligned rows, 2-way bank conflicts)
 template <typename T, int CIN, bool RES>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN == 64 ? 4 : (CIN == 128 ? 2 : 1), 8))) conv_pw_kernel(const ConvArgs p, int nblk, int nslices) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN == 64 ? 3 : (CIN == 128 ? 2 : 1), 8))) conv_pw_kernel(const ConvArgs p, int nblk, int nslices) {
     constexpr int NCH = CIN / 64;
     __shared__ __attribute__((aligned(16))) float ss[512];     // this slice's folded BN scale | shift
     __shared__ __attribute__((aligned(16))) char otile[4][32 * kPwRow];   // per wave: one block's outputs, [pixel][64 channels] (+ pad)
@@ -1130,8 +1130,8 @@ static int launch_pw_t(ConvArgs& a, hipStream_t stream) {
     if (num_cu <= 0) return VD3D_ELAUNCH;
     const int nslices = a.Cout / 256;
     const int nblk = (a.M + 31) / 32;
-    // grid = 8 XCDs x block lanes x slices; CIN 64: <= 128 VGPRs -> 4 workgroups per CU, CIN 128: 2, CIN 256: 1 (128 weight + 2 x 64 pixel registers)
-    const int per_cu = CIN == 64 ? 4 : (CIN == 128 ? 2 : 1);
+    // grid = 8 XCDs x block lanes x slices; CIN 64: <= 168 VGPRs (no spills) -> 3 workgroups per CU (4 at 128 VGPRs spill 13 and run the same 4.76 TB/s), CIN 128: 2, CIN 256: 1 (128 weight + 2 x 64 pixel registers)
+    const int per_cu = CIN == 64 ? 3 : (CIN == 128 ? 2 : 1);
     int lanes = num_cu * per_cu / (8 * nslices);
     const int need = (nblk + 7) / 8;
     if (lanes > need) lanes = need;
