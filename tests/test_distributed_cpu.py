@@ -74,3 +74,70 @@ def test_shard_range_covers_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+# ---- detector output through the gather (world 2): each rank runs the CPU oracle of the detector on ITS shard of the frames ------
+def _oracle_detections(lo, hi):
+    """(scores [n,K], boxes [n,K,11], labels [n,K], count [n]) padded like ``get_bboxes_batched`` returns them, from the oracle's
+    Stereo3D forward on the frames [lo, hi) of the 96x320 golden case (weights / inputs are seeded: every rank builds the same)."""
+    from oracle import detector_oracle as orc
+    from tests.common import load_golden, stereo_case_from_golden
+    from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3D
+    from visualdet3d_amd.utils import synthetic as syn
+    g = load_golden('stereo3d_r34_96x320')
+    cfg, (L, R, P2, P3), winit = stereo_case_from_golden(g)
+    sd = syn.seeded_state_dict(Stereo3D(cfg).state_dict(), **winit)
+    with torch.no_grad():
+        outs = orc.stereo3d_forward(sd, cfg, L[lo:hi], R[lo:hi], P2[lo:hi])
+    K = 128
+    n = hi - lo
+    scores, boxes = torch.zeros(n, K), torch.zeros(n, K, 11)
+    labels, count = torch.zeros(n, K, dtype=torch.int32), torch.zeros(n, dtype=torch.int32)
+    for f, (s_, b_, l_, _) in enumerate(outs):
+        k = len(s_)
+        assert k <= K
+        scores[f, :k], boxes[f, :k], labels[f, :k], count[f] = s_, b_, l_.reshape(-1).int(), k
+    return scores, boxes, labels, count, L.shape[0]
+
+
+def _detector_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from tests.common import load_golden
+    n_frames = int(load_golden('stereo3d_r34_96x320')['meta'][3])
+    lo, hi = vdist.shard_range(n_frames, rank, world)
+    scores, boxes, labels, count, _ = _oracle_detections(lo, hi)
+    gather = vdist.DetectionGather(hi - lo, 128, 'cpu')
+    gather(scores, boxes, labels, count)
+    pack, cnt = gather.detections()
+    if rank == 0:
+        q.put((pack.clone(), cnt.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_detector_output_through_the_gather_world2():
+    """What bench.py does per step with N ranks, on real detector output: every rank runs the detector (here its CPU oracle) on its
+    shard of the golden case's frames, DetectionGather moves the padded results to every rank in one collective, and rank 0's
+    unpacked detections equal the reference's golden detections frame by frame."""
+    from tests.common import assert_detections_close, load_golden
+    g = load_golden('stereo3d_r34_96x320')
+    n_frames = int(g['meta'][3])
+    assert n_frames % 2 == 0
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_detector_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    pack, cnt = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    dets = vdist.unpack_detections(pack, cnt)
+    assert len(dets) == n_frames and sum(int(c) for c in cnt) > 0
+    for f, (s_, b_, l_) in enumerate(dets):
+        assert_detections_close((s_, b_, l_), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=1e-4,
+                                what='gathered frame %d' % f)
