@@ -153,13 +153,20 @@ def test_bf16_mode_close_to_bf16_oracle():
     g = load_golden('km3d_dla34_96x320')
     cfg, (img, P2), winit = km3d_case_from_golden(g)
     m, sd = _model(cfg, winit, torch.bfloat16)
-    m.test_forward_batched(img.cuda(), P2.cuda())
+    outs = m.test_forward_batched(img.cuda(), P2.cuda())
     maps = m._last_raw
     with torch.no_grad():
-        _, st = orc.km3d_forward(sd, cfg, img, P2, rnd=orc.bf16_round, return_stages=True)
+        dets, st = orc.km3d_forward(sd, cfg, img, P2, rnd=orc.bf16_round, return_stages=True)
     for h in ('hm', 'hps', 'dim', 'rot'):
         # 16 stacked DCNv2 layers: a 1-ulp bf16 flip upstream moves sampling positions downstream -> looser than the ResNet paths
         assert rel_err(maps[h].permute(0, 3, 1, 2).cpu(), st[h]) < 0.15, h
+    # detection level: the decoded boxes (one-to-one matching, score + every box field within 5 % of the field's scale)
+    fr = []
+    for f in range(img.shape[0]):
+        s, b, l = [t.cpu() for t in outs[f]]
+        assert abs(len(s) - len(dets[f][0])) <= 10
+        fr.append(matched_fraction((s, b, l), dets[f], rtol=5e-2))
+    assert min(fr) >= 0.8, fr
 
 
 def test_fused_head_matches_unfused():
