@@ -1161,9 +1161,13 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         const double r = 1390.0 * util(128, 192, 512);
         if (r > best) { best = r; pick = 6; }
     }
-    if (a.Cout % 288 == 0) {
+    if (a.Cout % 288 == 0 || (sizeof(T) == 2 && a.Cout > 1152)) {
+        // (a partial last strip is fine: 2176 = 7.56 x 288 runs 1298 TF/s on the 288 strips against 1246 on 8 x 272 -- the 4 x 2-wave
+        //  16x16x32 layout reads fewer fragment bytes per MFMA than the 8 x 1 layout of the 272 strip)
         const double r = 1455.0 * util(256, 288, 256);
         if (r > best) { best = r; pick = 3; }
+    }
+    if (a.Cout % 288 == 0) {
         // bf16: 8 waves of 32 x 144 on 16x16x32 MFMAs: 1109 vs 929 TF/s (128x192 tiles) on the 1408 -> 576 reg output conv
         // (only with >= 2 strips per pixel tile: on the 288 -> 288 neck convs the 120 tiles leave half the chip idle, 69 vs 55 us)
         const double r2 = (sizeof(T) == 2 && a.Cout >= 576 ? 1200.0 : 850.0) * util(128, 288, 256);
