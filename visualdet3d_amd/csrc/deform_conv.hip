@@ -244,7 +244,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     constexpr uint32_t kDcnOOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* geo_tab = smem + 2 * STAGE;                // [tap][64 pixels] x entry
-
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z;
     const int o0 = blockIdx.y * BN;
@@ -271,21 +270,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
     const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
     const int64_t mb = b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx;
-    for (int tap = wave; tap < KK; tap += 4) {
+    // the logits of this lane's taps (every fourth: wave, wave + 4, ...) are requested up front, three taps at a time, offsets AND
+    // mask -- read one tap after the other, with the mask read only once the offsets say the sample is inside the image, the
+    // phase is six dependent memory round trips (12.4k of a workgroup's 39.6k cycles, cycle stamps)
+    constexpr int TPW = 3;
+    for (int t0 = wave; t0 < KK; t0 += 4 * TPW) {
+        float oh[TPW], ow[TPW], ml[TPW];
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+            const int tap = t0 + 4 * u;
+            oh[u] = ow[u] = ml[u] = 0.f;
+            if (tap < KK && pix < HoWo) {
+                oh[u] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
+                ow[u] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+                if (p.mask) ml[u] = p.mask[mb + (int64_t)tap * p.msk_sc];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TPW; ++u) {
+        const int tap = t0 + 4 * u;
+        if (tap >= KK) break;
         const int it = tap * 64 + px;
         uint32_t go[4] = {kDcnOOB, kDcnOOB, kDcnOOB, kDcnOOB};
         float gw[4] = {0.f, 0.f, 0.f, 0.f};
         float m = 0.f;
         if (pix < HoWo) {
             const int ti = tap / p.kw, tj = tap - ti * p.kw;
-            const float off_h = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
-            const float off_w = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+            const float off_h = oh[u];
+            const float off_w = ow[u];
             const float h_im = (float)(oy * p.sh - p.ph + ti * p.dh) + off_h;
             const float w_im = (float)(ox * p.sw - p.pw + tj * p.dw) + off_w;
             if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
                 m = 1.f;
                 if (p.mask) {
-                    m = p.mask[mb + (int64_t)tap * p.msk_sc];
+                    m = ml[u];
                     // 16-bit formats: v_exp / v_rcp (1 ulp each; the blended value is rounded to 11 / 8 bits next)
                     if (p.mask_sigmoid) m = FOLD ? __frcp_rn(1.0f + __expf(-m)) : 1.0f / (1.0f + expf(-m));
                 }
@@ -308,6 +326,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         }
         *(i32x4*)(geo_tab + (size_t)it * GE) = i32x4{(int)go[0], (int)go[1], (int)go[2], (int)go[3]};
         *(f32x4*)(geo_tab + (size_t)it * GE + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
+        }
     }
     }
     __syncthreads();
@@ -423,7 +442,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         if (more) stash(st ^ 1, cv, wv);             // the other stage was last read in slice kt-1 (barrier below covers it)
         __syncthreads();
     }
-
     // ---- epilogue: bias, optional folded BN, ReLU; 4 consecutive channels per accumulator quad -> NHWC vector stores ----
     const int pix = pix0 + wm * 32 + lr;
     if (pix >= HoWo) return;
