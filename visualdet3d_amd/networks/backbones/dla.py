@@ -26,12 +26,13 @@ class BasicBlock(nn.Module):
         self.stride = stride
         self._cache = fused.PackCache()
 
-    def forward_nhwc(self, x, residual=None):
+    def forward_nhwc(self, x, residual=None, out=None):
+        """``out``: optional channel slice of a wider NHWC buffer (the Root's concatenation) to write the block's output into."""
         if residual is None:
             residual = x
         dt = x.dtype
         y = ops.conv2d(x, _conv_bn(self._cache, 'c1', self.conv1, self.bn1, dt), relu=True)
-        return ops.conv2d(y, _conv_bn(self._cache, 'c2', self.conv2, self.bn2, dt), residual=residual, relu=True)
+        return ops.conv2d(y, _conv_bn(self._cache, 'c2', self.conv2, self.bn2, dt), out=out, residual=residual, relu=True)
 
 
 class Root(nn.Module):
@@ -43,13 +44,19 @@ class Root(nn.Module):
         self.residual = residual
         self._cache = fused.PackCache()
 
-    def forward_nhwc(self, *xs):
+    def forward_nhwc(self, *xs, buf=None):
+        """``buf``: the concatenation buffer when the caller had the first inputs written straight into its leading channel slices
+        (``xs[i]`` is then a view of ``buf``: no copy for it)."""
         B, H, W, _ = xs[0].shape
         tot = sum(t.shape[3] for t in xs)
-        buf = torch.empty((B, H, W, tot), dtype=xs[0].dtype, device=xs[0].device)
+        if buf is None:
+            buf = torch.empty((B, H, W, tot), dtype=xs[0].dtype, device=xs[0].device)
+        assert buf.shape[3] == tot
         off = 0
         for t in xs:
-            ops.copy_channels(t, buf[..., off:off + t.shape[3]])
+            dst = buf[..., off:off + t.shape[3]]
+            if t.data_ptr() != dst.data_ptr():
+                ops.copy_channels(t, dst)
             off += t.shape[3]
         pc = _conv_bn(self._cache, 'c', self.conv, self.bn, buf.dtype)
         return ops.conv2d(buf, pc, residual=xs[0] if self.residual else None, relu=True)
@@ -94,6 +101,15 @@ class Tree(nn.Module):
             residual = bottom
         if self.level_root:
             children.append(bottom)
+        if self.levels == 1:
+            # the two blocks write straight into the leading channel slices of the Root's concatenation [x2 | x1 | children...]
+            C = self.root.conv.out_channels
+            B, H, W, _ = bottom.shape
+            buf = torch.empty((B, H, W, 2 * C + sum(t.shape[3] for t in children)), dtype=x.dtype, device=x.device)
+            x1 = self.tree1.forward_nhwc(x, residual, out=buf[..., C:2 * C])
+            x2 = self.tree2.forward_nhwc(x1, out=buf[..., :C])
+            x = self.root.forward_nhwc(x2, x1, *children, buf=buf)
+            return x
         x1 = self.tree1.forward_nhwc(x, residual)
         if self.levels == 1:
             x2 = self.tree2.forward_nhwc(x1)
