@@ -758,18 +758,22 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             const i32x4 fb2 = *(const i32x4*)(smem + r2 * 512 + ((slot16 ^ (r2 & 15)) << 4));
             Fmt16<T>::mfma32(fa2, fb2, acc2);
         }
-        const int m2 = m0 + r2;
+        // The wave's 32 pixels x nh outputs are one contiguous run of the [M][nh] map.  Stored from the accumulator layout a lane
+        // writes nh scattered floats (16 store instructions of 32 lines each); parked as [pixel][nh] in the wave's own rows of the
+        // tile (its second-GEMM reads are done) the run goes out with consecutive lanes on consecutive floats: whole lines.
         const int nh = p.h_n[h];
-        if (m2 < p.M) {
-            float* dst = p.h_out[h] + (int64_t)m2 * nh;
+        float* stage = (float*)(smem + wave * 32 * 512);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = 8 * g + 4 * half + e;
-                    if (n < nh) dst[n] = acc2[4 * g + e] + p.h_b2[h * 32 + n];
-                }
-        }
+            for (int e = 0; e < 4; ++e) {
+                const int n = 8 * g + 4 * half + e;
+                if (n < nh) stage[lr * nh + n] = acc2[4 * g + e] + p.h_b2[h * 32 + n];
+            }
+        const int mw = m0 + wave * 32;                   // first pixel of this wave's run
+        const int nrun = (p.M - mw < 32 ? (p.M - mw > 0 ? p.M - mw : 0) : 32) * nh;
+        float* dst = p.h_out[h] + (int64_t)mw * nh;
+        for (int i = lane; i < nrun; i += 64) dst[i] = stage[i];
         return;
     }
     if constexpr (MS == 32 && WTN == 64 && sizeof(T) == 2) {
