@@ -483,6 +483,19 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+    // fused KM3D head: this tile's head constants go to LDS behind the operand stages while the first slices are in flight --
+    // read from global in the epilogue, the bias vectors and the 16 second-GEMM weight fragments were ~7k exposed cycles of the
+    // 45k-cycle tile (cycle stamps).  [2 * STAGE, +16 KiB): W2 of head tile_n as [32 rows][512 B], 16-byte slot s of row r at
+    // s ^ (r & 15);  then bias1[256] and bias2[32] fp32.
+    constexpr int HD_W2 = 2 * (BM + BN) * 128, HD_B1 = HD_W2 + 16384, HD_B2 = HD_B1 + 1024;
+    if constexpr (HEADF) {
+        for (int v = tid; v < 32 * 32; v += NW * 64) {
+            const int r = v >> 5, sl = v & 31;
+            *(i32x4*)(smem + HD_W2 + r * 512 + ((sl ^ (r & 15)) << 4)) = *(const i32x4*)(p.h_w2 + ((size_t)(tile_n * 32 + r) * 256 + sl * 8) * 2);
+        }
+        if (tid < 64) *(f32x4*)(smem + HD_B1 + tid * 16) = *(const f32x4*)(p.shift + n0 + tid * 4);
+        if (tid < 8) *(f32x4*)(smem + HD_B2 + tid * 16) = *(const f32x4*)(p.h_b2 + tile_n * 32 + tid * 4);
+    }
 
     // ---- loader state: lane -> (row within piece, logical 16-byte slot) ---------------------------------
     const int prow = lane >> 3;
@@ -733,7 +746,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int c = wn * WTN + i * 32 + 8 * g + 4 * half;       // channel inside the head
-                    const f32x4 sh = *(const f32x4*)(p.shift + n0 + c);
+                    const f32x4 sh = *(const f32x4*)(smem + HD_B1 + c * 4);
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[i][j][4 * g + e] + sh[e], 0.f);
@@ -750,11 +763,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         f32x16 acc2;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
-        const char* w2row = p.h_w2 + ((size_t)(h * 32 + lr) * 256) * 2;
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
             const int slot16 = 2 * ks + half;
-            const i32x4 fa2 = *(const i32x4*)(w2row + slot16 * 16);
+            const i32x4 fa2 = *(const i32x4*)(smem + HD_W2 + lr * 512 + ((slot16 ^ (lr & 15)) << 4));
             const i32x4 fb2 = *(const i32x4*)(smem + r2 * 512 + ((slot16 ^ (r2 & 15)) << 4));
             Fmt16<T>::mfma32(fa2, fb2, acc2);
         }
@@ -768,7 +780,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = 8 * g + 4 * half + e;
-                if (n < nh) stage[lr * nh + n] = acc2[4 * g + e] + p.h_b2[h * 32 + n];
+                if (n < nh) stage[lr * nh + n] = acc2[4 * g + e] + *(const float*)(smem + HD_B2 + n * 4);
             }
         const int mw = m0 + wave * 32;                   // first pixel of this wave's run
         const int nrun = (p.M - mw < 32 ? (p.M - mw > 0 ? p.M - mw : 0) : 32) * nh;
@@ -983,7 +995,7 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int LDS = 2 * (BM + BN) * 128 + (HEADF ? 16384 + 1024 + 128 : 0);    // fused head: + W2 fragments and biases of the tile's head
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static Vd3dLdsLimit lim;
