@@ -244,12 +244,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     constexpr uint32_t kDcnOOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* geo_tab = smem + 2 * STAGE;                // [tap][64 pixels] x entry
+    float* ctab = (float*)(geo_tab + 64 * (p.kh * p.kw) * GE);   // bias | scale | shift of this workgroup's BN output channels
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z;
     const int o0 = blockIdx.y * BN;
     const int HoWo = p.Ho * p.Wo;
     const int pix0 = blockIdx.x * 64;
     const int KK = p.kh * p.kw;
+    for (int i = tid; i < BN; i += 256) {
+        const int o = o0 + i;
+        ctab[i] = (p.bias && o < p.O) ? p.bias[o] : 0.f;
+        ctab[BN + i] = (p.scale && o < p.O) ? p.scale[o] : 1.f;
+        ctab[2 * BN + i] = (p.shift && o < p.O) ? p.shift[o] : 0.f;
+    }
     // Sampling map: 8 consecutive lanes fetch the 8 16-byte vectors of ONE pixel's 128-byte channel run, so a corner load of a
     // wave touches 8 cache lines (one per pixel) instead of 64; a thread handles pixels prow0 and prow0 + 32, vector vslot.
     const int prow0 = tid >> 3, vslot = tid & 7;
@@ -453,30 +460,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         for (int g = 0; g < 4; ++g) {
             const int oc = o0 + wn * (BN / 2) + i * 32 + 8 * g + 4 * half;
             float v[4];
-            if (oc + 3 < p.O) {                      // the quad's per-channel constants as three 16-byte loads
-                const f32x4 bz = p.bias ? *(const f32x4*)(p.bias + oc) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const f32x4 sc = p.scale ? *(const f32x4*)(p.scale + oc) : f32x4{1.f, 1.f, 1.f, 1.f};
-                const f32x4 sh = p.shift ? *(const f32x4*)(p.shift + oc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                // the quad's per-channel constants from the LDS table written at kernel start (bias 0 / scale 1 / shift 0 where the
+                // caller passed none: exact identities); read from global here they were 12 more 1 KiB loads per thread on the L1
+                // path that already bounds this kernel, exposed at the end of the workgroup
+                const int lc = wn * (BN / 2) + i * 32 + 8 * g + 4 * half;
+                const f32x4 bz = *(const f32x4*)(ctab + lc), sc = *(const f32x4*)(ctab + BN + lc), sh = *(const f32x4*)(ctab + 2 * BN + lc);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = acc[i][4 * g + e];
-                    if (p.bias) x += bz[e];
-                    if (p.scale) x = x * sc[e];
-                    if (p.shift) x = x + sh[e];
+                    float x = (acc[i][4 * g + e] + bz[e]) * sc[e] + sh[e];
                     if (p.relu) x = fmaxf(x, 0.f);
-                    v[e] = x;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int o = oc + e;
-                    float x = acc[i][4 * g + e];
-                    if (o < p.O) {
-                        if (p.bias) x += p.bias[o];
-                        if (p.scale) x = x * p.scale[o];
-                        if (p.shift) x = x + p.shift[o];
-                        if (p.relu) x = fmaxf(x, 0.f);
-                    }
                     v[e] = x;
                 }
             }
@@ -679,7 +672,7 @@ __global__ void __launch_bounds__(256) dcn_columns_wave_kernel(const DcnArgs p, 
 
 template <typename T, int BN>
 int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
-    const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * kDcnGeoBytes<T>;   // two stages + the geometry table
+    const int LDS = 2 * (64 + BN) * 128 + 64 * a.kh * a.kw * kDcnGeoBytes<T> + 3 * BN * 4;   // two stages + the geometry table + the epilogue constants
     if (LDS > 160 * 1024) { vd3d_set_error("deform_conv: kernel window too large for the NHWC path"); return VD3D_EINVAL; }
     static Vd3dLdsLimit lim;
     if (const int rc = vd3d_raise_lds_limit((const void*)dcn_nhwc_kernel<T, BN>, 160 * 1024, lim, "hipFuncSetAttribute(dcn_nhwc)")) return rc;
