@@ -50,7 +50,8 @@ template <> struct Mma<float> {
 // one v_permlane32_swap per dword pairs quads (g, g+1) so that every lane stores 16 contiguous bytes (half the store
 // instructions -- the store tail of short-K layers is issue-bound, cf. guide T21).
 template <typename T, int TM, int TN, int WTM, int WTN>
-VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int half) {
+VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int half, const float* ltab = nullptr, int ltn = 0) {
+    // ltab: optional LDS copy of the tile's constants, scale[ltn] | shift[ltn] for channels n0 .. n0 + ltn - 1 (1 / 0 where absent)
     const bool f32_out = sizeof(T) == 4 || p.out_f32;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -72,6 +73,11 @@ VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
                     if (ok) {
+                        if (ltab) {
+                            const f32x4 s = *(const f32x4*)(ltab + (nb - n0)), t = *(const f32x4*)(ltab + ltn + (nb - n0));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = v[e] * s[e] + t[e];
+                        } else {
                         if (p.scale) {
                             const f32x4 s = *(const f32x4*)(p.scale + nb);
 #pragma unroll
@@ -81,6 +87,7 @@ VD3D_DEV void conv_epilogue(const ConvArgs& p, f32x16 (&acc)[TN][TM], const int 
                             const f32x4 s = *(const f32x4*)(p.shift + nb);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) v[e] += s[e];
+                        }
                         }
                         if (p.residual) {
                             if constexpr (sizeof(T) == 2) {
@@ -165,7 +172,7 @@ template <typename T> struct MmaShape<T, 16> {
 // Epilogue for the 16x16x32 layout (weights = A operand): lane (l16, q) holds output channels 4q .. 4q+3 of pixel l16 of
 // the 16x16 block; bf16 only, 8-byte NHWC stores (vector path) or scalar stores.
 template <typename T, int TM, int TN, int WTN>
-VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int q) {
+VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int (&mrow)[TM], int n0, int wn, int q, const float* ltab = nullptr, int ltn = 0) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = mrow[j];
@@ -180,6 +187,11 @@ VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e];
             if (p.vec_epilogue) {
+                if (ltab) {
+                    const f32x4 s = *(const f32x4*)(ltab + (nb - n0)), t = *(const f32x4*)(ltab + ltn + (nb - n0));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * s[e] + t[e];
+                } else {
                 if (p.scale) {
                     const f32x4 s = *(const f32x4*)(p.scale + nb);
 #pragma unroll
@@ -189,6 +201,7 @@ VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int
                     const f32x4 s = *(const f32x4*)(p.shift + nb);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] += s[e];
+                }
                 }
                 if (p.residual) {
                     const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
@@ -386,7 +399,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const
 constexpr int kLineRow = 144;                  // bytes per pixel row of the parking tile (16-byte aligned, 2-way bank conflicts at most)
 template <typename T, int TM>
 VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const int (&mrow)[TM], int mblock0, int nw, int half, int lr, int lane,
-                                  char* tile) {
+                                  char* tile, const float* ltab, int ltn, int n0) {
     const int prow = lane >> 3, pslot = lane & 7;
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -401,15 +414,10 @@ VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                if (p.scale) {
-                    const f32x4 sc = *(const f32x4*)(p.scale + nb);
+                {
+                    const f32x4 s = *(const f32x4*)(ltab + (nb - n0)), t = *(const f32x4*)(ltab + ltn + (nb - n0));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= sc[e];
-                }
-                if (p.shift) {
-                    const f32x4 sh = *(const f32x4*)(p.shift + nb);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += sh[e];
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] * s[e] + t[e];
                 }
                 if (p.residual && mvalid) {
                     const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
@@ -495,6 +503,16 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         }
         if (tid < 64) *(f32x4*)(smem + HD_B1 + tid * 16) = *(const f32x4*)(p.shift + n0 + tid * 4);
         if (tid < 8) *(f32x4*)(smem + HD_B2 + tid * 16) = *(const f32x4*)(p.h_b2 + tile_n * 32 + tid * 4);
+    }
+    // the tile's folded-BN constants (scale | shift of channels n0 .. n0 + BN - 1; 1 / 0 where absent) behind the operand stages:
+    // the epilogues read them with ds_read instead of two global loads per accumulator quad at the end of the tile
+    float* ltab = (float*)(smem + 2 * (BM + BN) * 128);
+    if constexpr (!HEADF) {
+        for (int i = tid; i < BN; i += NW * 64) {
+            const int n = n0 + i;
+            ltab[i] = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
+            ltab[BN + i] = (p.shift && n < p.Cout) ? p.shift[n] : 0.f;
+        }
     }
 
     // ---- loader state: lane -> (row within piece, logical 16-byte slot) ---------------------------------
@@ -792,12 +810,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         if (p.line_store) {          // (host: 16-bit output, Cout % 64 == 0, aligned rows -- every wave's 64-channel strip is whole)
             __syncthreads();         // every wave is done with the operand stages
             if (n0 + wn * WTN < p.Cout)
-                conv_epilogue_lines<T, TM>(p, acc, mrow, m0 + wm * WTM, n0 + wn * WTN, half, lr, lane, smem + wave * (32 * kLineRow));
+                conv_epilogue_lines<T, TM>(p, acc, mrow, m0 + wm * WTM, n0 + wn * WTN, half, lr, lane, smem + wave * (32 * kLineRow), ltab, BN, n0);
             return;
         }
     }
-    if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
-    else conv_epilogue16<T, TM, TN, WTN>(p, acc, mrow, n0, wn, half);
+    if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half, ltab, BN);
+    else conv_epilogue16<T, TM, TN, WTN>(p, acc, mrow, n0, wn, half, ltab, BN);
 }
 
 // =====================================================================================================
@@ -995,7 +1013,7 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
-    constexpr int LDS = 2 * (BM + BN) * 128 + (HEADF ? 16384 + 1024 + 128 : 0);    // fused head: + W2 fragments and biases of the tile's head
+    constexpr int LDS = 2 * (BM + BN) * 128 + (HEADF ? 16384 + 1024 + 128 : (DMA ? 2 * BN * 4 : 0));    // + fused head: W2 fragments and biases; DMA tiles: scale | shift table
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static Vd3dLdsLimit lim;
