@@ -506,14 +506,29 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     }
     // the tile's folded-BN constants (scale | shift of channels n0 .. n0 + BN - 1; 1 / 0 where absent) behind the operand stages:
     // the epilogues read them with ds_read instead of two global loads per accumulator quad at the end of the tile
+    // (requested here, written to LDS after the prologue's DMAs are issued: the wait for these two loads must not delay them)
+    constexpr int TE = (BN + NW * 64 - 1) / (NW * 64);       // table entries per thread (1, or 2 for the 4-wave 288 / 352 strips)
     float* ltab = (float*)(smem + 2 * (BM + BN) * 128);
-    if constexpr (!HEADF) {
-        for (int i = tid; i < BN; i += NW * 64) {
-            const int n = n0 + i;
-            ltab[i] = (p.scale && n < p.Cout) ? p.scale[n] : 1.f;
-            ltab[BN + i] = (p.shift && n < p.Cout) ? p.shift[n] : 0.f;
+    float tsc[TE], tsh[TE];
+#pragma unroll
+    for (int u = 0; u < TE; ++u) {
+        tsc[u] = 1.f;
+        tsh[u] = 0.f;
+        const int i = tid + u * NW * 64;
+        if (!HEADF && i < BN && n0 + i < p.Cout) {
+            if (p.scale) tsc[u] = p.scale[n0 + i];
+            if (p.shift) tsh[u] = p.shift[n0 + i];
         }
     }
+    auto write_ltab = [&]() {
+        if constexpr (!HEADF) {
+#pragma unroll
+            for (int u = 0; u < TE; ++u) {
+                const int i = tid + u * NW * 64;
+                if (i < BN) { ltab[i] = tsc[u]; ltab[BN + i] = tsh[u]; }
+            }
+        }
+    };
 
     // ---- loader state: lane -> (row within piece, logical 16-byte slot) ---------------------------------
     const int prow = lane >> 3;
@@ -646,6 +661,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
         for (int g = 0; g < 4; ++g) issue_group(0, g);
         advance_k();
+        write_ltab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int kt = 0; kt < p.nk; ++kt) {
@@ -674,6 +690,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         advance_k();
         issue_group(1, 0, p.nk > 1);
         issue_group(1, 1, p.nk > 1);
+        write_ltab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         // weight fragments live in a ring of R registers refilled R fragments ahead (R | 4*TN keeps the register <->
@@ -970,10 +987,20 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const 
     // ---- STAGES-deep weight ring with a COUNTED vmcnt: at step t only W(t) (and everything older, incl. the halo issued
     // nine steps earlier) must have landed; the DMAs of steps t+1 .. t+STAGES-2 stay in flight across the barrier, so the
     // L2 -> LDS latency (several hundred cycles) is covered by STAGES-2 slices of MFMA work instead of one.
+    // scale | shift of this N tile go to LDS for the epilogue, as in the tile kernels: requested here, ahead of the first DMAs (older
+    // than everything the counted waits below track), written once those are in flight
+    static_assert(BN <= NW * 64, "one table entry per thread");
+    float* ltab = (float*)(smem + 2 * H_STAGE + STAGES * W_STAGE);
+    float tsc = 1.f, tsh = 0.f;
+    if (tid < BN && n0 + tid < p.Cout) {
+        if (p.scale) tsc = p.scale[n0 + tid];
+        if (p.shift) tsh = p.shift[n0 + tid];
+    }
     issue_halo(0, -1);
 #pragma unroll
     for (int s0 = 0; s0 < STAGES - 1; ++s0)
         if (s0 < nsteps) issue_w(s0, -1);
+    if (tid < BN) { ltab[tid] = tsc; ltab[BN + tid] = tsh; }       // (visible after the first step's barrier)
     for (int step = 0; step < nsteps; ++step) {
         if (step + STAGES - 2 < nsteps) wait_vmcnt<(STAGES - 2) * W_PIECES>();
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -989,7 +1016,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_halo_kernel(const 
         const int y = ty0 + pp / TW, x = tx0 + (pp & (TW - 1));
         mrow[j] = (y < p.H && x < p.W) ? (b * p.H + y) * p.W + x : -1;
     }
-    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half);
+    conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half, ltab, BN);
 }
 
 
@@ -997,7 +1024,7 @@ template <typename T, int TH, int TW, int BN, int WARPS_M, int WARPS_N, int STAG
 int launch_halo(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int HR = (TH + 2) * (TW + 2);
-    constexpr int LDS = 2 * ((HR + 7) / 8) * 1024 + STAGES * BN * 128;
+    constexpr int LDS = 2 * ((HR + 7) / 8) * 1024 + STAGES * BN * 128 + 2 * BN * 4;     // halo stages, weight stages, scale | shift table
     static_assert(LDS <= 160 * 1024, "halo tile does not fit the 160 KiB LDS");
     a.tiles_m = a.B * ((a.H + TH - 1) / TH) * ((a.W + TW - 1) / TW);
     a.tiles_n = (a.Cout + BN - 1) / BN;
