@@ -25,6 +25,7 @@ struct ConvArgs {
     int M, tiles_m, tiles_n, ntaps, nk;
     int vec_epilogue, wide_store, chunk_major;
     int group_m = 0;                  // > 0: DMA tile kernels walk group_m pixel tiles x all N tiles per XCD run (huge 1x1 GEMMs)
+    int strip_lines = 0;              // 16x16x32 strip tiles: 16-bit output re-laid through LDS (whole pixel runs per store instruction)
     int line_store = 0;               // 16-bit output re-laid through LDS so that store instructions cover whole 128-byte lines
     // fused KM3D head (vd3d_km3d_head_fused): per 256-channel N tile h, a second GEMM [256 px x 256] x [256 x n_h] in the
     // epilogue; h_w2 = packed [heads][32][256] bf16, h_b2 = [heads][32] fp32, h_out[h] = fp32 [M][h_n[h]]

@@ -242,6 +242,55 @@ VD3D_DEV void conv_epilogue16(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int
     }
 }
 
+// Whole-line variant of the 16x16x32 epilogue (16-bit output, every channel of the wave's strip inside Cout): the strips finish
+// their ONE round of tiles together, so the output leaves as a synchronised burst -- in the accumulator layout as 8-byte pieces
+// (32 bytes per pixel and store instruction).  Here a wave parks each 16-pixel block of its tile in LDS ([pixel][WTN channels +
+// pad]; the operand stages are free by now) and re-reads it row-major: a store instruction then covers whole pixel runs of
+// WTN * 2 contiguous bytes.  Residual reads stay in the accumulator layout.
+template <typename T, int TM, int TN, int WTN>
+VD3D_DEV void conv_epilogue16_lines(const ConvArgs& p, f32x4 (&acc)[TN][TM], const int (&mrow)[TM], int mblock0, int n0, int nw, int q, int l16,
+                                    int lane, char* tile, const float* ltab, int ltn) {
+    constexpr int ROWB = WTN * 2 + 16;                 // bytes per parked pixel row (16-byte aligned; + 16 spreads the banks)
+    constexpr int CPR = WTN / 8;                       // 16-byte chunks per pixel row
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = mrow[j];
+        const bool mvalid = m >= 0;
+        const int64_t rbase = (int64_t)(mvalid ? m : 0) * p.res_pix_stride;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int nb = nw + i * 16 + 4 * q;
+            float v[4];
+            const f32x4 s = *(const f32x4*)(ltab + (nb - n0)), t = *(const f32x4*)(ltab + ltn + (nb - n0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * s[e] + t[e];
+            if (p.residual && mvalid) {
+                const i32x2 rr = *(const i32x2*)(p.residual + (rbase + nb) * 2);
+                const uint32_t r0 = (uint32_t)(int)rr[0], r1 = (uint32_t)(int)rr[1];
+                v[0] += Fmt16<T>::lo(r0);
+                v[1] += Fmt16<T>::hi(r0);
+                v[2] += Fmt16<T>::lo(r1);
+                v[3] += Fmt16<T>::hi(r1);
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            *(i32x2*)(tile + l16 * ROWB + (i * 16 + 4 * q) * 2) = i32x2{Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3])};
+        }
+#pragma unroll
+        for (int it = 0; it < (16 * CPR + 63) / 64; ++it) {
+            const int c = it * 64 + lane;
+            if (c < 16 * CPR) {
+                const int r = c / CPR, ch = c - r * CPR;
+                const i32x4 o = *(const i32x4*)(tile + r * ROWB + ch * 16);
+                const int mm = mblock0 + j * 16 + r;
+                if (mm < p.M) *(i32x4*)(p.out + ((int64_t)mm * p.out_pix_stride + nw) * 2 + ch * 16) = o;
+            }
+        }
+    }
+}
+
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_kernel(const ConvArgs p) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
@@ -831,6 +880,17 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             return;
         }
     }
+    if constexpr (MS == 16 && WTN % 8 == 0 && !HEADF) {
+        // strips: whole-line stores when the wave's channel strip lies inside Cout and the output rows are 16-byte aligned
+        if (p.strip_lines) {
+            __syncthreads();         // every wave is done with the operand stages (workgroup-uniform branch)
+            if (n0 + wn * WTN + WTN <= p.Cout) {
+                conv_epilogue16_lines<T, TM, TN, WTN>(p, acc, mrow, m0 + wm * WTM, n0, n0 + wn * WTN, half, lr, lane,
+                                                      smem + wave * (16 * (WTN * 2 + 16)), ltab, BN);
+                return;
+            }
+        }
+    }
     if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half, ltab, BN);
     else conv_epilogue16<T, TM, TN, WTN>(p, acc, mrow, n0, wn, half, ltab, BN);
 }
@@ -1334,6 +1394,9 @@ static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     a.group_m = (a.ntaps == 1 && ((int64_t)a.M * p->Cin * es > (512ll << 20) || getenv("VD3D_FORCE_GROUP_M")) && !getenv("VD3D_NO_GROUP_M")) ? 4 : 0;
     // whole-line stores through LDS (conv_epilogue_lines): worth it where the output stream is a large share of the layer's bytes,
     // i.e. short K (1x1 convolutions and small-Cin 3x3): K <= 1152
+    // strips (16x16x32 tiles): whole-line stores through LDS whenever the 16-bit output rows are 16-byte aligned (the wave's strip must
+    // also lie inside Cout: checked per wave)
+    a.strip_lines = a.wide_store && !p->out_f32 && !getenv("VD3D_NO_LINE_STORE");
     a.line_store = a.wide_store && !p->out_f32 && p->Cout % 64 == 0 && (p->out_pix_stride % 64 == 0) && (((uintptr_t)p->out & 127) == 0) &&
                    (int64_t)p->kh * p->kw * p->Cin <= 1152 && !getenv("VD3D_NO_LINE_STORE");
     return VD3D_OK;
