@@ -1392,13 +1392,13 @@ static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     a.chunk_major = (a.ntaps > 1) && (p->Cin % bke == 0);
     // grouped tile order for 1x1 GEMMs whose pixel matrix exceeds the on-die caches (> 512 MB)
     a.group_m = (a.ntaps == 1 && ((int64_t)a.M * p->Cin * es > (512ll << 20) || getenv("VD3D_FORCE_GROUP_M")) && !getenv("VD3D_NO_GROUP_M")) ? 4 : 0;
-    // whole-line stores through LDS (conv_epilogue_lines): worth it where the output stream is a large share of the layer's bytes,
-    // i.e. short K (1x1 convolutions and small-Cin 3x3): K <= 1152
+    // whole-line stores through LDS (conv_epilogue_lines): short-K layers (the output stream is a large share of their bytes) and
+    // long-K layers alike (their few rounds of tiles end as synchronised store bursts)
     // strips (16x16x32 tiles): whole-line stores through LDS whenever the 16-bit output rows are 16-byte aligned (the wave's strip must
     // also lie inside Cout: checked per wave)
     a.strip_lines = a.wide_store && !p->out_f32 && !getenv("VD3D_NO_LINE_STORE");
     a.line_store = a.wide_store && !p->out_f32 && p->Cout % 64 == 0 && (p->out_pix_stride % 64 == 0) && (((uintptr_t)p->out & 127) == 0) &&
-                   (int64_t)p->kh * p->kw * p->Cin <= 1152 && !getenv("VD3D_NO_LINE_STORE");
+                   !getenv("VD3D_NO_LINE_STORE");
     return VD3D_OK;
 }
 
