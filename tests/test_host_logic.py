@@ -114,3 +114,44 @@ def test_product_package_never_touches_the_oracle():
     bench = open(os.path.join(root, 'bench.py')).read()
     uses = [m.start() for m in re.finditer(r'from oracle|import oracle', bench)]
     assert uses and all(bench.rfind('def ', 0, u) == bench.find('def cpu_baseline') for u in uses)
+
+
+def test_weight_register_images_match_the_layout_in_vd3d_h():
+    """Host-side packing of the MFMA register images the resident / point-wise / base-layer kernels load verbatim
+    (``vd3d_conv_params.weight_frag`` and ``vd3d_image_conv7x7`` in include/vd3d.h): every element against the documented index map."""
+    import random
+    import torch
+    from visualdet3d_amd import hip_ops as ops
+    rnd = random.Random(3)
+    g = torch.Generator().manual_seed(3)
+    # 3x3 / s1 / p1: [Cout/32][Cin/64][tap*4 + ks][lane][8]  <-  w[32 nb + (l & 31)][tap][64 kc + (2 ks + (l >> 5)) 8 + e]
+    w = torch.randn(64, 128, 3, 3, generator=g)
+    pc = ops.pack_conv(w, None, None, torch.float16, 1, 1, 1)
+    fr = pc.w_frag.reshape(2, 2, 36, 64, 8).float()
+    wh = w.half().float()
+    for _ in range(300):
+        nb, kc, f, l, e = rnd.randrange(2), rnd.randrange(2), rnd.randrange(36), rnd.randrange(64), rnd.randrange(8)
+        tap, ks = f // 4, f % 4
+        c = 64 * kc + (2 * ks + (l >> 5)) * 8 + e
+        assert fr[nb, kc, f, l, e] == wh[32 * nb + (l & 31), c, tap // 3, tap % 3]
+    # 1x1 / s1 / p0 (point-wise streaming kernel): the same image with one tap
+    w1 = torch.randn(256, 128, 1, 1, generator=g)
+    pc1 = ops.pack_conv(w1, None, None, torch.bfloat16, 1, 0, 1)
+    fr1 = pc1.w_frag.reshape(8, 2, 4, 64, 8).float()
+    w1b = w1.bfloat16().float()
+    for _ in range(300):
+        nb, kc, ks, l, e = rnd.randrange(8), rnd.randrange(2), rnd.randrange(4), rnd.randrange(64), rnd.randrange(8)
+        assert fr1[nb, kc, ks, l, e] == w1b[32 * nb + (l & 31), 64 * kc + (2 * ks + (l >> 5)) * 8 + e, 0, 0]
+    assert ops.pack_conv(torch.randn(96, 64, 1, 1), None, None, torch.bfloat16, 1, 0, 1).w_frag is None      # Cout % 256 != 0: tile kernels
+    # DLA base layer: [7][64][8]  <-  w[o = l & 15][c = e & 3][ky][kx = 2 (l >> 4) + (e >> 2)], zero for c = 3, kx = 7, o >= Cout
+    w7 = torch.randn(12, 3, 7, 7, generator=g)
+    pc7 = ops.pack_image_conv(w7, None, torch.float16, 1, 3)
+    fr7 = pc7.w_frag7.reshape(7, 64, 8).float()
+    w7h = w7.half().float()
+    for ky in range(7):
+        for l in range(64):
+            for e in range(8):
+                o, c, kx = l & 15, e & 3, 2 * (l >> 4) + (e >> 2)
+                want = w7h[o, c, ky, kx] if (o < 12 and c < 3 and kx < 7) else 0.0
+                assert fr7[ky, l, e] == want
+    assert ops.pack_image_conv(w7, None, torch.float32, 1, 3).w_frag7 is None             # fp32: generic path
