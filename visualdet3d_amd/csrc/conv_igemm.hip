@@ -545,13 +545,18 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     // 45k-cycle tile (cycle stamps).  [2 * STAGE, +16 KiB): W2 of head tile_n as [32 rows][512 B], 16-byte slot s of row r at
     // s ^ (r & 15);  then bias1[256] and bias2[32] fp32.
     constexpr int HD_W2 = 2 * (BM + BN) * 128, HD_B1 = HD_W2 + 16384, HD_B2 = HD_B1 + 1024;
+    // (requested here, written to LDS after the prologue's DMAs are issued -- see write_ltab below)
+    constexpr int HDV = HEADF ? (32 * 32) / (NW * 64) : 1;
+    i32x4 hd_w2[HDV];
+    f32x4 hd_b = {0.f, 0.f, 0.f, 0.f};
     if constexpr (HEADF) {
-        for (int v = tid; v < 32 * 32; v += NW * 64) {
-            const int r = v >> 5, sl = v & 31;
-            *(i32x4*)(smem + HD_W2 + r * 512 + ((sl ^ (r & 15)) << 4)) = *(const i32x4*)(p.h_w2 + ((size_t)(tile_n * 32 + r) * 256 + sl * 8) * 2);
+#pragma unroll
+        for (int u = 0; u < HDV; ++u) {
+            const int v = tid + u * NW * 64, r = v >> 5, sl = v & 31;
+            hd_w2[u] = *(const i32x4*)(p.h_w2 + ((size_t)(tile_n * 32 + r) * 256 + sl * 8) * 2);
         }
-        if (tid < 64) *(f32x4*)(smem + HD_B1 + tid * 16) = *(const f32x4*)(p.shift + n0 + tid * 4);
-        if (tid < 8) *(f32x4*)(smem + HD_B2 + tid * 16) = *(const f32x4*)(p.h_b2 + tile_n * 32 + tid * 4);
+        if (tid < 64) hd_b = *(const f32x4*)(p.shift + n0 + tid * 4);
+        else if (tid < 72) hd_b = *(const f32x4*)(p.h_b2 + tile_n * 32 + (tid - 64) * 4);
     }
     // the tile's folded-BN constants (scale | shift of channels n0 .. n0 + BN - 1; 1 / 0 where absent) behind the operand stages:
     // the epilogues read them with ds_read instead of two global loads per accumulator quad at the end of the tile
@@ -570,6 +575,15 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         }
     }
     auto write_ltab = [&]() {
+        if constexpr (HEADF) {
+#pragma unroll
+            for (int u = 0; u < HDV; ++u) {
+                const int v = tid + u * NW * 64, r = v >> 5, sl = v & 31;
+                *(i32x4*)(smem + HD_W2 + r * 512 + ((sl ^ (r & 15)) << 4)) = hd_w2[u];
+            }
+            if (tid < 64) *(f32x4*)(smem + HD_B1 + tid * 16) = hd_b;
+            else if (tid < 72) *(f32x4*)(smem + HD_B2 + (tid - 64) * 16) = hd_b;
+        }
         if constexpr (!HEADF) {
 #pragma unroll
             for (int u = 0; u < TE; ++u) {
