@@ -155,3 +155,22 @@ def test_weight_register_images_match_the_layout_in_vd3d_h():
                 want = w7h[o, c, ky, kx] if (o < 12 and c < 3 and kx < 7) else 0.0
                 assert fr7[ky, l, e] == want
     assert ops.pack_image_conv(w7, None, torch.float32, 1, 3).w_frag7 is None             # fp32: generic path
+
+
+def test_grouped_tile_order_is_a_bijection():
+    """The tile remap of ConvArgs::group_m (csrc/conv_igemm.hip: group_m pixel tiles x all N tiles per run) restated in Python: every
+    (tile_m, tile_n) is produced exactly once for tile counts that are and are not multiples of the group, and a run of
+    group_m * tiles_n consecutive indices covers all N tiles of group_m pixel tiles."""
+    def remap(tile, tiles_m, tiles_n, group_m):
+        per = group_m * tiles_n
+        g, rr = divmod(tile, per)
+        gm = min(group_m, tiles_m - g * group_m)
+        tile_n = rr // gm
+        return g * group_m + rr - tile_n * gm, tile_n
+
+    for tiles_m, tiles_n, gm in [(180, 8, 4), (7, 3, 4), (1, 5, 4), (9, 1, 4), (10, 2, 3)]:
+        seen = [remap(t, tiles_m, tiles_n, gm) for t in range(tiles_m * tiles_n)]
+        assert len(set(seen)) == tiles_m * tiles_n
+        assert all(0 <= m < tiles_m and 0 <= n < tiles_n for m, n in seen)
+        first = seen[:gm * tiles_n] if tiles_m >= gm else seen
+        assert {n for _, n in first} == set(range(tiles_n)) and len({m for m, _ in first}) == min(gm, tiles_m)
