@@ -79,13 +79,8 @@ typedef struct vd3d_conv_params {
 } vd3d_conv_params;
 
 int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream);
-/* Test / tuning hook, not part of the drop-in surface: force a tile configuration (0 = built-in heuristic) for every
- * following vd3d_conv2d_igemm call of the process.  The product library only accepts the ids of the tiles its heuristic can
- * select (vd3d_conv2d_production_tiles); a forced tile that cannot run a given convolution makes that call return
- * VD3D_EINVAL -- the library never returns numbers from a kernel that is wrong for the shape.  Experimental tiles and the
- * timing ablations live in the separate -DVD3D_TUNING build (libvd3d_hip_tuning.so, tools/bench_conv.py). */
-int vd3d_conv2d_set_tuning(int cfg);
-/* ids of the production tiles -> ids[0..cap); returns how many there are. */
+/* ids of the tiles the dispatch heuristic can select -> ids[0..cap); returns how many there are (every one of them is forced
+ * against the oracle by tests/test_conv_tiles_gpu.py through the test hook of csrc/test_hooks.h, which is not part of this ABI). */
 int vd3d_conv2d_production_tiles(int32_t* ids, int cap);
 
 /* Test-time image pipeline for ONE frame, fed from uint8 (data/pipeline/stereo_augmentator.py: ConvertToFloat :30-36,

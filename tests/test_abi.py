@@ -19,6 +19,12 @@ def test_header_symbols_are_exported_and_bound():
     assert len(declared) >= 25
     out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = set(re.findall(r' T (vd3d_[a-z0-9_]+)', out))
+    # test hooks (csrc/test_hooks.h) are exported but deliberately NOT part of the drop-in ABI
+    hooks = {e for e in exported if e.startswith('vd3d_test_')}
+    hdr = re.sub(r'/\*.*?\*/', '', open(os.path.join(REPO, 'visualdet3d_amd', 'csrc', 'test_hooks.h')).read(), flags=re.S)
+    assert hooks == set(re.findall(r'\b(vd3d_test_[a-z0-9_]+)\s*\(', hdr)) == set(_lib.TEST_HOOKS)
+    assert not any(d.startswith('vd3d_test_') for d in declared), 'test hooks must stay out of include/vd3d.h'
+    exported -= hooks
     assert declared <= exported, 'declared but not exported: %s' % sorted(declared - exported)
     assert exported <= declared, 'exported but not declared in include/vd3d.h: %s' % sorted(exported - declared)
     assert set(_lib.SIGNATURES) == declared, sorted(set(_lib.SIGNATURES) ^ declared)

@@ -2,7 +2,7 @@
 rounded exactly like the HIP path rounds them), not against another tile of the same family.
 
   * `vd3d_conv2d_production_tiles` lists the tile ids the heuristic in csrc/conv_igemm.hip can select; each one is FORCED
-    (`vd3d_conv2d_set_tuning`) on small shapes that are deliberately awkward for it: M not a tile multiple, Cout not a
+    (`vd3d_test_force_conv_tile`) on small shapes that are deliberately awkward for it: M not a tile multiple, Cout not a
     tile multiple, with / without residual, channel-slice input and output, fp32 output from bf16 compute.
   * the tiles the bench (BASELINE config 2, batch 8) actually runs are then checked under NATURAL dispatch at the
     bench's own layer shapes (M = 8 x 24 x 80 = 15360 pixels: 1408->1408, 1152->1152, 1408->576, 1408->256; layer1/2/3 of
@@ -32,11 +32,11 @@ class forced_tile:
 
     def __enter__(self):
         from visualdet3d_amd import _lib
-        _lib.lib().vd3d_conv2d_set_tuning(self.cfg)
+        _lib.lib().vd3d_test_force_conv_tile(self.cfg)
 
     def __exit__(self, *exc):
         from visualdet3d_amd import _lib
-        _lib.lib().vd3d_conv2d_set_tuning(0)
+        _lib.lib().vd3d_test_force_conv_tile(0)
 
 
 def run_case(B, H, W, Cin, Cout, k=3, stride=1, pad=1, dil=1, residual=False, relu=True, dtype=torch.bfloat16, bn=True,
@@ -227,7 +227,7 @@ def test_whole_line_epilogue_of_the_tile_kernels(cfg, dtype):
     """conv_epilogue_lines: short-K layers with Cout % 64 == 0 re-lay their 16-bit outputs through LDS so that store
     instructions cover whole 128-byte lines (ConvArgs::line_store).  Against the oracle, and bit-identical to the accumulator-layout
     stores it replaces (VD3D_NO_LINE_STORE=1): same arithmetic, only the store shape differs."""
-    import os
+    from visualdet3d_amd import _lib
     cases = [
         (2, 9, 31, 256, 128, dict(k=1, pad=0, residual=True)),                    # ragged M (558 pixels), two 64-channel strips
         (1, 13, 27, 64, 192, dict(residual=True, out_extra=64)),                  # 3x3, channel-slice view (pixel stride 256)
@@ -245,11 +245,8 @@ def test_whole_line_epilogue_of_the_tile_kernels(cfg, dtype):
     pc = ops.pack_conv(w, None, None, dtype, 1, 0, 1)
     with forced_tile(cfg):
         a = ops.conv2d(x, pc, residual=res, relu=True)
-        os.environ['VD3D_NO_LINE_STORE'] = '1'
-        try:
+        with _lib.test_switch('VD3D_NO_LINE_STORE'):
             b = ops.conv2d(x, pc, residual=res, relu=True)
-        finally:
-            del os.environ['VD3D_NO_LINE_STORE']
     assert torch.equal(a, b)
 
 
@@ -258,8 +255,7 @@ def test_grouped_tile_order_of_huge_1x1_gemms(cfg):
     """ConvArgs::group_m (1x1 GEMMs whose pixel matrix exceeds the on-die caches: the DCN column GEMM of BASELINE config 3) only
     permutes which workgroup computes which tile: forced on small shapes (VD3D_FORCE_GROUP_M=1), results must equal the plain order
     bit for bit -- tile counts that are and are not multiples of the group (4 pixel tiles), one and several N tiles."""
-    import os
-    from visualdet3d_amd import hip_ops as ops
+    from visualdet3d_amd import _lib, hip_ops as ops
     g = torch.Generator().manual_seed(21)
     for (B, H, W, Cin, Cout) in [(2, 18, 40, 192, 544), (1, 23, 31, 128, 272), (3, 16, 32, 64, 1088)]:
         x = torch.randn(B, H, W, Cin, generator=g).cuda().to(torch.bfloat16)
@@ -267,11 +263,8 @@ def test_grouped_tile_order_of_huge_1x1_gemms(cfg):
         pc = ops.pack_conv(w, None, None, torch.bfloat16, 1, 0, 1)
         with forced_tile(cfg):
             a = ops.conv2d(x, pc, relu=True)
-            os.environ['VD3D_FORCE_GROUP_M'] = '1'
-            try:
+            with _lib.test_switch('VD3D_FORCE_GROUP_M'):
                 b = ops.conv2d(x, pc, relu=True)
-            finally:
-                del os.environ['VD3D_FORCE_GROUP_M']
         assert torch.equal(a, b), (cfg, B, H, W, Cin, Cout)
     ulp, rel = run_case(2, 18, 40, 192, 544, k=1, pad=0, residual=True, dtype=torch.bfloat16, seed=77, cfg=cfg)
     assert ulp <= 1.0

@@ -200,19 +200,15 @@ def test_deform_columns_wave_kernel_matches_thread_per_vector_kernel(dtype):
     thread-per-vector one (VD3D_DCN_COLUMNS_GENERIC=1 forces it).  Same sampling arithmetic: fp32 equal to round-off, the 16-bit
     formats equal except where the folded modulation (sum (w m) x vs (sum w x) m) flips a rounding tie (<= 1 ulp, rare).
     Odd sizes: C = 72 channels (ragged last channel sweep), 7 x 9 pixels x 9 taps = 567 samples (ragged last wave)."""
-    import os
-    from visualdet3d_amd import hip_ops as ops
+    from visualdet3d_amd import _lib, hip_ops as ops
     g = torch.Generator().manual_seed(11)
     B, H, W, C = 2, 7, 9, 72
     x = torch.randn(B, H, W, C, generator=g).cuda().to(dtype)
     logits = (torch.randn(B, H, W, 32, generator=g) * 2.0).cuda()
     logits[0, 0, 0, :18] = 40.0                       # samples far outside the image -> zero columns
     cols = ops.deform_columns(x, logits[..., :18], logits[..., 18:27], (3, 3), (1, 1), (1, 1), (1, 1), mask_sigmoid=True)
-    os.environ['VD3D_DCN_COLUMNS_GENERIC'] = '1'
-    try:
+    with _lib.test_switch('VD3D_DCN_COLUMNS_GENERIC'):
         ref = ops.deform_columns(x, logits[..., :18], logits[..., 18:27], (3, 3), (1, 1), (1, 1), (1, 1), mask_sigmoid=True)
-    finally:
-        del os.environ['VD3D_DCN_COLUMNS_GENERIC']
     torch.cuda.synchronize()
     assert cols.shape == ref.shape and bool((cols[0, 0, 0] == 0).all())
     d = (cols.float() - ref.float()).abs()

@@ -102,3 +102,29 @@ def test_get_bboxes_reference_signature_no_clip_and_cls_agnostic_flag():
     head.test_cfg.cls_agnositc = False
     with pytest.raises(NotImplementedError):
         head.get_bboxes(cls.cuda(), reg.cuda(), a, P2.cuda(), img_batch=img)
+
+
+def test_pack_detections_record_wider_than_capacity_and_nan_padding():
+    """vd3d_pack_detections with K < k (KM3D's decode returns K = 100 rows; the gather record has 128) and NaN in the padding
+    rows (the result buffers are torch.empty): rows past the count and past K are exactly zero, the count rides in row k."""
+    from visualdet3d_amd import hip_ops as ops
+    B, K, k = 3, 100, 128
+    g = torch.Generator().manual_seed(3)
+    scores = torch.rand(B, K, generator=g)
+    boxes = torch.randn(B, K, 11, generator=g)
+    labels = torch.randint(0, 3, (B, K), generator=g, dtype=torch.int32)
+    count = torch.tensor([100, 0, 37], dtype=torch.int32)
+    for b in range(B):
+        scores[b, int(count[b]):] = float('nan')
+        boxes[b, int(count[b]):] = float('inf')
+    out = ops.pack_detections(scores.cuda(), boxes.cuda(), labels.cuda(), count.cuda(), k).cpu()
+    assert out.shape == (B, k + 1, 13) and bool(torch.isfinite(out).all())
+    for b in range(B):
+        n = int(count[b])
+        assert torch.equal(out[b, :n, 0], scores[b, :n]) and torch.equal(out[b, :n, 1:12], boxes[b, :n])
+        assert torch.equal(out[b, :n, 12], labels[b, :n].float())
+        assert bool((out[b, n:k] == 0).all()) and out[b, k, 0] == n and bool((out[b, k, 1:] == 0).all())
+    from visualdet3d_amd.distributed import DetectionGather
+    dg = DetectionGather(B, k, 'cuda', world=1)
+    dg.fill(scores.cuda(), boxes.cuda(), labels.cuda(), count.cuda())
+    assert torch.equal(dg.pack.cpu(), out)

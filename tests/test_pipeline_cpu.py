@@ -54,3 +54,26 @@ def test_gather_helpers_raise_on_overflow_marked_counts():
     with pytest.raises(RuntimeError, match='max_candidates'):
         g.detections()
     assert g.tensor_collective is False           # no process group / gloo: the list form; decided once, no try/except per step
+
+
+def test_padding_rows_are_zeroed_by_selection_not_by_multiplication():
+    """the padding of the device result buffers is uninitialised memory (``torch.empty``): NaN / Inf there must not
+    survive into the gathered record (NaN * 0 = NaN)."""
+    from visualdet3d_amd import distributed as vdist
+    B, K, k = 2, 6, 4
+    scores = torch.full((B, K), float('nan'))
+    boxes = torch.full((B, K, 11), float('inf'))
+    labels = torch.full((B, K), 7, dtype=torch.int32)
+    count = torch.tensor([2, 0], dtype=torch.int32)
+    scores[0, :2] = torch.tensor([0.9, 0.8])
+    boxes[0, :2] = 1.5
+    pack, c = vdist.pack_detections(scores, boxes, labels, count, k)
+    assert bool(torch.isfinite(pack).all()) and bool((pack[0, 2:] == 0).all()) and bool((pack[1] == 0).all())
+    assert pack[0, 0, 0] == 0.9 and pack[0, 1, 1] == 1.5 and pack[0, 1, 12] == 7 and c.tolist() == [2, 0]
+    g = vdist.DetectionGather(B, k, 'cpu', world=1)
+    g.fill(scores, boxes, labels, count)
+    assert bool(torch.isfinite(g.pack).all()) and bool((g.pack[0, 2:k] == 0).all()) and g.pack[0, k, 0] == 2
+    # a record wider than the detector's own capacity (KM3D decodes K = 100 rows, the bench gathers 128): rows K .. k-1 are zero
+    g2 = vdist.DetectionGather(B, 8, 'cpu', world=1)
+    g2.fill(scores, boxes, labels, count)
+    assert bool(torch.isfinite(g2.pack).all()) and bool((g2.pack[:, K:8] == 0).all())

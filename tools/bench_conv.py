@@ -50,7 +50,7 @@ for name, B, H, W, Cin, Cout in SHAPES:
     for c in cfgs:
         if skip(c, Cout):
             continue
-        _lib.lib().vd3d_conv2d_set_tuning(c)
+        _lib.lib().vd3d_test_force_conv_tile(c)
         try:
             out = ops.conv2d(x, pc, residual=res, relu=True)
             torch.cuda.synchronize()
@@ -68,7 +68,7 @@ for name, B, H, W, Cin, Cout in SHAPES:
     out = torch.empty_like(res)
     for rnd in range(4):                       # round-robin, several rounds: the first round is a clock warm-up
         for c in ok_cfgs:
-            _lib.lib().vd3d_conv2d_set_tuning(c)
+            _lib.lib().vd3d_test_force_conv_tile(c)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for _ in range(3):
                 ops.conv2d(x, pc, out=out, residual=res, relu=True)
@@ -83,5 +83,5 @@ for name, B, H, W, Cin, Cout in SHAPES:
     for c in cfgs:
         v = best.get(c, '--')
         line += '  cfg%d %s' % (c, ('%6.0f TF' % v) if isinstance(v, float) else v)
-    _lib.lib().vd3d_conv2d_set_tuning(0)
+    _lib.lib().vd3d_test_force_conv_tile(0)
     print(line, flush=True)

@@ -28,7 +28,7 @@ for name, B, H, W, Cin, Cout, res in SHAPES:
     line = '%-24s' % name
     ref = None
     for c in cfgs:
-        _lib.lib().vd3d_conv2d_set_tuning(c)
+        _lib.lib().vd3d_test_force_conv_tile(c)
         try:
             out = ops.conv2d(x, pc, residual=r, relu=True)
             torch.cuda.synchronize()
@@ -48,5 +48,5 @@ for name, B, H, W, Cin, Cout, res in SHAPES:
         torch.cuda.synchronize()
         t = s.elapsed_time(e) * 1e-4
         line += '  cfg%-2d %6.1f us %4.2f TB/s' % (c, t * 1e6, by / t / 1e12)
-    _lib.lib().vd3d_conv2d_set_tuning(0)
+    _lib.lib().vd3d_test_force_conv_tile(0)
     print(line, flush=True)

@@ -12,7 +12,7 @@ w = torch.randn(Cout, Cin, 3, 3, device='cuda') * 0.03
 pc = ops.pack_conv(w, None, None, torch.bfloat16, 1, 1, 1)
 res = torch.randn(B, H, W, Cout, device='cuda').to(torch.bfloat16)
 lib = _lib.lib()
-lib.vd3d_conv2d_set_tuning(67)
+lib.vd3d_test_force_conv_tile(67)
 for _ in range(3):
     ops.conv2d(x, pc, residual=res, relu=True)
 torch.cuda.synchronize()

@@ -7,9 +7,20 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VD3D_TUNING_LIB=1 (tools/ only): the -DVD3D_TUNING build with the experimental tiles / timing ablations; a value ending in
-# .so names an A/B build of the library next to this file
+# .so names an A/B build of the library NEXT TO THIS FILE (only the base name is used: a path in the environment must not be
+# able to load an arbitrary shared object).  Loading anything but the product library is announced on stderr.
 _T = os.environ.get('VD3D_TUNING_LIB', '')
-LIB_PATH = os.path.join(_HERE, _T if _T.endswith('.so') else ('libvd3d_hip_tuning.so' if _T else 'libvd3d_hip.so'))
+if _T.endswith('.so'):
+    if os.path.basename(_T) != _T:
+        raise ImportError('VD3D_TUNING_LIB=%r: only the name of a library next to %s is accepted, not a path' % (_T, _HERE))
+    _NAME = _T
+else:
+    _NAME = 'libvd3d_hip_tuning.so' if _T else 'libvd3d_hip.so'
+LIB_PATH = os.path.join(_HERE, _NAME)
+if _NAME != 'libvd3d_hip.so':
+    import sys as _sys
+    print('[visualdet3d_amd] WARNING: loading %s instead of the product library (VD3D_TUNING_LIB=%s): tuning builds contain '
+          'timing ablations whose results are wrong by construction' % (_NAME, _T), file=_sys.stderr)
 
 VD3D_BF16 = 0
 VD3D_F32 = 1
@@ -73,7 +84,6 @@ SIGNATURES = {
     'vd3d_abi_version': (c_int, []),
     'vd3d_last_error': (C.c_char_p, []),
     'vd3d_conv2d_igemm': (c_int, [C.POINTER(ConvParams), c_void_p]),
-    'vd3d_conv2d_set_tuning': (c_int, [c_int]),
     'vd3d_conv2d_production_tiles': (c_int, [c_void_p, c_int]),
     'vd3d_pack_image_nhwc4': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_maxpool3x3s2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
@@ -113,6 +123,11 @@ SIGNATURES = {
     'vd3d_km3d_head_fused': (c_int, [C.POINTER(ConvParams), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'vd3d_post_opt': (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_float] * 3 + [c_int, c_void_p]),
 }
+# TEST hooks (csrc/test_hooks.h): exported by the library, NOT part of the drop-in ABI of include/vd3d.h
+TEST_HOOKS = {
+    'vd3d_test_force_conv_tile': (c_int, [c_int]),
+    'vd3d_test_set_switch': (c_int, [C.c_char_p, c_int]),
+}
 # declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)
 PENDING = {
 }
@@ -136,7 +151,7 @@ def lib():
         # /opt/rocm's copy first would leave two HIP runtimes in the process ("no ROCm-capable device").
         import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(TEST_HOOKS.items()):
             fn = getattr(h, name)  # AttributeError if the .so is stale
             fn.restype = res
             fn.argtypes = args
@@ -151,3 +166,17 @@ def check(rc, what):
     if rc != 0:
         msg = lib().vd3d_last_error()
         raise Vd3dError('%s failed (rc=%d): %s' % (what, rc, msg.decode() if msg else ''))
+
+
+class test_switch:
+    """``with test_switch('VD3D_NO_LINE_STORE'):`` -- flip one of the library's A/B switches for the block; the
+    library reads the environment only once per process, so tests go through the hook of csrc/test_hooks.h."""
+
+    def __init__(self, name, on=True):
+        self.name, self.on = name.encode(), int(bool(on))
+
+    def __enter__(self):
+        check(lib().vd3d_test_set_switch(self.name, self.on), 'vd3d_test_set_switch')
+
+    def __exit__(self, *exc):
+        check(lib().vd3d_test_set_switch(self.name, 1 - self.on), 'vd3d_test_set_switch')

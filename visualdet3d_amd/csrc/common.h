@@ -132,6 +132,14 @@ template <> struct Vec16<float> {
 void vd3d_set_error(const char* msg);
 int vd3d_check_launch(const char* what);
 
+// A/B switches between two CORRECT implementations.  Each is the environment variable of the same name, read ONCE
+// per process (no getenv on the launch path, no race with setenv); tests flip them through vd3d_test_set_switch (test_hooks.h).
+enum Vd3dSwitch {
+    VD3D_SW_CONV_DEBUG, VD3D_SW_FORCE_GROUP_M, VD3D_SW_NO_GROUP_M, VD3D_SW_NO_LINE_STORE, VD3D_SW_DCN_GENERIC,
+    VD3D_SW_DCN_COLUMNS_GENERIC, VD3D_SW_CONV3D_VALU, VD3D_SW_DCN_NO_WINDOW, VD3D_SW_COUNT
+};
+bool vd3d_switch(Vd3dSwitch s);
+
 static inline int vd3d_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Per-DEVICE launch bookkeeping.  hipFuncSetAttribute acts on the current device's copy of a kernel, so "dynamic-LDS limit

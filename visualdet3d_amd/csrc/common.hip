@@ -2,6 +2,10 @@
 #include "common.h"
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
+#include <mutex>
+#include "test_hooks.h"
 
 static thread_local char g_err[512] = "";
 
@@ -15,6 +19,29 @@ int vd3d_check_launch(const char* what) {
     if (e == hipSuccess) return VD3D_OK;
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return VD3D_ELAUNCH;
+}
+
+static const char* const kSwitchNames[VD3D_SW_COUNT] = {
+    "VD3D_CONV_DEBUG", "VD3D_FORCE_GROUP_M", "VD3D_NO_GROUP_M", "VD3D_NO_LINE_STORE", "VD3D_DCN_GENERIC",
+    "VD3D_DCN_COLUMNS_GENERIC", "VD3D_CONV3D_VALU", "VD3D_DCN_NO_WINDOW"};
+static std::atomic<int> g_switch[VD3D_SW_COUNT];
+static std::once_flag g_switch_once;
+
+static void switches_from_env() {
+    for (int i = 0; i < VD3D_SW_COUNT; ++i) g_switch[i].store(getenv(kSwitchNames[i]) != nullptr, std::memory_order_relaxed);
+}
+
+bool vd3d_switch(Vd3dSwitch s) {
+    std::call_once(g_switch_once, switches_from_env);
+    return g_switch[s].load(std::memory_order_relaxed) != 0;
+}
+
+extern "C" int vd3d_test_set_switch(const char* name, int on) {
+    std::call_once(g_switch_once, switches_from_env);
+    for (int i = 0; i < VD3D_SW_COUNT; ++i)
+        if (name && !strcmp(name, kSwitchNames[i])) { g_switch[i].store(on != 0, std::memory_order_relaxed); return VD3D_OK; }
+    vd3d_set_error("vd3d_test_set_switch: unknown switch");
+    return VD3D_EINVAL;
 }
 
 int vd3d_current_device() {

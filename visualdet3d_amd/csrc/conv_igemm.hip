@@ -1128,12 +1128,13 @@ int launch(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_igemm");
 }
 
-// Tile override: 0 = heuristic, otherwise a config id (vd3d_conv2d_set_tuning).  The PRODUCT build only knows the ids of the
+// Tile override: 0 = heuristic, otherwise a config id (vd3d_test_force_conv_tile, csrc/test_hooks.h: a TEST hook, thread-local,
+// not declared in include/vd3d.h).  The PRODUCT build only knows the ids of the
 // tiles the heuristic below can pick (tests/test_conv_tiles_gpu.py forces each of them on awkward shapes and compares with
 // the oracle); a forced tile that cannot run the given convolution is an error, never a silent fallback.  Experimental
 // tiles and the timing ablations (results wrong by construction) exist only in a -DVD3D_TUNING build
 // (`python -m visualdet3d_amd.build --tuning` -> libvd3d_hip_tuning.so, used by tools/bench_conv.py).
-static int g_force_cfg = 0;
+static thread_local int g_force_cfg = 0;      // per calling thread: a test forcing a tile cannot leak into other threads' launches
 
 static int forced_tile_error(const char* why) {
     char msg[160];
@@ -1272,47 +1273,50 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     // x tile-edge waste x last-round occupancy.  Candidates: 128x128 (2 workgroups/CU), 256x256 (8 waves of 128x64,
     // 1/CU), and "column strips" 256xBN / 128xBN with BN = 288 | 352 (= 1152/4, 1408/4: every wave owns 32 pixels x
     // the whole strip) which put the 1152- and 1408-channel layers at B = 8 on the chip in ONE ~94 %-full round.
+    // workgroup slots of one round: one (256-row tiles, > 80 KiB of LDS) or two (128-row tiles) workgroups per CU of THIS device
+    const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
+    const int kSlots1 = cus, kSlots2 = 2 * cus;
     auto util = [&](int bm, int bn, int slots) {
         const double tm = (a.M + bm - 1) / bm, tn = (a.Cout + bn - 1) / bn;
         const double tiles = tm * tn;
         const double rounds = (double)((int64_t)((tiles + slots - 1) / slots));
         return ((double)a.M * a.Cout) / (tm * bm * tn * bn) * tiles / (rounds * slots);
     };
-    double best = 1000.0 * util(128, 128, 512);
+    double best = 1000.0 * util(128, 128, kSlots2);
     int pick = 0;
-    const double r256 = 1450.0 * util(256, 256, 256);
+    const double r256 = 1450.0 * util(256, 256, kSlots1);
     if (r256 > best) { best = r256; pick = 1; }
     if (a.Cout % 352 == 0) {
-        const double r = 1470.0 * util(256, 352, 256);
+        const double r = 1470.0 * util(256, 352, kSlots1);
         if (r > best) { best = r; pick = 2; }
-        const double r2 = 900.0 * util(128, 352, 256);
+        const double r2 = 900.0 * util(128, 352, kSlots1);
         if (r2 > best) { best = r2; pick = 4; }
     }
     if (sizeof(T) == 2 && a.Cout % 272 == 0) {   // 2176 = 8 x 272 (Stereo3D R50 head): 8 waves of 32 x 272 on 16x16x32 MFMAs, +20 %
-        const double r = 1320.0 * util(256, 272, 256);
+        const double r = 1320.0 * util(256, 272, kSlots1);
         if (r > best) { best = r; pick = 7; }
     }
     if (a.Cout % 192 == 0) {     // 80 KiB LDS: two workgroups per CU
-        const double r = 1390.0 * util(128, 192, 512);
+        const double r = 1390.0 * util(128, 192, kSlots2);
         if (r > best) { best = r; pick = 6; }
     }
     if (a.Cout % 288 == 0 || (sizeof(T) == 2 && a.Cout > 1152)) {
         // (a partial last strip is fine: 2176 = 7.56 x 288 runs 1298 TF/s on the 288 strips against 1246 on 8 x 272 -- the 4 x 2-wave
         //  16x16x32 layout reads fewer fragment bytes per MFMA than the 8 x 1 layout of the 272 strip)
-        const double r = 1455.0 * util(256, 288, 256);
+        const double r = 1455.0 * util(256, 288, kSlots1);
         if (r > best) { best = r; pick = 3; }
     }
     if (a.Cout % 288 == 0) {
         // bf16: 8 waves of 32 x 144 on 16x16x32 MFMAs: 1109 vs 929 TF/s (128x192 tiles) on the 1408 -> 576 reg output conv
         // (only with >= 2 strips per pixel tile: on the 288 -> 288 neck convs the 120 tiles leave half the chip idle, 69 vs 55 us)
-        const double r2 = (sizeof(T) == 2 && a.Cout >= 576 ? 1200.0 : 850.0) * util(128, 288, 256);
+        const double r2 = (sizeof(T) == 2 && a.Cout >= 576 ? 1200.0 : 850.0) * util(128, 288, kSlots1);
         if (r2 > best) { best = r2; pick = 5; }
         if (sizeof(T) == 2 && a.Cout == 288) {     // 128 x 144 tiles on 16x16x32 MFMAs, two workgroups per CU: 544 vs 484 TF/s on 288 -> 288
-            const double r3 = 1160.0 * util(128, 144, 512);
+            const double r3 = 1160.0 * util(128, 144, kSlots2);
             if (r3 > best) { best = r3; pick = 8; }
         }
     }
-    if (getenv("VD3D_CONV_DEBUG")) fprintf(stderr, "[vd3d conv] M=%d N=%d pick=%d best=%.0f\n", a.M, a.Cout, pick, best);
+    if (vd3d_switch(VD3D_SW_CONV_DEBUG)) fprintf(stderr, "[vd3d conv] M=%d N=%d pick=%d best=%.0f\n", a.M, a.Cout, pick, best);
     switch (pick) {
         // the software-pipelined main loop (PIPE) measured +2.5 % (256x352) ... +17 % (256x288 on Cout 576) over the
         // barrier-per-slice loop on every shape of the hot path
@@ -1344,7 +1348,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int vd3d_conv2d_set_tuning(int cfg) {
+extern "C" int vd3d_test_force_conv_tile(int cfg) {
     g_force_cfg = cfg;
     return VD3D_OK;
 }
@@ -1405,14 +1409,14 @@ static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     a.wide_store = a.vec_epilogue && oes == 2 && (p->Cout % 16 == 0) && (p->out_pix_stride % 8 == 0) && (((uintptr_t)p->out & 15) == 0);
     a.chunk_major = (a.ntaps > 1) && (p->Cin % bke == 0);
     // grouped tile order for 1x1 GEMMs whose pixel matrix exceeds the on-die caches (> 512 MB)
-    a.group_m = (a.ntaps == 1 && ((int64_t)a.M * p->Cin * es > (512ll << 20) || getenv("VD3D_FORCE_GROUP_M")) && !getenv("VD3D_NO_GROUP_M")) ? 4 : 0;
+    a.group_m = (a.ntaps == 1 && ((int64_t)a.M * p->Cin * es > (512ll << 20) || vd3d_switch(VD3D_SW_FORCE_GROUP_M)) && !vd3d_switch(VD3D_SW_NO_GROUP_M)) ? 4 : 0;
     // whole-line stores through LDS (conv_epilogue_lines): short-K layers (the output stream is a large share of their bytes) and
     // long-K layers alike (their few rounds of tiles end as synchronised store bursts)
     // strips (16x16x32 tiles): whole-line stores through LDS whenever the 16-bit output rows are 16-byte aligned (the wave's strip must
     // also lie inside Cout: checked per wave)
-    a.strip_lines = a.wide_store && !p->out_f32 && !getenv("VD3D_NO_LINE_STORE");
+    a.strip_lines = a.wide_store && !p->out_f32 && !vd3d_switch(VD3D_SW_NO_LINE_STORE);
     a.line_store = a.wide_store && !p->out_f32 && p->Cout % 64 == 0 && (p->out_pix_stride % 64 == 0) && (((uintptr_t)p->out & 127) == 0) &&
-                   !getenv("VD3D_NO_LINE_STORE");
+                   !vd3d_switch(VD3D_SW_NO_LINE_STORE);
     return VD3D_OK;
 }
 

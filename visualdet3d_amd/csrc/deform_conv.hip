@@ -716,7 +716,7 @@ int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
     // channel-contiguous activations, one group: the NHWC fast path (everything the detectors launch)
     if (a.groups == 1 && a.dgroups == 1 && a.in_sc == 1 && a.out_sc == 1 && a.Cg % bke == 0 && ((uintptr_t)q->in & 15) == 0 &&
         (int64_t)a.H * a.in_sy * es < 0x7fffffffll && 64 * a.kh * a.kw * 48 + 2 * (64 + 256) * 128 <= 160 * 1024 &&
-        a.in_sx % (16 / es) == 0 && a.in_sy % (16 / es) == 0 && a.in_sb % (16 / es) == 0 && !getenv("VD3D_DCN_GENERIC"))
+        a.in_sx % (16 / es) == 0 && a.in_sy % (16 / es) == 0 && a.in_sb % (16 / es) == 0 && !vd3d_switch(VD3D_SW_DCN_GENERIC))
         return q->dtype == VD3D_BF16 ? dispatch_dcn_nhwc<short>(a, s) : (q->dtype == VD3D_F16 ? dispatch_dcn_nhwc<hf16>(a, s) : dispatch_dcn_nhwc<float>(a, s));
     dim3 grid((a.Ho * a.Wo + 63) / 64, (q->O + 63) / 64, q->B);
     if (q->dtype == VD3D_BF16) hipLaunchKernelGGL(dcn_kernel<short>, grid, dim3(256), 0, s, a);
@@ -748,7 +748,7 @@ int launch_dcn_columns(const vd3d_dcn_params* q, void* columns, hipStream_t s) {
     a.mask_sigmoid = q->mask_sigmoid; a.relu = 0;
     if (a.Ho <= 0 || a.Wo <= 0 || q->B <= 0) { vd3d_set_error("deform_columns: empty output"); return VD3D_EINVAL; }
     const int64_t in_span = ((int64_t)(q->B - 1) * a.in_sb + (int64_t)(q->H - 1) * a.in_sy + (int64_t)(q->W - 1) * a.in_sx + q->C) * es;
-    if (in_span < 0x7ffffff0ll && !getenv("VD3D_DCN_COLUMNS_GENERIC")) {
+    if (in_span < 0x7ffffff0ll && !vd3d_switch(VD3D_SW_DCN_COLUMNS_GENERIC)) {
         // wave-per-sample kernel: geometry once per (pixel, tap) instead of once per 16-byte vector
         const int64_t nsamp = (int64_t)q->B * a.Ho * a.Wo * q->kh * q->kw;
         const int64_t nitems = ((nsamp + 63) / 64) * (((int64_t)q->C * es + 1023) / 1024);   // (64 samples, 1 KiB channel step) per wave

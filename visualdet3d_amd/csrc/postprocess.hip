@@ -297,7 +297,7 @@ __global__ void pack_detections_kernel(const float* __restrict__ scores, const f
     const int c = count[b];
     float v = 0.f;
     if (r == k) v = f == 0 ? (float)c : 0.f;
-    else if (r < c) {
+    else if (r < c && r < K) {                                  // K < k is allowed (KM3D decodes K = 100 rows): rows K .. k-1 stay zero
         const int64_t src = (int64_t)b * K + r;
         v = f == 0 ? scores[src] : (f == 12 ? (float)labels[src] : boxes[src * 11 + (f - 1)]);
     }
@@ -307,7 +307,7 @@ __global__ void pack_detections_kernel(const float* __restrict__ scores, const f
 extern "C" int vd3d_pack_detections(const float* scores, const float* boxes, const int32_t* labels, const int32_t* count, int B, int K,
                                     int k, float* pack, void* stream) {
     if (B == 0) return VD3D_OK;
-    if (!scores || !boxes || !labels || !count || !pack || B < 0 || k < 0 || k > K) { vd3d_set_error("pack_detections: bad args"); return VD3D_EINVAL; }
+    if (!scores || !boxes || !labels || !count || !pack || B < 0 || k < 0 || K < 0) { vd3d_set_error("pack_detections: bad args"); return VD3D_EINVAL; }
     const int n = (k + 1) * 13;
     hipLaunchKernelGGL(pack_detections_kernel, dim3((n + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, scores, boxes, labels, count, B, K, k, pack);
     return vd3d_check_launch("pack_detections");

@@ -293,6 +293,7 @@ extern "C" int vd3d_psm_cosine(const void* left, const void* right, void* cost, 
 
 extern "C" int vd3d_costvol_build(const void* left, const void* right, void* vol, int B, int H, int W, int F, int D,
                                   int ips, int dtype, void* stream) {
+    if (dtype != VD3D_BF16 && dtype != VD3D_F32) { vd3d_set_error("costvol_build: dtype must be VD3D_BF16 or VD3D_F32 (no fp16 instantiation)"); return VD3D_EINVAL; }
     const int ve = dtype == VD3D_BF16 ? 8 : 4;
     if (!left || !right || !vol || F % ve || ips % ve) { vd3d_set_error("costvol_build: F and stride must be 16-byte multiples"); return VD3D_EINVAL; }
     const int64_t total = (int64_t)B * D * H * W * (F / ve);
@@ -309,6 +310,7 @@ extern "C" int vd3d_conv3d_3x3x3(const void* in, const float* weight, const floa
                                  int B, int D, int H, int W, int Cin, int Cout, int relu, int out_fd_major,
                                  int ops, int dtype, void* stream) {
     if (!in || !weight || !scale || !shift || !out) { vd3d_set_error("conv3d: null pointer"); return VD3D_EINVAL; }
+    if (dtype != VD3D_BF16 && dtype != VD3D_F32) { vd3d_set_error("conv3d: dtype must be VD3D_BF16 or VD3D_F32 (no fp16 instantiation)"); return VD3D_EINVAL; }
     const int64_t total = (int64_t)B * D * H * W;
     const unsigned grid = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
@@ -316,7 +318,7 @@ extern "C" int vd3d_conv3d_3x3x3(const void* in, const float* weight, const floa
     hipLaunchKernelGGL((conv3d_kernel<T, CI, CO>), dim3(grid), dim3(256), 0, s, (const T*)in, weight, scale, shift, \
                        (T*)out, B, D, H, W, relu, out_fd_major, ops)
     const unsigned mgrid = (unsigned)(((total + 15) / 16 + 3) / 4 < 2048 ? ((total + 15) / 16 + 3) / 4 : 2048);   // 4 waves / block
-    if (dtype == VD3D_BF16 && Cout == 8 && (Cin == 16 || Cin == 8) && ((uintptr_t)in & 15) == 0 && !getenv("VD3D_CONV3D_VALU")) {
+    if (dtype == VD3D_BF16 && Cout == 8 && (Cin == 16 || Cin == 8) && ((uintptr_t)in & 15) == 0 && !vd3d_switch(VD3D_SW_CONV3D_VALU)) {
         if (Cin == 16) hipLaunchKernelGGL(conv3d_mfma_kernel<16>, dim3(mgrid), dim3(256), 0, s, (const short*)in, weight, scale, shift, (short*)out, B, D, H, W, relu, out_fd_major, ops);
         else hipLaunchKernelGGL(conv3d_mfma_kernel<8>, dim3(mgrid), dim3(256), 0, s, (const short*)in, weight, scale, shift, (short*)out, B, D, H, W, relu, out_fd_major, ops);
     }

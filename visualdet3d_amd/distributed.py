@@ -15,11 +15,12 @@ def shard_range(n, rank, world):
 
 def pack_detections(scores, boxes, labels, count, k):
     """padded (scores [B,K], boxes [B,K,11], labels [B,K], count [B]) -> one float tensor [B, k, 13] (rows past a frame's
-    count zeroed: the padding of the device buffers is uninitialised memory) + count [B]."""
+    count zeroed BY SELECTION: the padding of the device buffers is uninitialised memory and may hold NaN / Inf, which a
+    multiply by 0 would keep) + count [B]."""
     k = min(k, scores.shape[1])
     pack = torch.cat([scores[:, :k, None], boxes[:, :k], labels[:, :k, None].to(scores.dtype)], dim=2).contiguous()
     valid = torch.arange(k, device=count.device)[None, :] < count[:, None]
-    return pack * valid[:, :, None].to(pack.dtype), torch.clamp(count, max=k)
+    return pack.masked_fill(~valid[:, :, None], 0), torch.clamp(count, max=k)
 
 
 def gather_detections(pack, count, group=None):
@@ -63,8 +64,9 @@ class DetectionGather:
         self.B, self.k = B, k
         self.pack = torch.zeros((B, k + 1, 13), dtype=torch.float32, device=device)
         self.out = torch.zeros((self.world, B, k + 1, 13), dtype=torch.float32, device=device)
-        backend = dist.get_backend(group) if dist.is_initialized() else 'none'
-        self.tensor_collective = (backend == 'nccl')
+        backend = str(dist.get_backend(group)) if dist.is_initialized() else 'none'
+        # per-device backend strings ('cpu:gloo,cuda:nccl') count as RCCL for device buffers
+        self.tensor_collective = ('nccl' in backend) and torch.device(device).type == 'cuda'
 
     def fill(self, scores, boxes, labels, count):
         """Pack one step's padded results into the send buffer (stream-ordered; no collective).  Device tensors: ONE
@@ -72,15 +74,14 @@ class DetectionGather:
         k, p = self.k, self.pack
         if scores.is_cuda:
             from . import hip_ops
-            assert scores.shape[1] >= k, 'detection capacity %d < gather rows %d' % (scores.shape[1], k)
-            hip_ops.pack_detections(scores, boxes, labels, count, k, out=p)
+            hip_ops.pack_detections(scores, boxes, labels, count, k, out=p)      # K < k allowed: rows K .. k-1 are zero
             return
         kk = min(k, scores.shape[1])
         p[:, :k].zero_()
-        valid = (torch.arange(kk)[None, :] < count[:, None].clamp(min=0)).to(p.dtype)
-        p[:, :kk, 0] = scores[:, :kk] * valid
-        p[:, :kk, 1:12] = boxes[:, :kk] * valid[:, :, None]
-        p[:, :kk, 12] = labels[:, :kk].to(torch.float32) * valid
+        valid = torch.arange(kk)[None, :] < count[:, None].clamp(min=0)          # selection, not a multiply: padding may be NaN
+        p[:, :kk, 0] = scores[:, :kk].masked_fill(~valid, 0)
+        p[:, :kk, 1:12] = boxes[:, :kk].masked_fill(~valid[:, :, None], 0)
+        p[:, :kk, 12] = labels[:, :kk].to(torch.float32).masked_fill(~valid, 0)
         p[:, k, 1:] = 0
         p[:, k, 0] = count.to(torch.float32)                 # negative (overflow marker) survives the round trip
 

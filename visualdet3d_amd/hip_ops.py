@@ -320,8 +320,15 @@ def nchw_f32_to_nhwc(x, dtype, out=None):
 
 
 # --------------------------------------------------------------------------------------------- stereo
+def _bf16_or_f32(t, what):
+    """the stereo-only kernels (PSM cosine volume, concat volume, 3-D convs) are instantiated for bf16 and fp32 only"""
+    if t.dtype not in (torch.bfloat16, torch.float32):
+        raise _lib.Vd3dError('%s: dtype %s not supported (bf16 | fp32 only; there is no fp16 instantiation)' % (what, t.dtype))
+
+
 def psm_cosine(left, right, D, out=None):
     _require_cuda(left, right)
+    _bf16_or_f32(left, 'psm_cosine')
     B, H, W, Cc = left.shape
     assert right.shape == left.shape and left.dtype == right.dtype
     assert _dense_pixels(left) and _dense_pixels(right) and left.stride(2) == right.stride(2)
@@ -335,6 +342,7 @@ def psm_cosine(left, right, D, out=None):
 
 def costvol_build(left, right, D):
     _require_cuda(left, right)
+    _bf16_or_f32(left, 'costvol_build')
     B, H, W, F = left.shape
     assert _dense_pixels(left) and _dense_pixels(right) and left.stride(2) == right.stride(2)
     vol = torch.empty((B, D, H, W, 2 * F), dtype=left.dtype, device=left.device)
@@ -361,6 +369,7 @@ def pack_conv3d(weight, bias, bn):
 def conv3d_3x3x3(vol, pc, relu=True, out_nhwc=None):
     """vol: [B,D,H,W,Cin] channels-last.  out_nhwc given => write NHWC [B,H,W,Cout*D] (channel = f*D + d)."""
     _require_cuda(vol)
+    _bf16_or_f32(vol, 'conv3d_3x3x3')
     B, D, H, W, Cin = vol.shape
     assert Cin == pc.Cin and vol.is_contiguous()
     if out_nhwc is not None:
@@ -410,10 +419,11 @@ def head_postprocess(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, sc
 
 def pack_detections(scores, boxes, labels, count, k, out=None):
     """Padded (scores [B,K], boxes [B,K,11], labels [B,K] i32, count [B] i32) -> one fp32 block [B, k+1, 13] (row k carries the
-    count; rows past the count are zero): vd3d_pack_detections, one launch, capturable in the step's hipGraph."""
+    count; rows past the count -- and, when K < k, rows past K -- are zero): vd3d_pack_detections, one launch, capturable in the
+    step's hipGraph.  K and k are independent (KM3D's decode returns K = 100 rows; the gather record may be wider)."""
     _require_cuda(scores, boxes, labels, count, out)
     B, K = scores.shape
-    k = min(int(k), K)
+    k = int(k)
     assert boxes.shape == (B, K, 11) and labels.shape == (B, K) and count.shape == (B,)
     assert scores.dtype == boxes.dtype == torch.float32 and labels.dtype == count.dtype == torch.int32
     assert scores.is_contiguous() and boxes.is_contiguous() and labels.is_contiguous() and count.is_contiguous()

@@ -196,12 +196,20 @@ class ModulatedDeformConvPack(ModulatedDeformConv):
 
     def forward(self, x):
         """Reference contract: NCHW fp32 in, NCHW fp32 out (deform_conv.py:459-466)."""
-        out = _offset_conv_nchw(self, x)
-        o1, o2, mask = torch.chunk(out, 3, dim=1)
-        offset = torch.cat((o1, o2), dim=1)
-        mask = torch.sigmoid(mask)
-        return modulated_deform_conv(x, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                                     self.groups, self.deformable_groups)
+        if not x.is_cuda:
+            raise NotImplementedError
+        logits = _offset_conv_nchw(self, x)              # [B, 3K, Ho, Wo] fp32 = (o1 | o2 | mask logits)
+        # the reference's chunk(3) + cat(o1, o2) + sigmoid(mask) (deform_conv.py:461-464) without any torch arithmetic: (o1 | o2)
+        # IS the first 2K channels, and the kernel applies the sigmoid to the mask logits it reads (mask_sigmoid = 1)
+        K = self.kernel_size[0] * self.kernel_size[1]
+        G = self.deformable_groups
+        x = x.float().contiguous()
+        pd = self._cache.get(('w', torch.float32), [self.weight], lambda: ops.pack_dcn_weight(self.weight, torch.float32))
+        out = torch.empty((x.shape[0], self.out_channels) + tuple(logits.shape[2:]), dtype=torch.float32, device=x.device)
+        bias = self.bias.detach().float() if self.bias is not None else None
+        return ops.deform_conv_general(x, pd, logits[:, :2 * K * G], logits[:, 2 * K * G:3 * K * G], out, 'nchw', bias=bias,
+                                       stride=_pair(self.stride), padding=_pair(self.padding), dilation=_pair(self.dilation),
+                                       groups=self.groups, deformable_groups=G, mask_sigmoid=True)
 
     def forward_nhwc(self, x, bn=None, relu=False, out=None):
         """Engine path on NHWC activations (bf16 | fp32): offset logits (fp32) -> fused sample + sigmoid(mask) + MFMA +
