@@ -38,9 +38,17 @@ def fp16_round(x):
 class Ctx:
     """state_dict + rounding policy."""
 
-    def __init__(self, sd, rnd=identity):
+    def __init__(self, sd, rnd=identity, stage_taps=None):
         self.sd = {k: v.detach().cpu().float() if torch.is_floating_point(v) else v.detach().cpu() for k, v in sd.items()}
         self.rnd = rnd
+        # optional list receiving one record per fused operation of the path (kind, state_dict key, input / output tensors, the
+        # op's parameters): what tests/test_stage_taps_gpu.py feeds, op by op, to the HIP kernels (teacher forcing: every HIP stage
+        # sees the ORACLE's input, so a 1-ulp flip cannot cascade and each stage can be held to ulps)
+        self.stage_taps = stage_taps
+
+    def tap(self, kind, key, **kw):
+        if self.stage_taps is not None:
+            self.stage_taps.append(dict(kind=kind, key=key, **kw))
 
     def w(self, key):
         """conv weight, rounded like the packed HIP weights are."""
@@ -80,7 +88,10 @@ def conv_bn_act(c, x, conv, bn=None, relu=True, stride=1, padding=1, dilation=1,
         y = y + residual
     if relu:
         y = F.relu(y)
-    return c.rnd(y) if out_round else y
+    y = c.rnd(y) if out_round else y
+    c.tap('dwconv' if groups > 1 else 'conv', conv, bn=bn, x=x, residual=residual, y=y, relu=relu, stride=stride, padding=padding,
+          dilation=dilation, out_round=out_round)
+    return y
 
 
 # ------------------------------------------------------------------------------------------- backbone
@@ -111,10 +122,14 @@ def resnet(c, p, x, depth=34, num_stages=3, out_indices=(0, 1, 2), strides=(1, 2
     """backbones/resnet.py:184-198 (+ _make_layer :133-152: first block ignores dilation)."""
     block, layers = _LAYERS[depth]
     outs = []
+    img = x
+    taps, c.stage_taps = c.stage_taps, None          # the stem is tapped as ONE fused stage (conv + BN + ReLU + max pool), below
     x = conv_bn_act(c, c.rnd(x), p + '.conv1', p + '.bn1', True, stride=2, padding=3)
+    c.stage_taps = taps
     if -1 in out_indices:
         outs.append(x)
     x = F.max_pool2d(x, 3, 2, 1)
+    c.tap('stem', p, x=img, y=x)
     for i in range(num_stages):
         for j in range(layers[i]):
             bp = '%s.layer%d.%d' % (p, i + 1, j)
@@ -135,7 +150,9 @@ def psm_cosine(c, left, right, max_disp, downsample):
             cost[:, d, :, d:] = (left[:, :, :, d:] * right[:, :, :, :-d]).mean(dim=1)
         else:
             cost[:, d] = (left * right).mean(dim=1)
-    return c.rnd(cost)
+    cost = c.rnd(cost)
+    c.tap('psm_cosine', 'D%d' % D, left=left, right=right, y=cost)
+    return cost
 
 
 def cost_volume(c, p, left, right, max_disp=192, downsample=16):
@@ -153,12 +170,16 @@ def cost_volume(c, p, left, right, max_disp=192, downsample=16):
             vol[:, :Fc, d] = lf
             vol[:, Fc:, d] = rf
     x = vol
+    c.tap('costvol_build', p, left=lf, right=rf, y=vol)
     for i in (0, 3):
         w = c.w('%s.conv3d.%d.weight' % (p, i))
         y = F.conv3d(x, w, None, padding=1)
         s, t = c.bn('%s.conv3d.%d' % (p, i + 1))
         t = c.sd['%s.conv3d.%d.bias' % (p, i)] * s + t
-        x = c.rnd(F.relu(_affine(y, s, t)))
+        y = c.rnd(F.relu(_affine(y, s, t)))
+        c.tap('conv3d', '%s.conv3d.%d' % (p, i), x=x, y=y, last=(i == 3))
+        x = y
+    c.tap('cost_volume', p, left=lf, right=rf, y=x.reshape(B, -1, H, W))      # the three launches as one stage
     return x.reshape(B, -1, H, W)
 
 
@@ -171,12 +192,17 @@ def res_ghost(c, p, x):
 
 def cost_volume_pyramid(c, p, v4, v8, v16):
     """detectors/yolostereo3d_core.py:63-71 (eval branch)."""
+    def pool(x, key):
+        y = c.rnd(F.avg_pool2d(x, 2))
+        c.tap('avgpool', key, x=x, y=y)
+        return y
+
     x = res_ghost(c, p + '.four_to_eight.0', v4)
-    x = c.rnd(F.avg_pool2d(x, 2))
+    x = pool(x, p + '.four_to_eight.1')
     x = basic_block(c, p + '.four_to_eight.2', x)
     x = torch.cat([x, v8], dim=1)
     x = res_ghost(c, p + '.eight_to_sixteen.0', x)
-    x = c.rnd(F.avg_pool2d(x, 2))
+    x = pool(x, p + '.eight_to_sixteen.1')
     x = basic_block(c, p + '.eight_to_sixteen.2', x)
     x = torch.cat([x, v16], dim=1)
     x = res_ghost(c, p + '.depth_reason.0', x)
@@ -663,10 +689,11 @@ def load_priors(preprocessed_path, obj_types):
     return mean, std
 
 
-def stereo3d_forward(sd, cfg, left, right, P2, rnd=identity, return_stages=False):
+def stereo3d_forward(sd, cfg, left, right, P2, rnd=identity, return_stages=False, stage_taps=None):
     """Stereo3D.test_forward (detectors/yolostereo3d_detector.py:77-96) generalised to B >= 1: per-sample
-    post-processing identical to the reference's batch-1 path.  Returns a list of (scores, boxes, labels)."""
-    c = Ctx(sd, rnd)
+    post-processing identical to the reference's batch-1 path.  Returns a list of (scores, boxes, labels).
+    ``stage_taps``: optional list that receives one record per fused operation (see ``Ctx``)."""
+    c = Ctx(sd, rnd, stage_taps)
     depth = cfg.backbone.depth
     feats, stages = stereo_core(c, left.float(), right.float(), depth)
     ncls = len(cfg.obj_types)

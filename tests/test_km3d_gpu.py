@@ -194,32 +194,76 @@ def test_fused_head_matches_unfused():
             assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 2e-3, (k, shape, dt)
 
 
-def test_bf16_dcn_blocks_teacher_forced_vs_bf16_oracle():
-    """Stage-tapped parity of the 16 DCNv2 + BN + ReLU blocks of DLA-Up in bf16: every block is fed the ORACLE's (bf16-rounded)
-    input and compared with the oracle's output of that block, so a 1-ulp flip in one layer cannot cascade through the
-    sampling positions of the next 15 (that cascade is what forces the loose bound of the end-to-end bf16 comparison above).
-    Offsets are recomputed by the HIP block's own offset conv from the same input."""
-    g = load_golden('km3d_dla34_96x320')
-    cfg, (img, P2), winit = km3d_case_from_golden(g)
-    m, sd = _model(cfg, winit, torch.bfloat16)
-    taps = {}
-    with torch.no_grad():
-        orc.km3d_forward(sd, cfg, img, P2, rnd=orc.bf16_round, taps=taps)
+def _teacher_forced_dcn_blocks(m, taps, dtype):
+    """Every DCNv2 + BN + ReLU block of DLA-Up fed the ORACLE's (rounded) input and compared with the oracle's output of that
+    block -> worst error in units of (2 ulp of the format + 5e-4 of the block's output scale).  Offsets are recomputed by the HIP
+    block's own offset conv from the same input."""
     assert len(taps) == 16
     mods = dict(m.named_modules())
-    worst = 0.0
+    two_ulp = 2.0 ** (-6 if dtype == torch.bfloat16 else -9)
+    worst, lines = 0.0, []
     for name, (x, want) in taps.items():
         blk = mods[name]
-        got = blk.forward_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda().to(torch.bfloat16))
+        got = blk.forward_nhwc(x.permute(0, 2, 3, 1).contiguous().cuda().to(dtype))
         got = got.float().cpu().permute(0, 3, 1, 2)
         sc = want.abs().max().item()
         d = (got - want).abs()
-        # within 2 bf16 ulp of the oracle, plus the effect of fp32-summation-order differences in the OFFSETS (1e-6 px) and in
-        # the 9 * C-long dot product (measured worst over the 16 blocks: 2 ulp + 2.5e-4 of the output scale)
-        ulp = (d / (want.abs() * 2.0 ** -6 + 5e-4 * sc)).max().item()
+        # within 2 ulp of the oracle, plus the effect of fp32-summation-order differences in the OFFSETS (1e-6 px) and in the
+        # 9 * C-long dot product (measured worst over the 16 blocks in bf16: 2 ulp + 2.5e-4 of the output scale)
+        ulp = (d / (want.abs() * two_ulp + 5e-4 * sc)).max().item()
         worst = max(worst, ulp)
-        assert ulp <= 1.0, '%s: %.2f (x 2 bf16 ulp), rel %.2e' % (name, ulp, d.max().item() / sc)
-    print('\n[KM3D bf16 teacher-forced DCN blocks] worst %.2f x (2 bf16 ulp + 5e-4 scale)' % worst)
+        lines.append('%s %s: %.2f (x 2 ulp + 5e-4 scale), rel %.2e' % (name, tuple(want.shape), ulp, d.max().item() / sc))
+    return worst, lines
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_dcn_blocks_teacher_forced_vs_rounded_oracle(dtype):
+    """Stage-tapped parity of the 16 DCNv2 + BN + ReLU blocks of DLA-Up in bf16 and in fp16 (BASELINE config 5's type): a 1-ulp
+    flip in one layer cannot cascade through the sampling positions of the next 15 (that cascade is what forces the loose bound
+    of the end-to-end 16-bit comparisons)."""
+    g = load_golden('km3d_dla34_96x320')
+    cfg, (img, P2), winit = km3d_case_from_golden(g)
+    m, sd = _model(cfg, winit, dtype)
+    taps = {}
+    with torch.no_grad():
+        orc.km3d_forward(sd, cfg, img, P2, rnd=orc.bf16_round if dtype == torch.bfloat16 else orc.fp16_round, taps=taps)
+        worst, lines = _teacher_forced_dcn_blocks(m, taps, dtype)
+    print('\n[KM3D %s teacher-forced DCN blocks] worst %.2f x (2 ulp + 5e-4 scale)' % (dtype, worst))
+    assert worst <= 1.0, '\n'.join(lines)
+
+
+def test_fp16_mode_config5_at_size_512x1760():
+    """BASELINE config 5 IN ITS OWN ARITHMETIC TYPE AT ITS OWN SIZE: KM3D DLA-34, 512 x 1760, fp16 (one frame; the reference's DCN
+    dispatches half: deform_conv_cuda_kernel.cu:769-799 AT_DISPATCH_FLOATING_TYPES_AND_HALF).
+      (a) the 16 DCNv2 blocks TEACHER-FORCED in fp16 at size (inputs 64 x 128 x 440 ... 512 x 16 x 55): 2 fp16 ulp + 5e-4 scale;
+      (b) end to end: the nine head maps vs the oracle with fp16 rounding points and vs the committed outputs of the reference
+          itself (tests/golden/km3d_dla34_512x1760.npz, fp32), detections matched one to one."""
+    g = load_golden('km3d_dla34_512x1760')
+    cfg, (img, P2), winit = km3d_case_from_golden(g)
+    assert tuple(img.shape[2:]) == (512, 1760)
+    m, sd = _model(cfg, winit, torch.float16)
+    taps = {}
+    with torch.no_grad():
+        dets, st = orc.km3d_forward(sd, cfg, img, P2, rnd=orc.fp16_round, return_stages=True, taps=taps)
+        worst, lines = _teacher_forced_dcn_blocks(m, taps, torch.float16)
+    print('\n[KM3D fp16 512x1760 teacher-forced DCN blocks] worst %.2f x (2 fp16 ulp + 5e-4 scale)' % worst)
+    assert worst <= 1.0, '\n'.join(lines)
+    outs = m.test_forward_batched(img.cuda(), P2.cuda())
+    maps = m._last_raw
+    worst_o = worst_g = 0.0
+    for h in orc.KM3D_HEADS:
+        got = maps[h].permute(0, 3, 1, 2).contiguous().cpu()
+        eo, eg = rel_err(got, st[h]), rel_err(subsample(got[0:1]), g['f0_%s_sub' % h])
+        print('[KM3D fp16 512x1760] %-9s vs fp16-rounded oracle %.2e, vs fp32 reference golden %.2e' % (h, eo, eg))
+        worst_o, worst_g = max(worst_o, eo), max(worst_g, eg)
+    assert worst_o < 3e-2 and worst_g < 3e-2
+    s, b, l = [t.cpu() for t in outs[0]]
+    ref = (g['f0_scores'], g['f0_boxes'], g['f0_labels'])
+    frac_g = matched_fraction((s, b, l), ref, rtol=3e-2)
+    frac_o = matched_fraction((s, b, l), dets[0], rtol=3e-2)
+    print('[KM3D fp16 512x1760] %d detections (reference %d, fp16 oracle %d): %.0f %% / %.0f %% matched one-to-one within 3e-2'
+          % (len(s), len(ref[0]), len(dets[0][0]), 100 * frac_g, 100 * frac_o))
+    assert abs(len(s) - len(ref[0])) <= 5 and frac_g >= 0.9 and frac_o >= 0.9
 
 
 def test_fp16_mode_config5_vs_fp16_oracle_and_reference_golden():

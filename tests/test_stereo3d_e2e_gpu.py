@@ -135,17 +135,18 @@ def test_config2_batch8_bf16_detection_level_acceptance():
         per layer, by tests/test_conv_tiles_gpu.py (every bench tile within one bf16 ulp of the oracle on identical inputs);
     (c) detection set: detections are matched BY ANCHOR INDEX; every oracle detection whose score clears the threshold by
         more than the observed score difference is found by the HIP path (and vice versa) unless an NMS decision involving
-        it was marginal; matched boxes agree within the observed logit difference pushed through the decode."""
-    m, sd, cfg = _bench_model_c2(torch.bfloat16)
-    B, H, W = 8, 384, 1280
-    L, R = syn.stereo_pair(B, H, W, seed=100)
-    P2, P3 = syn.kitti_calib(W, batch=B)
-    scores, boxes, labels, aidx, count = [t.cpu() for t in m.forward_device(L.cuda(), R.cuda(), P2.cuda())]
+        it was marginal; matched boxes agree within the observed logit difference pushed through the decode.
+
+    This workload (bench.py's seeded random head) has NO margin: its candidates score within the bf16 noise of each other.  The
+    per-stage statement of correctness in this dtype is tests/test_stage_taps_gpu.py (every stage teacher-forced, <= 2 ulp); the
+    LITERAL detection-set bar of SURVEY.md 7.3-2 is asserted on the margin-controlled workload of
+    tests/test_margin_workload_gpu.py."""
+    from tests.conftest import c2_bf16_case
+    case = c2_bf16_case()          # model + ONE run of the bf16-rounded oracle, shared with tests/test_stage_taps_gpu.py / test_margin_workload_gpu.py
+    m, B, H, W, ref, st = case['model'], case['B'], case['H'], case['W'], case['ref'], case['stages']
+    scores, boxes, labels, aidx, count = [t.cpu() for t in m.forward_device(case['L'].cuda(), case['R'].cuda(), case['P2'].cuda())]
     cls, reg = [t.float().cpu() for t in m._last_raw]
     assert int(count.min()) >= 0
-    torch.set_num_threads(min(64, torch.get_num_threads()))
-    with torch.no_grad():
-        ref, st = orc.stereo3d_forward(sd, cfg, L, R, P2, rnd=orc.bf16_round, return_stages=True)
     thr, iou_thr = 0.75, 0.4
     # (a) exact post-processing on identical logits
     n_det = 0
