@@ -11,6 +11,7 @@ stem -> ResNet-34 (L and R stacked) -> cost volumes -> ghost pyramid -> head tow
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -26,6 +27,7 @@ if REPO not in sys.path:
 GFLOP_PER_PAIR = 473.82          # conv/GEMM 2*MAC per 384x1280 pair (Stereo3D R34)
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
+C_float3 = ctypes.c_float * 3
 
 
 def parse():
@@ -46,6 +48,13 @@ def parse():
                     help='no GPU work: time the CPU baseline(s) on this host and print them (used in the build container, where '
                          'the reference tree exists, to calibrate the "port" against the reference itself)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--feed', default='resident', choices=['resident', 'host'],
+                    help="resident (default, the headline): synthetic network inputs already in HBM.  host: every step uploads 2 x batch "
+                         "uint8 KITTI-sized frames (375 x 1242 x 3) from pinned host memory into a double-buffered device ring on a "
+                         "copy stream and runs vd3d_preprocess_image (crop / resize / normalise) inside the captured step -- the "
+                         "PCIe-inclusive rate, the one thing that differs between 1 and 8 ranks of a node")
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the extra timed runs of BASELINE configs 3 and 5 (attached to the line as other_configs at N = 1)')
     return ap.parse_args()
 
 
@@ -63,64 +72,108 @@ def build_model(args, device):
     return model, cfg, sd
 
 
-def profile_convs(model, inputs, reps=3):
-    """Per-launch HIP-event timing of the dominant kernel family (conv_igemm) on the launch stream.
-    Returns (total_flops_per_step, total_seconds_per_step, n_launches)."""
+def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
+    """Per-launch HIP-event timing of the MFMA kernel families on the launch stream, side streams off (durations must not
+    overlap): every launch through hip_ops.conv2d (the implicit-GEMM family), deform_conv_general (fused DCN), deform_columns
+    (DCN sampling half) and km3d_head_fused.  Returns a dict: conv family (flops, seconds, launches, algorithmic bytes, dominant
+    layer shape) + per-family totals of the other entries."""
     from visualdet3d_amd import hip_ops as ops
-    records = []
-    orig = ops.conv2d
+    records = []     # (family, flops, start, end, bytes, label)
 
-    def timed(x, pc, out=None, residual=None, relu=False, out_f32=False):
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    orig = dict(conv2d=ops.conv2d, dcn=ops.deform_conv_general, cols=ops.deform_columns, head=ops.km3d_head_fused)
+
+    def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
+        s, e = ev(), ev()
         s.record()
-        o = orig(x, pc, out=out, residual=residual, relu=relu, out_f32=out_f32)
+        o = orig['conv2d'](x, pc, out=out, residual=residual, relu=relu, out_f32=out_f32)
         e.record()
         B, Ho, Wo, Co = o.shape
         nbytes = (x.shape[0] * x.shape[1] * x.shape[2] * pc.Cin * x.element_size() + pc.Cout * pc.kh * pc.kw * pc.Cin * x.element_size()
                   + o.numel() * o.element_size() + (residual.numel() * residual.element_size() if residual is not None else 0))
-        records.append((2.0 * B * Ho * Wo * Co * pc.kh * pc.kw * pc.Cin, s, e, nbytes,
+        records.append(('conv', 2.0 * B * Ho * Wo * Co * pc.kh * pc.kw * pc.Cin, s, e, nbytes,
                         '%dx%d s%d %4d->%4d @ %dx%dx%d' % (pc.kh, pc.kw, pc.stride, pc.Cin, pc.Cout, B, Ho, Wo)))
         return o
 
-    ops.conv2d = timed
-    overlap = model.bbox_head.overlap_towers
-    overlap_neck = model.core.overlap_neck
-    model.bbox_head.overlap_towers = False     # serial launches: per-kernel event times must not overlap
-    model.core.overlap_neck = False
+    def dcn(x, pd, offset, mask, out, layout, **kw):
+        s, e = ev(), ev()
+        s.record()
+        o = orig['dcn'](x, pd, offset, mask, out, layout, **kw)
+        e.record()
+        if layout == 'nhwc':
+            B, Ho, Wo, Co = o.shape
+        else:
+            B, Co, Ho, Wo = o.shape
+        records.append(('dcn', 2.0 * B * Ho * Wo * Co * pd.kh * pd.kw * pd.Cg, s, e, 0,
+                        'dcn %dx%d %4d->%4d @ %dx%dx%d' % (pd.kh, pd.kw, pd.Cg, Co, B, Ho, Wo)))
+        return o
+
+    def cols(x, *a, **kw):
+        s, e = ev(), ev()
+        s.record()
+        o = orig['cols'](x, *a, **kw)
+        e.record()
+        records.append(('dcn_columns', 0.0, s, e, x.numel() * x.element_size() + o.numel() * o.element_size(), 'dcn columns %s' % (tuple(o.shape),)))
+        return o
+
+    def head(x, pc_first, w2_packed, b2, n_out):
+        s, e = ev(), ev()
+        s.record()
+        o = orig['head'](x, pc_first, w2_packed, b2, n_out)
+        e.record()
+        B, H, W, _ = x.shape
+        fl = 2.0 * B * H * W * (pc_first.Cout * 9 * pc_first.Cin + 256 * sum(int(n) for n in n_out))
+        records.append(('km3d_head_fused', fl, s, e, 0, 'fused head %d->%d x %d @ %dx%dx%d' % (pc_first.Cin, 256, len(n_out), B, H, W)))
+        return o
+
+    ops.conv2d, ops.deform_conv_general, ops.deform_columns, ops.km3d_head_fused = conv2d, dcn, cols, head
+    switches = []
+    for mod, attr in ((getattr(model, 'bbox_head', None), 'overlap_towers'), (getattr(model, 'core', None), 'overlap_neck')):
+        if mod is not None and hasattr(mod, attr):
+            switches.append((mod, attr, getattr(mod, attr)))
+            setattr(mod, attr, False)           # serial launches: per-kernel event times must not overlap
     try:
         with torch.no_grad():
             for _ in range(reps):
                 model.forward_device(*inputs)
         torch.cuda.synchronize()
     finally:
-        ops.conv2d = orig
-        model.bbox_head.overlap_towers = overlap
-        model.core.overlap_neck = overlap_neck
+        ops.conv2d, ops.deform_conv_general, ops.deform_columns, ops.km3d_head_fused = orig['conv2d'], orig['dcn'], orig['cols'], orig['head']
+        for mod, attr, v in switches:
+            setattr(mod, attr, v)
     # No event-overhead correction: per-launch HIP events were compared with the kernel durations of a rocprofv3 --kernel-trace
     # of this very command (`bench.py --no-overlap`, tools/profile_round.sh -> profiles/*_serial_roofline_check.txt): the raw
-    # event sums agree with the profiler within ~1 % (an empty event pair reads 5-6 us, but around a kernel that cost is not
-    # inside the reading: subtracting it made the bench read 3.5-8 % short of the profiler).
-    ovh_ms = 0.0
-    if os.environ.get('VD3D_BENCH_LAYERS'):
-        per = len(records) // reps
+    # event sums read the family 0.1-4 % LONGER than the profiler (an empty event pair reads 5-6 us, of which 0-3 us end up inside
+    # a reading; subtracting a calibrated overhead over-corrected by 3.5-8 %), so the line stays on the conservative side.
+    per = len(records) // reps
+    if os.environ.get(verbose_env):
         for i in range(per):
-            fl = records[i][0]
-            t = sum(records[i + r * per][1].elapsed_time(records[i + r * per][2]) - ovh_ms for r in range(reps)) / reps
-            print('  conv %2d  %-32s %8.2f GF  %8.1f us  %7.1f TF/s' % (i, records[i][4], fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
-    flops = sum(r[0] for r in records) / reps
-    secs = sum(max(r[1].elapsed_time(r[2]) - ovh_ms, 0.0) for r in records) * 1e-3 / reps
-    # the single most expensive layer shape of the family (its launches all run the same kernel): reported next to the family figure
+            fl = records[i][1]
+            t = sum(records[i + r * per][2].elapsed_time(records[i + r * per][3]) for r in range(reps)) / reps
+            print('  %-16s %2d  %-40s %8.2f GF  %8.1f us  %7.1f TF/s' % (records[i][0], i, records[i][5], fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
+    fam = {}
+    for r in records:
+        d = fam.setdefault(r[0], dict(flops=0.0, secs=0.0, launches=0, bytes=0.0))
+        d['flops'] += r[1] / reps
+        d['secs'] += max(r[2].elapsed_time(r[3]), 0.0) * 1e-3 / reps
+        d['launches'] += 1.0 / reps
+        d['bytes'] += r[4] / reps
+    # the single most expensive layer shape over all families (its launches all run the same kernel)
     by_shape = {}
     for r in records:
-        d = by_shape.setdefault(r[4], [0.0, 0.0, 0])
-        d[0] += r[0]
-        d[1] += max(r[1].elapsed_time(r[2]) - ovh_ms, 0.0) * 1e-3
+        d = by_shape.setdefault((r[0], r[5]), [0.0, 0.0, 0])
+        d[0] += r[1]
+        d[1] += max(r[2].elapsed_time(r[3]), 0.0) * 1e-3
         d[2] += 1
-    name, (fl, tt, n) = max(by_shape.items(), key=lambda kv: kv[1][1])
-    dominant = dict(layer=name, launches_per_step=n // reps, share_of_family_time=round(tt / (secs * reps), 4),
-                    avg_launch_us=round(tt / n * 1e6, 1), achieved=round(fl / tt / 1e12, 1))
-    return flops, secs, len(records) // reps, sum(r[3] for r in records) / reps, ovh_ms * 1e3, dominant
+    total_secs = sum(d['secs'] for d in fam.values())
+    dominant = {}
+    for family in fam:
+        (f_, name), (fl, tt, n) = max(((k, v) for k, v in by_shape.items() if k[0] == family), key=lambda kv: kv[1][1])
+        dominant[family] = dict(layer=name, launches_per_step=n // reps, share_of_family_time=round(tt / (fam[family]['secs'] * reps), 4),
+                                avg_launch_us=round(tt / n * 1e6, 1), achieved=round(fl / tt / 1e12, 1) if tt > 0 else 0.0)
+    return fam, dominant, total_secs
 
 
 def _cpu_model():
@@ -170,6 +223,203 @@ def cpu_baseline(cfg, sd, args):
                 sample='%d fp32 batch-1 %dx%d stereo pairs through %s in %.1f s' % (n, args.height, args.width, what, el))
 
 
+KDET = 128                                   # detections per frame that travel (device -> host, rank -> ranks)
+
+# BASELINE.json configs 3 and 5 AS STATED, timed after the headline with the same rules (inputs resident in HBM, hipGraph replay,
+# results packed + copied to the host + checked inside the timed region).  gf = conv / GEMM / DCN 2*MAC per unit.
+OTHER_CONFIGS = [
+    dict(key='C3', workload='YOLOStereo3D ResNet-50 + DCNv2 (base) head, 288x1280 stereo pairs, batch=32', kind='stereo', depth=50,
+         H=288, W=1280, B=32, gf=472.0, dcn_head=True, dtype='bf16', wseed=6, head_std=0.006, score_thr=0.5),   # weights / threshold of the golden case stereo3d_r50_dcn_288x1280
+
+    dict(key='C5', workload='KM3D_example (DLA-34 CenterNet mono3D, keypoint head), 512x1760 images, batch=16', kind='km3d',
+         H=512, W=1760, B=16, gf=326.18, dtype='fp16'),
+]
+
+
+def pin_to_gpu_numa_node(local_rank):
+    """Bind this rank's host threads to the CPUs of the NUMA node its GPU hangs off (pinned-memory copies and the launch thread stay
+    local; matters for --feed host at 8 ranks).  Best effort: returns a description, never raises."""
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        bdf = '%04x:%02x:%02x.0' % (getattr(props, 'pci_domain_id', 0), props.pci_bus_id, props.pci_device_id)
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read().strip())
+        if node < 0:
+            return 'gpu %s: no NUMA node reported' % bdf
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return 'gpu %s -> NUMA node %d (%d cpus)' % (bdf, node, len(cpus))
+    except Exception as e:      # noqa: BLE001  (sysfs layout / permissions differ between hosts)
+        return 'not pinned (%s)' % e
+
+
+class Stepper:
+    """One configuration's timed step: warm-up, optional side-stream pass, hipGraph capture of `forward_device + pack`, then per
+    step: replay, copy the packed [B, KDET + 1, 13] record to pinned host memory, ONE host sync, check the counts."""
+
+    def __init__(self, model, inputs, B, device, use_graph=True, pre=None):
+        from visualdet3d_amd import hip_ops
+        self.model, self.inputs, self.B, self.pre = model, inputs, B, pre
+        self.pack_static = torch.zeros((B, KDET + 1, 13), dtype=torch.float32, device=device)
+        self.pinned = torch.empty((1, B, KDET + 1, 13), dtype=torch.float32).pin_memory()
+        self.graph = None
+
+        def step_device():
+            """One step on the device: (host feed: preprocessing of the uploaded frames,) the whole forward incl. decode + NMS,
+            then ONE launch that packs the padded results (scores, boxes, labels, per-frame count) into the record."""
+            if self.pre is not None:
+                self.pre()
+            out = model.forward_device(*inputs)
+            hip_ops.pack_detections(out[0], out[1], out[2], out[-1], KDET, out=self.pack_static)
+            return out
+
+        self.step_device = step_device
+        with torch.no_grad():
+            for _ in range(2):                       # packs weights, builds anchor tables, warms the allocator
+                self.static_out = step_device()
+            torch.cuda.synchronize()
+            if use_graph:
+                if not os.environ.get('VD3D_BENCH_NOSIDE'):
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        step_device()
+                    torch.cuda.current_stream().wait_stream(side)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.static_out = step_device()
+
+    def forward_step(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.static_out
+        with torch.no_grad():
+            return self.step_device()
+
+    @staticmethod
+    def check(host_block):
+        """host_block [ranks, B, KDET + 1, 13] (pinned): per-frame counts ride in row KDET."""
+        c = host_block[:, :, KDET, 0]
+        assert float(c.min()) >= 0, 'candidate overflow in the head post-processing'
+        return c.clone()
+
+    def run(self, n, before_step=None):
+        counts = None
+        for i in range(n):
+            if before_step is not None:
+                before_step(i)
+            self.forward_step()
+            self.pinned[0].copy_(self.pack_static, non_blocking=True)      # device -> host copy of the step's results
+            torch.cuda.current_stream().synchronize()                       # the one host sync per step
+            counts = self.check(self.pinned)
+        return counts
+
+    def timed(self, steps, warmup):
+        self.run(warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        counts = self.run(steps)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, counts
+
+
+class HostFeed:
+    """--feed host: 2 x B uint8 KITTI-sized frames per step travel from pinned host memory into a double-buffered device ring on a
+    copy stream; the step itself (captured in the hipGraph) starts with vd3d_preprocess_image on a STATIC device frame buffer
+    (crop / cv2-style resize / pad / normalise -> the fp32 NCHW network input), which the main stream refreshes from ring slot
+    (i & 1) right before the replay.  Upload i + 1 overlaps step i."""
+    HS, WS = 375, 1242          # KITTI frame
+
+    def __init__(self, B, H, W, device, L, R, seed=0):
+        from visualdet3d_amd import hip_ops
+        g = torch.Generator().manual_seed(seed)
+        self.host = [torch.randint(0, 256, (2 * B, self.HS, self.WS, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+        self.ring = [torch.empty((2 * B, self.HS, self.WS, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.frames = torch.empty((2 * B, self.HS, self.WS, 3), dtype=torch.uint8, device=device)       # the graph's static source
+        self.copy_stream = torch.cuda.Stream()
+        self.uploaded = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [torch.cuda.Event() for _ in range(2)]
+        self.B, self.size, self.L, self.R = B, (H, W), L, R
+        self.mean, self.std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+        self.bytes_per_step = self.host[0].numel()
+        self.hip_ops = hip_ops
+        self.frames.copy_(self.host[0])
+
+    preprocess = None               # set by main(): the 2 x B vd3d_preprocess_image launches that open the captured step
+
+    def upload(self, i):
+        """enqueue the H2D copy of step i's frames into ring slot (i & 1) on the copy stream"""
+        s = i & 1
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.consumed[s])          # slot free: the step that used it has copied it out
+            self.ring[s].copy_(self.host[s], non_blocking=True)
+            self.uploaded[s].record(self.copy_stream)
+
+    def before_step(self, i):
+        """main stream, right before step i's replay: wait for step i's frames, refresh the graph's static source from ring slot
+        (i & 1), then start step i + 1's upload so that it travels while step i computes."""
+        main = torch.cuda.current_stream()
+        s = i & 1
+        if i == 0:
+            self.upload(0)                                          # first step of a run: nothing was prefetched for it
+        main.wait_event(self.uploaded[s])
+        self.frames.copy_(self.ring[s], non_blocking=True)          # D2D, 22 MB at HBM speed
+        self.consumed[s].record(main)
+        self.upload(i + 1)
+
+
+def time_other_config(c, device, steps, warmup):
+    """-> the `other_configs` entry of one BASELINE configuration, or {'error': ...}."""
+    from visualdet3d_amd.networks.utils.registry import DETECTOR_DICT
+    import visualdet3d_amd.networks.detectors  # noqa: F401
+    from visualdet3d_amd.utils import synthetic as syn
+    tmp = tempfile.mkdtemp()
+    if c['kind'] == 'stereo':
+        cfg = syn.stereo3d_cfg(tmp, depth=c['depth'], score_thr=c.get('score_thr', 0.75), nms_iou_thr=0.4)
+        syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+        if c.get('dcn_head'):
+            from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3DBaseHead
+            m = Stereo3DBaseHead(cfg)
+        else:
+            m = DETECTOR_DICT[cfg.name](cfg)
+    else:
+        cfg = syn.km3d_cfg(output_w=c['W'] // 4)
+        m = DETECTOR_DICT[cfg.name](cfg)
+    m.load_state_dict(syn.seeded_state_dict(m.state_dict(), seed=c.get('wseed', 1), head_std=c.get('head_std', 0.0005)))
+    m = m.to(device).eval()
+    m.compute_dtype = torch.float16 if c['dtype'] == 'fp16' else torch.bfloat16
+    B, H, W = c['B'], c['H'], c['W']
+    P2, _ = syn.kitti_calib(W, batch=B)
+    if c['kind'] == 'stereo':
+        L, R = syn.stereo_pair(B, H, W, seed=3)
+        inputs = (L.to(device), R.to(device), P2.to(device))
+    else:
+        inputs = (syn.mono_image(B, H, W, seed=3).to(device), P2.to(device))
+    st = Stepper(m, inputs, B, device)
+    elapsed, counts = st.timed(steps, warmup)
+    fam, dominant, _ = profile_ops(m, inputs, reps=2, verbose_env='VD3D_BENCH_LAYERS_OTHER')
+    value = B * steps / elapsed
+    # the single (family, layer shape) that costs the step most
+    dom_family = max(dominant, key=lambda k: dominant[k]['avg_launch_us'] * dominant[k]['launches_per_step'])
+    entry = dict(config=c['key'], workload=c['workload'], dtype=c['dtype'], steps=steps, warmup=warmup,
+                 ms_per_step=round(elapsed / steps * 1e3, 3), value=round(value, 2), unit='img/s',
+                 whole_path_frac=round(value * c['gf'] / 1e3 / PEAK_BF16_TFLOPS, 4), gflop_per_unit=c['gf'],
+                 detections_last_step=int(counts.sum()),
+                 families={k: dict(launches=int(round(v['launches'])), ms=round(v['secs'] * 1e3, 3),
+                                   achieved_tflops=round(v['flops'] / v['secs'] / 1e12, 1) if v['flops'] else None,
+                                   frac=round(v['flops'] / v['secs'] / 1e12 / PEAK_BF16_TFLOPS, 4) if v['flops'] else None)
+                           for k, v in fam.items()},
+                 dominant_kernel=dict(dominant[dom_family], family=dom_family, unit='TFLOP/s'),
+                 frac=round(dominant[dom_family]['achieved'] / PEAK_BF16_TFLOPS, 4))
+    del st, m, inputs
+    torch.cuda.empty_cache()
+    return entry
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -187,6 +437,7 @@ def main():
     assert torch.cuda.is_available(), 'bench.py measures the MI355X HIP path; no GPU visible'
     torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
     device = torch.device('cuda', local_rank)
+    numa = pin_to_gpu_numa_node(local_rank) if (world > 1 or args.feed == 'host') else 'not pinned (single rank, resident inputs)'
     if dist:
         import torch.distributed as td
         td.init_process_group(backend='nccl', init_method='env://')
@@ -204,32 +455,24 @@ def main():
     if os.environ.get('VD3D_BENCH_NOTOWER') or args.no_overlap:
         model.bbox_head.overlap_towers = False
     from visualdet3d_amd import hip_ops
-    KDET = 128                                   # detections per frame that travel (device -> host, rank -> ranks)
-    pack_static = torch.zeros((B, KDET + 1, 13), dtype=torch.float32, device=device)
 
-    def step_device():
-        """One step on the device: the whole forward incl. decode + NMS, then ONE launch that packs the padded results (scores,
-        boxes, labels, per-frame count) into the [B, KDET + 1, 13] record that is copied to the host / gathered."""
-        scores, boxes, labels, aidx, count = model.forward_device(*inputs)
-        hip_ops.pack_detections(scores, boxes, labels, count, KDET, out=pack_static)
-        return scores, boxes, labels, aidx, count
+    feed = None
+    if args.feed == 'host':
+        feed = HostFeed(B, args.height, args.width, device, L, R, seed=rank)
+        mean_c = (C_float3)(*feed.mean)
+        std_c = (C_float3)(*feed.std)
+        Hr, Wr, _ = hip_ops.resized_shape(feed.HS, feed.WS, 0, feed.size)
 
-    graph = None
-    static_out = None
-    with torch.no_grad():
-        for _ in range(2):                       # packs weights, builds anchor tables, warms the allocator
-            static_out = step_device()
-        torch.cuda.synchronize()
-        if not args.no_graph:
-            if not os.environ.get('VD3D_BENCH_NOSIDE'):
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    step_device()
-                torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_out = step_device()
+        def preprocess():           # 2 x B launches inside the captured step: frame b -> L[b] / R[b] (fp32 NCHW, the reference's input)
+            from visualdet3d_amd import _lib
+            for b in range(2 * B):
+                dst = L[b] if b < B else R[b - B]
+                _lib.check(_lib.lib().vd3d_preprocess_image(feed.frames[b].data_ptr(), feed.HS, feed.WS, 0, Hr, Wr, dst.data_ptr(), None,
+                                                            args.height, args.width, mean_c, std_c, hip_ops._stream()), 'vd3d_preprocess_image')
+        feed.preprocess = preprocess
+
+    stepper = Stepper(model, inputs, B, device, use_graph=not args.no_graph, pre=feed.preprocess if feed else None)
+    graph, pack_static = stepper.graph, stepper.pack_static
 
     # Results leave the device every step, inside the timed region: the packed record of the step (B x (KDET + 1) x 13 floats,
     # ~53 KB) is copied to pinned host memory and its counts are checked on the host.
@@ -237,7 +480,7 @@ def main():
     # own stream, double buffered: the comm stream first copies the graph's static record into send buffer (i & 1) (so the
     # next replay may overwrite the record at once), then gathers, then copies the gathered block to the host; the host reads
     # step k's results while step k+1 is already enqueued, so the collective's latency overlaps the next forward.
-    gatherers, comm_stream, taken_ev, packed_ev, done_ev = None, None, None, None, None
+    gather_ev = []
     if dist:
         import torch.distributed as td
         from visualdet3d_amd.distributed import DetectionGather
@@ -248,48 +491,36 @@ def main():
         done_ev = [torch.cuda.Event() for _ in range(2)]
         pinned = [torch.empty((world, B, KDET + 1, 13), dtype=torch.float32).pin_memory() for _ in range(2)]
     else:
-        pinned = [torch.empty((1, B, KDET + 1, 13), dtype=torch.float32).pin_memory()]
-
-    def forward_step():
-        if graph is not None:
-            graph.replay()
-            return static_out
-        with torch.no_grad():
-            return step_device()
-
-    def check(host_block):
-        """host_block [ranks, B, KDET + 1, 13] (pinned): per-frame counts ride in row KDET."""
-        c = host_block[:, :, KDET, 0]
-        assert float(c.min()) >= 0, 'candidate overflow in the head post-processing'
-        return c.clone()
+        pinned = [stepper.pinned]
 
     def run(n):
         """n steps; returns the (host) detection counts [ranks, B] of the last one."""
-        counts = None
         if not dist:
-            for _ in range(n):
-                forward_step()
-                pinned[0][0].copy_(pack_static, non_blocking=True)      # device -> host copy of the step's results
-                torch.cuda.current_stream().synchronize()               # the one host sync per step
-                counts = check(pinned[0])
-            return counts
+            return stepper.run(n, before_step=feed.before_step if feed else None)
+        counts = None
         main = torch.cuda.current_stream()
 
         def collect(i):
             done_ev[i & 1].synchronize()
-            return check(pinned[i & 1])
+            return Stepper.check(pinned[i & 1])
 
         for i in range(n):
             g = gatherers[i & 1]
             if i >= 1:
                 main.wait_event(taken_ev[(i - 1) & 1])       # step i-1's record has been copied out of the static buffer
-            forward_step()
+            if feed:
+                feed.before_step(i)
+            stepper.forward_step()
             packed_ev[i & 1].record(main)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(packed_ev[i & 1])
                 g.pack.copy_(pack_static, non_blocking=True)
                 taken_ev[i & 1].record(comm_stream)
+                t_s, t_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t_s.record(comm_stream)
                 out = g.gather()
+                t_e.record(comm_stream)
+                gather_ev.append((t_s, t_e))
                 pinned[i & 1].copy_(out, non_blocking=True)
                 done_ev[i & 1].record(comm_stream)
             if i >= 1:
@@ -304,6 +535,7 @@ def main():
     run(args.warmup)
     if dbg:
         print('[bench] warmup done', file=sys.stderr, flush=True)
+    del gather_ev[:]
     if dist:
         td.barrier()
     torch.cuda.synchronize()
@@ -315,9 +547,11 @@ def main():
     elapsed = time.perf_counter() - t0
     if dbg:
         print('[bench] timed region done %.3f s' % elapsed, file=sys.stderr, flush=True)
-    print('[bench] rank %d/%d on cuda:%d: %d steps in %.4f s = %.3f ms/step (%d detections in the last step%s)'
+    gather_us = sum(s.elapsed_time(e) for s, e in gather_ev) / max(len(gather_ev), 1) * 1e3 if gather_ev else None
+    print('[bench] rank %d/%d on cuda:%d: %d steps in %.4f s = %.3f ms/step (%d detections in the last step%s)%s; %s'
           % (rank, world, local_rank, args.steps, elapsed, elapsed / args.steps * 1e3, int(counts.sum()),
-             ' over all ranks' if dist else ''), file=sys.stderr, flush=True)
+             ' over all ranks' if dist else '', '; all_gather %.1f us/step on the comm stream' % gather_us if gather_us is not None else '', numa),
+          file=sys.stderr, flush=True)
     if dist:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -325,19 +559,23 @@ def main():
     assert counts is not None and float(counts.min()) >= 0, 'candidate overflow in the head post-processing'
     if os.environ.get('VD3D_BENCH_DUMP'):
         # test hook (tests/test_bench_dist_gpu.py): the last step's host-side results next to forward_device's own
-        torch.save(dict(host=pinned[(args.steps - 1) & 1 if dist else 0].clone(), direct=[t.cpu() for t in forward_step()]),
+        torch.save(dict(host=pinned[(args.steps - 1) & 1 if dist else 0].clone(), direct=[t.cpu() for t in stepper.forward_step()],
+                        inputs=[L.cpu(), R.cpu()] if feed else None),
                    os.environ['VD3D_BENCH_DUMP'])
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        flops, secs, nl, alg_bytes, ev_us, dominant = profile_convs(model, inputs)
-        traffic = None
-        pmc = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
-        if not os.path.exists(pmc):
-            pmc = os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')
-        if args.dtype == 'bf16' and B == 8 and os.path.exists(pmc):
-            traffic = json.load(open(pmc))['conv_hbm_bytes_per_forward']   # PMC pass of this same command, see profiles/
+        fam, dominant_all, _ = profile_ops(model, inputs)
+        conv, dominant = fam['conv'], dominant_all['conv']
+        flops, secs, nl, alg_bytes = conv['flops'], conv['secs'], int(round(conv['launches'])), conv['bytes']
+        traffic, traffic_source = None, None
+        for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+            pmc = os.path.join(REPO, 'profiles', name)
+            if args.dtype == 'bf16' and B == 8 and os.path.exists(pmc):
+                traffic = json.load(open(pmc))['conv_hbm_bytes_per_forward']
+                traffic_source = 'profiles/%s (STATIC: read from the committed rocprofv3 --pmc passes of this same command, NOT measured in this run)' % name
+                break
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         ach = flops / secs / 1e12
         line = {
@@ -348,14 +586,30 @@ def main():
             'config': {'workload': 'Stereo3D_example (YOLOStereo3D, ResNet-34) %dx%d stereo pairs, batch=%d per GPU'
                                    % (args.height, args.width, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
-                       'side_streams': not args.no_overlap, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world)},
+                       'side_streams': not args.no_overlap, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world),
+                       'feed': args.feed if not feed else 'host: %d uint8 bytes uploaded per step and rank (2 x %d frames of %dx%dx3) + vd3d_preprocess_image inside the step'
+                               % (feed.bytes_per_step, B, feed.HS, feed.WS)},
             'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw / conv_ksplit256 / conv_small / conv_pw (all %d launches per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                         'traffic': traffic, 'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
+                         'traffic': traffic, 'traffic_source': traffic_source,
+                         'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
                          'algorithmic_bytes': alg_bytes,
                          'dominant_layer': dict(dominant, unit='TFLOP/s', frac=round(dominant['achieved'] / peak, 4)),
                          'whole_path_frac': round(value / world * GFLOP_PER_PAIR * (args.height * args.width) / (384 * 1280) / 1e3 / peak, 4)},
         }
+        if gather_us is not None:
+            line['config']['all_gather_us_per_step_rank0'] = round(gather_us, 1)
+        if world == 1 and not dist and not args.no_other_configs and args.feed == 'resident' and args.dtype == 'bf16' and not args.no_graph:
+            # BASELINE configs 3 and 5 as stated, driver-observed: same rules, after the headline's timed region (~10 s extra)
+            del stepper
+            torch.cuda.empty_cache()
+            others = []
+            for c in OTHER_CONFIGS:
+                try:
+                    others.append(time_other_config(c, device, steps=max(5, min(args.steps, 20)), warmup=max(2, min(args.warmup, 5))))
+                except Exception as e:      # noqa: BLE001  (an extra config must never take the headline line down with it)
+                    others.append(dict(config=c['key'], workload=c['workload'], error='%s: %s' % (type(e).__name__, e)))
+            line['other_configs'] = others
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, sd, args)
         print(json.dumps(line))

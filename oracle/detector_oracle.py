@@ -72,7 +72,9 @@ def _affine(y, scale, shift):
 
 def conv_bn_act(c, x, conv, bn=None, relu=True, stride=1, padding=1, dilation=1, groups=1, residual=None, out_round=True):
     """conv (+bias) (+eval BN) (+residual) (+ReLU) == one fused HIP layer; output rounded once."""
-    w = c.w(conv + '.weight')
+    # depth-wise (ghost cheap_operation) weights stay fp32 in the HIP path (hip_ops.pack_dwconv: 9 fp32 taps per channel, VALU
+    # kernel): only the MFMA operands are rounded to the 16-bit compute type
+    w = c.w(conv + '.weight') if groups == 1 else c.sd[conv + '.weight']
     y = F.conv2d(x, w, None, stride=stride, padding=padding, dilation=dilation, groups=groups)
     n = w.shape[0]
     scale = torch.ones(n)

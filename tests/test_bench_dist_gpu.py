@@ -67,3 +67,37 @@ def test_pack_detections_kernel_matches_host_pack():
     gth = vdist.DetectionGather(B, k, 'cuda', world=1)
     gth.fill(scores.cuda(), boxes.cuda(), labels.cuda(), count.cuda())
     assert torch.equal(gth.pack.cpu(), got)
+
+
+def test_bench_feed_host_uploads_frames_and_preprocesses_inside_the_step():
+    """``bench.py --feed host`` (world = 1): every step uploads 2 x B uint8 KITTI-sized frames from pinned host memory into the
+    device ring on the copy stream and runs vd3d_preprocess_image inside the captured step.  The network inputs the step produced
+    equal the oracle's preprocessing (oracle/preprocess_ref.py, pinned to the reference's augmentation classes) of the frames of
+    the LAST step's ring slot, and the detections that reached the host are the ones forward_device returns for those inputs."""
+    import numpy as np
+    from oracle import preprocess_ref
+    dump = os.path.join(tempfile.mkdtemp(), 'dump.pt')
+    steps, B = 3, 2
+    env = dict(os.environ, VD3D_BENCH_DUMP=dump, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', str(steps), '--warmup', '2', '--batch', str(B), '--no-cpu-baseline',
+           '--feed', 'host']
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['config']['feed'].startswith('host:') and 'other_configs' not in line and line['value'] > 50
+    d = torch.load(dump)
+    L, R = d['inputs']
+    g = torch.Generator().manual_seed(0)                       # HostFeed(seed = rank 0): slot 0 then slot 1
+    slots = [torch.randint(0, 256, (2 * B, 375, 1242, 3), dtype=torch.uint8, generator=g) for _ in range(2)]
+    frames = slots[(steps - 1) & 1]
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    for b, dst in ((0, L[0]), (B - 1, L[B - 1]), (B, R[0]), (2 * B - 1, R[B - 1])):
+        want = preprocess_ref.preprocess(frames[b].numpy(), 0, (384, 1280), mean, std)
+        np.testing.assert_allclose(dst.numpy(), want, rtol=0, atol=2e-6)
+    host = d['host']
+    scores, boxes, labels, aidx, count = d['direct']
+    k = host.shape[2] - 1
+    for b in range(B):
+        n = int(count[b])
+        assert n >= 0 and int(host[0, b, k, 0]) == n
+        assert torch.equal(host[0, b, :n, 0], scores[b, :n]) and torch.equal(host[0, b, :n, 1:12], boxes[b, :n])
