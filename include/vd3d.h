@@ -159,6 +159,13 @@ int vd3d_psm_cosine(const void* left, const void* right, void* cost, int B, int 
  *   vol[b,d,y,x,0:F]  = L[b,y,x,:] (x >= d else 0);  vol[b,d,y,x,F:2F] = R[b,y,x-d,:] (x >= d else 0). */
 int vd3d_costvol_build(const void* left, const void* right, void* vol, int B, int H, int W, int F, int D,
                        int in_pix_stride, int dtype, void* stream);
+/* CostVolume.forward after its 1x1 down-sample, in ONE launch (lib/PSM_cost_volume.py:45-68): concat volume (never materialised) ->
+ * Conv3d(2F -> F) + BN3d + ReLU -> Conv3d(F -> F) + BN3d + ReLU -> reshape to NHWC [B][H][W][F*D] (channel = f*D + d, written with
+ * out_pix_stride).  bf16 only, F = 8 (PSM_features of every shipped config), D <= 24; the intermediate volume is rounded to bf16
+ * exactly where vd3d_conv3d_3x3x3 rounds it.  left / right: NHWC [B][H][W][F] (in_pix_stride); w1 [27][2F][F], w2 [27][F][F] fp32. */
+int vd3d_cost_volume_fused(const void* left, const void* right, const float* w1, const float* scale1, const float* shift1,
+                           const float* w2, const float* scale2, const float* shift2, void* out, int B, int H, int W, int F, int D,
+                           int in_pix_stride, int out_pix_stride, int dtype, void* stream);
 /* Conv3d(3x3x3, pad 1) + folded BN3d + ReLU, channels-last [B][D][H][W][Cin] (lib/PSM_cost_volume.py:34-41).
  * weight: [27][Cin][Cout] fp32.  If out_fd_major != 0 the result is written as NHWC [B][H][W][Cout*D] with
  * channel = f*D + d (the reshape at PSM_cost_volume.py:66-67) using out_pix_stride. */

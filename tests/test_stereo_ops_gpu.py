@@ -52,3 +52,35 @@ def test_cost_volume_module(dtype):
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     assert got.shape == ref.shape
     assert ((got - ref).abs().max() / ref.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize('B,H,W,D', [(2, 7, 45, 12), (1, 24, 80, 12), (3, 2, 40, 5), (1, 5, 83, 24)])
+def test_cost_volume_fused_launch_equals_the_three_launch_path(B, H, W, D):
+    """vd3d_cost_volume_fused (concat volume + 2 x Conv3d + BN3d + ReLU + reshape in one launch; the volume and the intermediate
+    never reach HBM) against costvol_build + 2 x conv3d_3x3x3: same MFMA slices in the same order and the same bf16 rounding
+    point for the intermediate, so the results are BIT-IDENTICAL -- ragged tiles (H, W not multiples of 2 x 40), a channel-slice
+    output, and the oracle as the external reference."""
+    from visualdet3d_amd import hip_ops as ops
+    from visualdet3d_amd.networks.lib.PSM_cost_volume import CostVolume
+    from visualdet3d_amd.utils import synthetic as syn
+    m = CostVolume(downsample_scale=16, max_disp=16 * D, input_features=64, PSM_features=8)
+    sd = syn.seeded_state_dict({'x.' + k: v for k, v in m.state_dict().items()}, seed=7)
+    sd = {k[2:]: v for k, v in sd.items()}
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(B * 100 + W)
+    x = torch.randn(2 * B, H, W, 64, generator=g).cuda().to(torch.bfloat16)
+    buf = torch.full((B, H, W, 8 * D + 16), 5.0, dtype=torch.bfloat16, device='cuda')
+    with torch.no_grad():
+        m.fuse_volume = True
+        a = m.forward_nhwc(x, B, out=buf[..., 8:8 + 8 * D])
+        m.fuse_volume = False
+        b = m.forward_nhwc(x, B)
+    assert a.shape == b.shape == (B, H, W, 8 * D)
+    assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+    assert bool((buf[..., :8] == 5.0).all()) and bool((buf[..., 8 + 8 * D:] == 5.0).all())
+    xs = x.float().cpu().permute(0, 3, 1, 2)
+    c = orc.Ctx({'cv.' + k: v for k, v in sd.items()}, orc.bf16_round)
+    ref = orc.cost_volume(c, 'cv', xs[:B], xs[B:], 16 * D, 16)
+    got = a.float().cpu().permute(0, 3, 1, 2)
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-2

@@ -95,6 +95,7 @@ SIGNATURES = {
     'vd3d_psm_cosine': (c_int, [c_void_p] * 3 + [c_int] * 8 + [c_void_p]),
     'vd3d_costvol_build': (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),
     'vd3d_conv3d_3x3x3': (c_int, [c_void_p] * 5 + [c_int] * 10 + [c_void_p]),
+    'vd3d_cost_volume_fused': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_void_p]),
     'vd3d_head_workspace_bytes': (c_int64, [c_int, c_int]),
     'vd3d_head_postprocess': (c_int, [C.POINTER(HeadParams), c_void_p]),
     'vd3d_pack_detections': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),

@@ -262,6 +262,143 @@ __global__ void __launch_bounds__(256) conv3d_mfma_kernel(const short* __restric
     }
 }
 
+// ---- CostVolume.forward in ONE launch (bf16, PSM_features = 8) ---------------------------------------------------------
+// lib/PSM_cost_volume.py:45-68 after the 1x1 down-sample: concat volume -> Conv3d + BN3d + ReLU -> Conv3d + BN3d + ReLU -> reshape.
+// As three launches (costvol_build + 2 x conv3d_mfma) the stage cost ~100 us of a 3.8 ms stereo step for 2 GFLOP on a 5.9 MB volume:
+// pure launch latency and dependent global round trips.  Here a workgroup owns TY x TX pixels x all D disparities:
+//   phase 1: the first conv on the (TY + 2) x (TX + 2) x D haloed tile; its B operand is gathered straight from the two 8-channel
+//            feature maps (vol[.., d, y, x] = L[y, x] | R[y, x - d] for x >= d, else 0 -- the concat volume is never built), results
+//            (BN + ReLU, rounded to bf16: the unfused path's rounding point) go to LDS, zero outside the image (conv padding);
+//   phase 2: the second conv from LDS; outputs are parked in LDS as the pixel's 8 * D-channel run (channel = f * D + d) and
+//   phase 3: leave as whole 16-byte vectors (the unfused kernel wrote 2-byte pieces).
+// Same MFMA formulation as conv3d_mfma_kernel: v_mfma_f32_16x16x32_bf16, weights = A operand (8 of 16 rows used), 16 voxels = B.
+template <int TY, int TX>
+__global__ void __launch_bounds__(256) cost_volume_fused_kernel(const short* __restrict__ left, const short* __restrict__ right,
+                                                                const float* __restrict__ w1, const float* __restrict__ s1, const float* __restrict__ t1,
+                                                                const float* __restrict__ w2, const float* __restrict__ s2, const float* __restrict__ t2,
+                                                                short* __restrict__ out, int H, int W, int D, int ips, int ops, int xtiles, int ytiles,
+                                                                int vec_out) {
+    constexpr int MY = TY + 2, MX = TX + 2, F = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* mid = smem;                                  // [D][MY][MX] x 16 B (8 bf16 channels)
+    short* outt = (short*)(smem + (size_t)D * MY * MX * 16);   // [TY * TX][F * D]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
+    int t = blockIdx.x;
+    const int xt = t % xtiles; t /= xtiles;
+    const int yt = t % ytiles;
+    const int b = t / ytiles;
+    const int y0 = yt * TY, x0 = xt * TX;
+    const short* lb = left + (int64_t)b * H * W * ips;
+    const short* rb = right + (int64_t)b * H * W * ips;
+    // weight fragments of both convs: row = output channel l16 (rows >= 8 zero), k = this lane's 8 (tap, channel) values
+    i32x4 wf1[14], wf2[7];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int tap = s * 2 + (q >> 1), ch = 8 * (q & 1);
+        Vec16<short> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = (l16 < F && tap < 27) ? w1[(tap * 16 + ch + 2 * e) * F + l16] : 0.f;
+            const float c = (l16 < F && tap < 27) ? w1[(tap * 16 + ch + 2 * e + 1) * F + l16] : 0.f;
+            o.set2(e, a, c);
+        }
+        wf1[s] = o.raw;
+    }
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int tap = s * 4 + q;
+        Vec16<short> o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = (l16 < F && tap < 27) ? w2[(tap * 8 + 2 * e) * F + l16] : 0.f;
+            const float c = (l16 < F && tap < 27) ? w2[(tap * 8 + 2 * e + 1) * F + l16] : 0.f;
+            o.set2(e, a, c);
+        }
+        wf2[s] = o.raw;
+    }
+    float sc1[4], sh1[4], sc2[4], sh2[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int o = (4 * q + e) & 7;
+        sc1[e] = s1[o]; sh1[e] = t1[o]; sc2[e] = s2[o]; sh2[e] = t2[o];
+    }
+    // ---- phase 1: first conv on the haloed tile -> mid (LDS)
+    const int nmid = D * MY * MX;
+    for (int g = wave; g * 16 < nmid; g += 4) {
+        const int v = g * 16 + l16;
+        const bool vin = v < nmid;
+        const int vv = vin ? v : 0;
+        const int mx = vv % MX, my = (vv / MX) % MY, d = vv / (MX * MY);
+        const int y = y0 - 1 + my, x = x0 - 1 + mx;
+        const bool img = vin && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int tap = s * 2 + (q >> 1);
+            const int kd = tap / 9, ky = (tap - kd * 9) / 3, kx = tap - kd * 9 - ky * 3;
+            const int id = d - 1 + kd, iy = y - 1 + ky, ix = x - 1 + kx;
+            const bool ok = img && tap < 27 && (unsigned)id < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ix >= id;
+            i32x4 frag = {0, 0, 0, 0};
+            if (ok) {
+                const short* src = (q & 1) ? rb + ((int64_t)iy * W + (ix - id)) * ips : lb + ((int64_t)iy * W + ix) * ips;
+                frag = *(const i32x4*)src;
+            }
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf1[s]), __builtin_bit_cast(bf16x8, frag), acc, 0, 0, 0);
+        }
+        if (vin && q < 2) {
+            i32x2 o2 = {0, 0};
+            if (img) {
+                float r[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e] * sc1[e] + sh1[e], 0.f);
+                o2[0] = Fmt16<short>::pack2(r[0], r[1]);
+                o2[1] = Fmt16<short>::pack2(r[2], r[3]);
+            }
+            *(i32x2*)(mid + (size_t)v * 16 + q * 8) = o2;
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: second conv from LDS -> the pixel's channel run (f * D + d) in LDS
+    const int nout = D * TY * TX;
+    for (int g = wave; g * 16 < nout; g += 4) {
+        const int v = g * 16 + l16;
+        const bool vin = v < nout;
+        const int vv = vin ? v : 0;
+        const int tx = vv % TX, ty = (vv / TX) % TY, d = vv / (TX * TY);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const int tap = s * 4 + q;
+            const int kd = tap / 9, ky = (tap - kd * 9) / 3, kx = tap - kd * 9 - ky * 3;
+            const int id = d - 1 + kd;
+            i32x4 frag = {0, 0, 0, 0};
+            if (vin && tap < 27 && (unsigned)id < (unsigned)D) frag = *(const i32x4*)(mid + (size_t)((id * MY + ty + ky) * MX + tx + kx) * 16);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf2[s]), __builtin_bit_cast(bf16x8, frag), acc, 0, 0, 0);
+        }
+        if (vin && q < 2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) outt[(ty * TX + tx) * (F * D) + (4 * q + e) * D + d] = f2bf(fmaxf(acc[e] * sc2[e] + sh2[e], 0.f));
+        }
+    }
+    __syncthreads();
+    // ---- phase 3: whole vectors out
+    const int run = F * D;                              // channels per pixel
+    if (vec_out) {
+        const int vpp = run / 8;                        // 16-byte vectors per pixel
+        for (int i = tid; i < TY * TX * vpp; i += 256) {
+            const int pix = i / vpp, part = i - pix * vpp;
+            const int y = y0 + pix / TX, x = x0 + pix % TX;
+            if (y < H && x < W) *(i32x4*)(out + (((int64_t)b * H + y) * W + x) * ops + part * 8) = *(const i32x4*)(outt + pix * run + part * 8);
+        }
+    } else {
+        for (int i = tid; i < TY * TX * run; i += 256) {
+            const int pix = i / run, c = i - pix * run;
+            const int y = y0 + pix / TX, x = x0 + pix % TX;
+            if (y < H && x < W) out[(((int64_t)b * H + y) * W + x) * ops + c] = outt[i];
+        }
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
@@ -327,4 +464,25 @@ extern "C" int vd3d_conv3d_3x3x3(const void* in, const float* weight, const floa
     else { vd3d_set_error("conv3d: only (Cin,Cout) in {(16,8),(8,8)} are instantiated (CostVolume PSM_features=8)"); return VD3D_EINVAL; }
 #undef VD3D_C3D
     return vd3d_check_launch("conv3d_3x3x3");
+}
+
+extern "C" int vd3d_cost_volume_fused(const void* left, const void* right, const float* w1, const float* scale1, const float* shift1,
+                                      const float* w2, const float* scale2, const float* shift2, void* out, int B, int H, int W, int F,
+                                      int D, int ips, int ops, int dtype, void* stream) {
+    if (!left || !right || !w1 || !scale1 || !shift1 || !w2 || !scale2 || !shift2 || !out) { vd3d_set_error("cost_volume_fused: null pointer"); return VD3D_EINVAL; }
+    if (dtype != VD3D_BF16 || F != 8 || D < 1 || D > 24 || ips % 8 || ((uintptr_t)left & 15) || ((uintptr_t)right & 15)) {
+        vd3d_set_error("cost_volume_fused: bf16, PSM_features = 8, D <= 24, 16-byte aligned feature pixels only (other cases: the three-launch path)");
+        return VD3D_EINVAL;
+    }
+    if (B == 0) return VD3D_OK;
+    constexpr int TY = 2, TX = 40;
+    const int xtiles = (W + TX - 1) / TX, ytiles = (H + TY - 1) / TY;
+    const int lds = D * (TY + 2) * (TX + 2) * 16 + TY * TX * F * D * 2;
+    const int vec_out = ((F * D) % 8 == 0) && (ops % 8 == 0) && (((uintptr_t)out & 15) == 0);
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)cost_volume_fused_kernel<TY, TX>, lds, lim, "hipFuncSetAttribute(cost_volume_fused)")) return rc;
+    hipLaunchKernelGGL((cost_volume_fused_kernel<TY, TX>), dim3((unsigned)(B * ytiles * xtiles)), dim3(256), lds, (hipStream_t)stream,
+                       (const short*)left, (const short*)right, w1, scale1, shift1, w2, scale2, shift2, (short*)out, H, W, D, ips, ops,
+                       xtiles, ytiles, vec_out);
+    return vd3d_check_launch("cost_volume_fused");
 }

@@ -383,6 +383,26 @@ def conv3d_3x3x3(vol, pc, relu=True, out_nhwc=None):
 
 
 # --------------------------------------------------------------------------------------------- head
+def cost_volume_fused_supported(left, D):
+    return left.dtype == torch.bfloat16 and left.shape[3] == 8 and D <= 24 and left.stride(2) % 8 == 0
+
+
+def cost_volume_fused(left, right, p0, p1, D, out=None):
+    """CostVolume after the 1x1 down-sample in one launch (vd3d_cost_volume_fused): left / right NHWC [B,H,W,8] bf16 ->
+    NHWC [B,H,W,8*D] (channel = f*D + d).  The three-launch path (costvol_build + 2 x conv3d_3x3x3) is the fp32 / general one."""
+    _require_cuda(left, right)
+    B, H, W, F = left.shape
+    assert right.shape == left.shape and cost_volume_fused_supported(left, D) and left.stride(2) == right.stride(2)
+    assert _dense_pixels(left) and _dense_pixels(right) and (p0.Cin, p0.Cout, p1.Cin, p1.Cout) == (2 * F, F, F, F)
+    if out is None:
+        out = torch.empty((B, H, W, F * D), dtype=left.dtype, device=left.device)
+    assert out.shape == (B, H, W, F * D) and out.dtype == left.dtype and _dense_pixels(out)
+    check(_lib.lib().vd3d_cost_volume_fused(_p(left), _p(right), _p(p0.w), _p(p0.scale), _p(p0.shift), _p(p1.w), _p(p1.scale), _p(p1.shift),
+                                            _p(out), B, H, W, F, D, left.stride(2), out.stride(2), dtype_code(left.dtype), _stream()),
+          'vd3d_cost_volume_fused')
+    return out
+
+
 def head_postprocess(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr,
                      use_filter=True, y_min_max=(-0.5, 1.8), x_max=40.0, max_cand=4096, max_det=None, workspace=None):
     """Device-side get_bboxes for a whole batch.  Returns padded (scores [B,K], boxes [B,K,11], labels [B,K] i32,

@@ -47,6 +47,7 @@ class CostVolume(nn.Module):
         )
         self.output_channel = PSM_features * self.depth_channel
         self._cache = fused.PackCache()
+        self.fuse_volume = True       # False: the three-launch path (A/B, per-stage parity taps)
 
     def forward_nhwc(self, feats_lr, batch, out=None):
         """feats_lr: NHWC [2B,H,W,C] with left images first (as the backbone produced them)."""
@@ -55,10 +56,13 @@ class CostVolume(nn.Module):
         pc = self._cache.get(('ds', dt), [conv.weight, conv.bias] + fused.bn_sources(bn),
                              lambda: ops.pack_conv(conv.weight, conv.bias, fused.bn_tuple(bn), dt, 1, 0, 1))
         small = ops.conv2d(feats_lr, pc, relu=True)  # [2B,H,W,F]
-        vol = ops.costvol_build(small[:batch], small[batch:], self.depth_channel)
         c0, b0, c1, b1 = self.conv3d[0], self.conv3d[1], self.conv3d[3], self.conv3d[4]
         p0 = self._cache.get('c3d0', [c0.weight, c0.bias] + fused.bn_sources(b0), lambda: ops.pack_conv3d(c0.weight, c0.bias, fused.bn_tuple(b0)))
         p1 = self._cache.get('c3d1', [c1.weight, c1.bias] + fused.bn_sources(b1), lambda: ops.pack_conv3d(c1.weight, c1.bias, fused.bn_tuple(b1)))
+        if self.fuse_volume and ops.cost_volume_fused_supported(small, self.depth_channel) and (p0.Cin, p1.Cin) == (16, 8):
+            # bf16: concat volume + both Conv3d + BN3d + ReLU + reshape in ONE launch (the volume never reaches HBM)
+            return ops.cost_volume_fused(small[:batch], small[batch:], p0, p1, self.depth_channel, out=out)
+        vol = ops.costvol_build(small[:batch], small[batch:], self.depth_channel)
         mid = ops.conv3d_3x3x3(vol, p0, relu=True)
         B, D, H, W, _ = mid.shape
         if out is None:
