@@ -123,6 +123,12 @@ def _shapes_for(cfg):
             (1, 9, 40, 64, 28, dict(out_f32=True, relu=False)),               # Cout % 4 == 0 < 32: masked stores
             (3, 64, 96, 16, 16, dict(in_extra=16, out_extra=16)),             # channel-slice views, many tiles per workgroup
             (2, 32, 64, 64, 16, dict()),
+            # MORE tiles than workgroup slots (512): every workgroup walks 2 - 3 tiles, the steady state of the halo ring AND of the
+            # fragment ring across the tile boundary (round 2 had no such case for Cin 16 | 32 and shipped a ring that rotated there)
+            (2, 256, 512, 16, 16, dict()),                                   # 1024 tiles, DLA level 0 shape family
+            (3, 512, 1024, 16, 32, dict(stride=2)),                          # 1536 tiles, DLA level 1 (stride 2)
+            (2, 320, 512, 32, 32, dict(relu=False)),                          # 1280 tiles, Cin 32 (NF = 18)
+            (5, 128, 440, 64, 32, dict(out_f32=True, bn=False, relu=False)),  # 1120 tiles, DCN offset conv at the KM3D s4 shape
         ]
     if cfg == 61:       # register-resident weights: Cin 128 (128-channel slices) | 256 (64-channel slices, K halves added in LDS)
         return [

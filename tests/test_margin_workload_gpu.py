@@ -36,13 +36,15 @@ CH = ((16, 0, 1.0), (17, 0, 0.5), (0, 1, 0.25))        # (anchor, class, gain re
 MARGIN = 10.0
 
 
-def _best_level(vals, lo_cnt, hi_cnt, min_level=-1e30):
-    """widest gap between consecutive sorted values with lo_cnt..hi_cnt values above it -> (gap, level, count)"""
-    v = torch.sort(vals, descending=True).values
+def _best_level(vals, lo_cnt, hi_cnt, min_level=-1e30, also=None, need=0):
+    """widest gap between consecutive sorted values with lo_cnt..hi_cnt values above it -> (gap, level, count).  ``also``: boolean
+    per value; at least ``need`` of the values above the level must carry it."""
+    v, order = torch.sort(vals, descending=True)
+    cum = torch.cumsum(also[order].long(), 0) if also is not None else None
     best = (0.0, None, 0)
     for n in range(lo_cnt, min(hi_cnt, len(v) - 1) + 1):
         gap, lvl = (v[n - 1] - v[n]).item(), 0.5 * (v[n - 1] + v[n]).item()
-        if lvl > min_level and gap > best[0]:
+        if lvl > min_level and gap > best[0] and (cum is None or int(cum[n - 1]) >= need):
             best = (gap, lvl, n)
     return best
 
@@ -64,7 +66,10 @@ def design_margin_head(x_pen, mask):
                 continue
             # channel 1 (same centres, next scale, half the gain) must sit ABOVE channel 0's level: then logit0 - logit1 =
             # g/2 (r + L1 - 2 L0) >= g (L1 - L0) > 0 wherever both are candidates, i.e. anchor 16 always outranks anchor 17
-            g1 = _best_level(r[mask[..., CH[1][0]]], 4, 160, min_level=g0[1] + 0.5 * g0[0])
+            # (and at least 8 of its candidates must sit where anchor 16 passes the ground filter too, so that NMS has suppressions
+            # to decide: the filter depends on the anchor's prior depth, the two masks differ at the image border)
+            m1 = mask[..., CH[1][0]]
+            g1 = _best_level(r[m1], 8, 160, min_level=g0[1] + 0.5 * g0[0], also=mask[..., CH[0][0]][m1], need=8)
             if g1[1] is None:
                 continue
             # channel 2's candidates are removed by the z-prior filter before NMS: its level is free

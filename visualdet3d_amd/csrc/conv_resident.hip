@@ -520,7 +520,13 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int n
     constexpr int NST = (150 * 1024 / STAGE) >= 4 ? 4 : ((150 * 1024 / STAGE) >= 3 ? 3 : 2);
     constexpr int KS = CIN / 16, NF = 9 * KS;                          // MFMAs (= A fragments) per tile and wave
     constexpr int NS = OUTF32 ? 4 : 2;                                // stores per tile and wave
-    constexpr int RING = NF >= 8 ? 4 : 2;
+    // Fragment ring: fragment j of EVERY tile lives in slot j % RING, and the slot freed by fragment f is refilled with fragment f + RING
+    // -- across the tile boundary that is next tile's fragment f + RING - NF, whose slot is (f + RING - NF) % RING: the two agree only
+    // when RING divides NF.  (Round 2 shipped RING = 4 with NF = 9 | 18 (Cin 16 | 32): from a workgroup's SECOND tile on the MFMAs read
+    // rotated fragments -- wrong results whenever a launch had more tiles than workgroup slots, i.e. at BASELINE config 5's size;
+    // found by the fp16-at-size test of round 3.  Cin 64 (NF = 36) was unaffected.)
+    constexpr int RING = NF % 4 == 0 ? 4 : 3;
+    static_assert(NF % RING == 0, "the fragment ring must divide the fragments of a tile");
     static_assert(CIN == 16 || CIN == 32 || CIN == 64, "small-channel kernel: Cin 16 | 32 | 64");
     static_assert(NST * STAGE + 512 <= 160 * 1024, "halo ring does not fit the LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
