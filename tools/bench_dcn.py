@@ -1,6 +1,7 @@
 """Micro-benchmark of the fused DCNv2 kernel (vd3d_deform_conv, NHWC fast path) on the KM3D up-path shapes (MI355X):
     python tools/bench_dcn.py [fp16|bf16] [reps]
 Prints per-launch time (HIP events around `reps` back-to-back launches), TF/s and the algorithmic GB/s."""
+import os
 import sys
 
 import torch
@@ -23,7 +24,7 @@ for name, B, H, W, C, O in SHAPES:
     x = torch.randn(B, H, W, C, device='cuda').to(dt)
     w = torch.randn(O, C, 3, 3, device='cuda') * (2.0 / (9 * C)) ** 0.5
     pd = ops.pack_dcn_weight(w, dt)
-    logits = torch.randn(B, H, W, 32, device='cuda') * 1.5
+    logits = torch.randn(B, H, W, 32, device='cuda') * float(os.environ.get('VD3D_DCN_SIGMA', '1.5'))   # spread of the offsets in pixels
     out = torch.empty(B, H, W, O, device='cuda', dtype=dt)
     run = lambda: ops.deform_conv_general(x, pd, logits[..., :18], logits[..., 18:27], out, 'nhwc', stride=(1, 1), padding=(1, 1),
                                           dilation=(1, 1), groups=1, deformable_groups=1, mask_sigmoid=True, relu=True)

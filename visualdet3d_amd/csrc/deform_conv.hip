@@ -490,6 +490,283 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         }
 }
 
+// ---- 64 -> 64 channel DCNv2 3x3 / s1 / p1: corners gathered from an LDS-staged input window, weights resident in LDS ---------------
+// The kernel above is bound by the L1 request path for C = O = 64 (the ten full-resolution launches of KM3D's DLA-Up, 2.2 ms of a
+// 9.8 ms step at 8.8 % of the MFMA peak): per 64-pixel workgroup and tap every thread issues 8 corner gathers + 2 weight vectors of
+// 1 KiB per wave, every needed input pixel passes through L1 ~36 times, and every workgroup streams the whole 74 KB weight panel
+// (1 GB per launch at 16 x 128 x 440).  Here:
+//   * PERSISTENT workgroups (one per CU, 4 waves); the 64 x 576 weights are loaded ONCE per workgroup into LDS as MFMA A-fragment
+//     images (72 x 1 KiB, lane-linear: conflict-free ds_read_b128);
+//   * a tile is 8 x 8 output pixels; its input WINDOW of (8 + 2 * 3 + 1)^2 = 15 x 15 pixels x 128 B is staged once by LDS-DMA
+//     (out-of-image pixels arrive as zeros = the reference's "corner outside the image contributes 0"), double buffered: tile k+1's
+//     window and offset logits travel while tile k computes; the four corners of a sample are four ds_read_b128 (256 B/clk/CU
+//     instead of the 64 B/clk L1 path), XOR-swizzled on the 16-byte slot by the window pixel;
+//   * a wave owns 16 pixels x all 64 output channels on v_mfma_f32_16x16x32: the blended values ARE the B fragment (lane (pixel,
+//     k-group) blends the 2 x 8 channels it multiplies) -- no column tile in LDS, no barrier inside a tile, ONE barrier per tile;
+//   * samples whose corners leave the window (learned offsets beyond +-2 px) take the global-gather path per (wave, tap): same
+//     arithmetic, only slower -- results are bit-identical to dcn_nhwc_kernel in every case (same blend order, same modulation fold);
+//   * outputs leave as whole 128-byte lines (parked per wave in its own geometry slot of LDS).
+// MEASURED (round 3, 16 x 128 x 440 fp16, offsets sigma 0.5 px): 419 us against 354 us for dcn_nhwc_kernel -- the L1 path is gone, but
+// with 151 KB of LDS per workgroup only ONE wave runs per SIMD and nothing hides its LDS / VALU latencies (the blend alone is ~1050
+// VALU instructions per tile and wave = a 113 us floor for this launch; the gather kernel keeps 12 waves per CU busy at ~32 % VALU
+// utilisation).  The kernel is therefore NOT the default: it runs only with VD3D_DCN_WINDOW=1 (tests exercise it that way and hold it
+// bit-identical to the gather kernel).  What would make it pay is two waves per SIMD: weights split over K into registers (8 waves,
+// 144 VGPRs each, partial sums reduced in LDS) instead of 74 KB of LDS -- DESIGN.md section 9.
+constexpr int kWinP = 3, kWinD = 8 + 2 * kWinP + 1, kWinPix = kWinD * kWinD;            // 15 x 15 window pixels
+constexpr int kWinPieces = (kWinPix * 8 + 63) / 64, kWinBytes = kWinPieces * 1024;       // 29 DMA pieces of 1 KiB
+constexpr int kWinWts = 9 * 2 * 4 * 1024;                                                // (tap, k-step, 16-channel block) fragments
+constexpr int kWinGeoWave = 9 * 16 * 16, kWinGeo = 4 * kWinGeoWave;                      // per wave: 9 taps x 16 pixels x 16 B
+constexpr int kWinLds = kWinWts + 2 * kWinBytes + 2 * kWinGeo;                           // 151 552 B
+
+template <typename T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) dcn_win64_kernel(const DcnArgs p, int ntiles, int tiles_x, int tiles_y) {
+    static_assert(sizeof(T) == 2, "16-bit formats only");
+    constexpr uint32_t kOOBw = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wts = smem;
+    char* win = smem + kWinWts;
+    char* geo = win + 2 * kWinBytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int prow = 2 * wave + (n >> 3), pcol = n & 7;                 // this lane's pixel inside the tile
+    // XCD-aware persistent walk: the workgroups of one XCD (private L2) take a contiguous run of tiles, neighbours share window halos
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_xcd = nwg >> 3;
+    const int chunk = (ntiles + 7) >> 3;
+    auto tile_of = [&](int k) { const int i = jx + k * per_xcd; return i < chunk ? xcd * chunk + i : ntiles; };
+    const int tiles_img = tiles_x * tiles_y;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0x7fffffff, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    // ---- weights -> LDS fragment images (once per workgroup): fragment f = (tap*2 + s)*4 + blk, lane l: row blk*16 + (l & 15),
+    // k = tap*64 + s*32 + (l >> 4)*8 .. +7
+    for (int idx = tid; idx < 72 * 64; idx += 256) {
+        const int f = idx >> 6, l = idx & 63;
+        const int tap = f >> 3, sx = (f >> 2) & 1, blk = f & 3;
+        const int o = blk * 16 + (l & 15), kk = tap * 64 + sx * 32 + (l >> 4) * 8;
+        *(i32x4*)(wts + idx * 16) = *(const i32x4*)((const char*)p.w + ((size_t)o * p.Kpad + kk) * 2);
+    }
+    // per-channel constants of this lane's 16 output channels (blk*16 + g*4 + e)
+    float cb[4][4], cs[4][4], ct[4][4];
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int o = blk * 16 + g * 4 + e;
+            cb[blk][e] = p.bias ? p.bias[o] : 0.f;
+            cs[blk][e] = p.scale ? p.scale[o] : 1.f;
+            ct[blk][e] = p.shift ? p.shift[o] : 0.f;
+        }
+    // DMA lane constants: piece q = wave + 4*it, chunk c = 64 q + lane -> window pixel pp = c >> 3, LDS slot c & 7 holds vector
+    // (slot ^ key(pp)) of that pixel (the swizzle is applied to the SOURCE: the DMA writes lane-linear)
+    constexpr int NIT = (kWinPieces + 3) / 4;
+    int d_rel[NIT], d_yx[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = wave + 4 * it, c = q * 64 + lane, pp = c >> 3, sl = c & 7;
+        const int v = sl ^ ((pp >> 1) & 7);
+        const int wy = pp / kWinD, wx = pp - wy * kWinD;
+        d_rel[it] = (int)((wy * p.in_sy + wx * p.in_sx + v * 8) * 2);
+        d_yx[it] = (q < kWinPieces && pp < kWinPix) ? (wy | (wx << 8)) : -1;
+    }
+    auto decode = [&](int t, int& b, int& ty0, int& tx0) {
+        b = t / tiles_img;
+        const int r = t - b * tiles_img, ty = r / tiles_x;
+        ty0 = ty * 8;
+        tx0 = (r - ty * tiles_x) * 8;
+    };
+    auto issue_window = [&](int t, int buf) {
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+        const int base = (int)((b * p.in_sb + (ty0 - kWinP) * p.in_sy + (tx0 - kWinP) * p.in_sx) * 2);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int q = wave + 4 * it;
+            if (q < kWinPieces) {                                   // wave-uniform
+                const int wy = d_yx[it] & 255, wx = (d_yx[it] >> 8) & 255;
+                const bool ok = d_yx[it] >= 0 && (unsigned)(ty0 - kWinP + wy) < (unsigned)p.H && (unsigned)(tx0 - kWinP + wx) < (unsigned)p.W;
+                const uint32_t off = ok ? (uint32_t)(base + d_rel[it]) : kOOBw;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(win + buf * kWinBytes + q * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    // the offset / mask logits of this wave's 9 x 16 geometry entries (entry e = r*64 + lane: tap e >> 4, pixel e & 15)
+    float l_oh[3], l_ow[3], l_ml[3];
+    auto issue_logits = [&](int t) {
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = r * 64 + lane, tap = e >> 4, nn = e & 15;
+            const int y = ty0 + 2 * wave + (nn >> 3), x = tx0 + (nn & 7);
+            l_oh[r] = l_ow[r] = l_ml[r] = 0.f;
+            if (e < 144 && y < p.Ho && x < p.Wo) {
+                const int64_t ob = b * p.off_sb + y * p.off_sy + x * p.off_sx;
+                l_oh[r] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
+                l_ow[r] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+                if (p.mask) l_ml[r] = p.mask[b * p.msk_sb + y * p.msk_sy + x * p.msk_sx + (int64_t)tap * p.msk_sc];
+            }
+        }
+    };
+    // geometry entry: { (h_low + 1) | (w_low + 1) << 16, lh, lw, m }; an invalid sample (outside (-1, H) x (-1, W), or a pixel
+    // beyond the image edge of a ragged tile) carries m = 0 and the tile origin (always inside the window)
+    auto write_geometry = [&](int t, int buf) -> bool {
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+        bool leaves = false;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = r * 64 + lane, tap = e >> 4, nn = e & 15;
+            if (e < 144) {
+                const int y = ty0 + 2 * wave + (nn >> 3), x = tx0 + (nn & 7);
+                const int ti = tap / 3, tj = tap - ti * 3;
+                int hl = ty0, wl = tx0;
+                float lh = 0.f, lw = 0.f, m = 0.f;
+                if (y < p.Ho && x < p.Wo) {
+                    const float h_im = (float)(y - 1 + ti) + l_oh[r];
+                    const float w_im = (float)(x - 1 + tj) + l_ow[r];
+                    if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                        m = 1.f;
+                        if (p.mask) {
+                            m = l_ml[r];
+                            if (p.mask_sigmoid) m = __frcp_rn(1.0f + __expf(-m));
+                        }
+                        hl = (int)floorf(h_im);
+                        wl = (int)floorf(w_im);
+                        lh = h_im - (float)hl;
+                        lw = w_im - (float)wl;
+                    }
+                }
+                *(i32x4*)(geo + buf * kWinGeo + wave * kWinGeoWave + e * 16) = i32x4{(hl + 1) | ((wl + 1) << 16), f2i(lh), f2i(lw), f2i(m)};
+                leaves |= !((unsigned)(hl - (ty0 - kWinP)) <= (unsigned)(kWinD - 2) && (unsigned)(wl - (tx0 - kWinP)) <= (unsigned)(kWinD - 2));
+            }
+        }
+        return __builtin_amdgcn_ballot_w64(leaves) != 0;         // wave-uniform: this wave's tile needs the global-gather path somewhere
+    };
+
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7fffffff, 0x00020000);
+    int t = tile_of(0);
+    bool slow = false, slow_next = false;
+    if (t < ntiles) {
+        issue_window(t, 0);
+        issue_logits(t);
+        slow = write_geometry(t, 0);
+    }
+    for (int k = 0; t < ntiles; ++k) {
+        const int buf = k & 1;
+        // the window of this tile (DMA issued a whole tile ago) must have landed; the only younger VMEM operations of this wave are
+        // the previous tile's two (unconditional) output stores, which need not be waited for
+        if (k == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int tn = tile_of(k + 1);
+        if (tn < ntiles) {
+            issue_window(tn, buf ^ 1);
+            issue_logits(tn);
+        }
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+        const char* W0 = win + buf * kWinBytes;
+        char* G0 = geo + buf * kWinGeo + wave * kWinGeoWave;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // The nine taps as straight-line code (FAST: every sample of this wave's tile inside the window -- known since the geometry
+        // was computed -- so no branch separates the taps and the next tap's LDS reads are scheduled under this tap's blend), or with
+        // the per-tap window test and the global-gather fallback (SLOW).
+        auto taps = [&](auto slow_c) {
+        constexpr bool SLOW = decltype(slow_c)::value;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const i32x4 ge = *(const i32x4*)(G0 + (tap * 16 + n) * 16);
+            const int hl = (ge[0] & 0xffff) - 1, wl = (int)((uint32_t)ge[0] >> 16) - 1;
+            const float lh = i2f(ge[1]), lw = i2f(ge[2]), m = i2f(ge[3]);
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            float w[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[c] *= m;                  // the modulation folded into the weights, as in dcn_nhwc_kernel
+            const int wy = hl - (ty0 - kWinP), wx = wl - (tx0 - kWinP);
+            const bool inwin = (unsigned)wy <= (unsigned)(kWinD - 2) && (unsigned)wx <= (unsigned)(kWinD - 2);
+            i32x4 cv[2][4];
+            if (!SLOW || __builtin_amdgcn_ballot_w64(!inwin) == 0) {
+                const int pw = wy * kWinD + wx;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int q = pw + (c >> 1) * kWinD + (c & 1);
+                    const int a0 = q * 128 + ((g ^ ((q >> 1) & 7)) << 4);
+                    cv[0][c] = *(const i32x4*)(W0 + a0);
+                    cv[1][c] = *(const i32x4*)(W0 + (a0 ^ 64));              // vector g + 4: the swizzled slot differs in bit 2 only
+                }
+            } else {
+                // some sample of this (wave, tap) leaves the window: gather every corner from global memory (out-of-image -> zeros)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int y = hl + (c >> 1), x = wl + (c & 1);
+                    const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                    const uint32_t off = ok ? (uint32_t)((b * p.in_sb + y * p.in_sy + x * p.in_sx + g * 8) * 2) : kOOBw;
+                    cv[0][c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));
+                    cv[1][c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off + 64 : kOOBw, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                float vals[8];
+                if constexpr (std::is_same<T, hf16>::value) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        vals[2 * d] = mix_fma_lo(cv[sx][3][d], w[3], mix_fma_lo(cv[sx][2][d], w[2], mix_fma_lo(cv[sx][1][d], w[1], mix_mul_lo(cv[sx][0][d], w[0]))));
+                        vals[2 * d + 1] = mix_fma_hi(cv[sx][3][d], w[3], mix_fma_hi(cv[sx][2][d], w[2], mix_fma_hi(cv[sx][1][d], w[1], mix_mul_hi(cv[sx][0][d], w[0]))));
+                    }
+                } else {
+                    Vec16<T> c1, c2, c3, c4;
+                    c1.raw = cv[sx][0]; c2.raw = cv[sx][1]; c3.raw = cv[sx][2]; c4.raw = cv[sx][3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vals[e] = fmaf(w[3], c4.get(e), fmaf(w[2], c3.get(e), fmaf(w[1], c2.get(e), w[0] * c1.get(e))));
+                }
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) {
+                    const i32x4 fa = *(const i32x4*)(wts + (((tap * 2 + sx) * 4 + blk) * 64 + lane) * 16);
+                    Fmt16<T>::mfma16(fa, o.raw, acc[blk]);
+                }
+            }
+        }
+        };
+        if (slow) taps(std::true_type{});
+        else taps(std::false_type{});
+        // ---- epilogue: bias, folded BN, ReLU; the wave's 16 pixels x 64 channels parked in its own geometry slot, out as whole lines
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = (acc[blk][e] + cb[blk][e]) * cs[blk][e] + ct[blk][e];
+                if (p.relu) x = fmaxf(x, 0.f);
+                v[e] = x;
+            }
+            i32x2 o2;
+            o2[0] = Fmt16<T>::pack2(v[0], v[1]);
+            o2[1] = Fmt16<T>::pack2(v[2], v[3]);
+            *(i32x2*)(G0 + n * 128 + (blk * 16 + g * 4) * 2) = o2;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = lane + 64 * r, px = j >> 3, part = j & 7;
+            const int y = ty0 + 2 * wave + (px >> 3), x = tx0 + (px & 7);
+            const i32x4 val = *(const i32x4*)(G0 + px * 128 + part * 16);
+            const uint32_t off = (y < p.Ho && x < p.Wo) ? (uint32_t)((b * p.out_sb + y * p.out_sy + x * p.out_sx) * 2 + part * 16) : kOOBw;
+            __builtin_amdgcn_raw_buffer_store_b128(val, out_rsrc, off, 0, 0);      // always issued (the vmcnt count above relies on it)
+        }
+        if (tn < ntiles) slow_next = write_geometry(tn, buf ^ 1);
+        slow = slow_next;
+        t = tn;
+    }
+}
+
 // ---- sampled columns in HBM (large output-channel counts) -------------------------------------------------------------
 // The fused kernel above produces a pixel tile's sampled columns once per BN <= 256 output channels: with O = 2176 (the DCNv2
 // head of BASELINE config 3) the gather + blend is repeated 9 times and the launch takes 12 ms.  For such layers the columns
@@ -681,8 +958,36 @@ int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
     return vd3d_check_launch("deform_conv(nhwc)");
 }
 
+// the LDS-window kernel: 16-bit, 3x3 / s1 / p1 / d1, C = O = 64, line-aligned NHWC output, tensors addressable with 32-bit offsets
+static bool dcn_win64_ok(const DcnArgs& a, int es) {
+    const int64_t in_span = ((int64_t)(a.B - 1) * a.in_sb + (int64_t)(a.H - 1) * a.in_sy + (int64_t)(a.W - 1) * a.in_sx + a.C) * es;
+    return es == 2 && a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.dh == 1 && a.dw == 1 && a.Cg == 64 &&
+           a.C == 64 && a.O == 64 && a.Kpad >= 576 && a.H < 32768 && a.W < 32768 && in_span < 0x7ffffff0ll &&
+           a.out_sx % 8 == 0 && a.out_sy % 8 == 0 && a.out_sb % 8 == 0 && ((uintptr_t)a.out & 15) == 0 &&
+           ((int64_t)(a.B - 1) * a.out_sb + (int64_t)(a.H - 1) * a.out_sy + (int64_t)(a.W - 1) * a.out_sx + a.O) * es < 0x7ffffff0ll &&
+           vd3d_switch(VD3D_SW_DCN_WINDOW);       // OPT-IN (measured slower than the gather kernel, see the kernel's header)
+}
+
+template <typename T>
+int launch_dcn_win64(const DcnArgs& a, hipStream_t s) {
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)dcn_win64_kernel<T>, kWinLds, lim, "hipFuncSetAttribute(dcn_win64)")) return rc;
+    const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
+    const int64_t ntiles = (int64_t)a.B * tiles_x * tiles_y;
+    if (ntiles > 0x7fffffff) return VD3D_ERANGE;
+    const int cus = vd3d_device_cu_count();
+    if (cus < 8) return VD3D_ELAUNCH;
+    int64_t grid = (ntiles + 7) / 8 * 8;                       // a multiple of 8: one lane of workgroups per XCD
+    if (grid > cus / 8 * 8) grid = cus / 8 * 8;
+    hipLaunchKernelGGL(dcn_win64_kernel<T>, dim3((unsigned)grid), dim3(256), kWinLds, s, a, (int)ntiles, tiles_x, tiles_y);
+    return vd3d_check_launch("deform_conv(window)");
+}
+
 template <typename T>
 int dispatch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (dcn_win64_ok(a, 2)) return launch_dcn_win64<T>(a, s);
+    }
     if (a.O > 128) return launch_dcn_nhwc<T, 256>(a, s);
     if (a.O > 64) return launch_dcn_nhwc<T, 128>(a, s);
     return launch_dcn_nhwc<T, 64>(a, s);

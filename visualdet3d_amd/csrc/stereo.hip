@@ -282,6 +282,7 @@ __global__ void __launch_bounds__(256) cost_volume_fused_kernel(const short* __r
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* mid = smem;                                  // [D][MY][MX] x 16 B (8 bf16 channels)
     short* outt = (short*)(smem + (size_t)D * MY * MX * 16);   // [TY * TX][F * D]
+    float* wst = (float*)smem;                         // prologue only: the fp32 weights of both convs, staged for the fragment build
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, q = lane >> 4;
     int t = blockIdx.x;
     const int xt = t % xtiles; t /= xtiles;
@@ -290,7 +291,13 @@ __global__ void __launch_bounds__(256) cost_volume_fused_kernel(const short* __r
     const int y0 = yt * TY, x0 = xt * TX;
     const short* lb = left + (int64_t)b * H * W * ips;
     const short* rb = right + (int64_t)b * H * W * ips;
-    // weight fragments of both convs: row = output channel l16 (rows >= 8 zero), k = this lane's 8 (tap, channel) values
+    // ---- weights: coalesced into LDS, then every lane gathers its A-fragment values (row = output channel l16, rows >= 8 zero;
+    // k = this lane's 8 (tap, channel) values).  (Built straight from global memory the 168 scattered 4-byte loads per lane were
+    // ~10 us of a 90 us kernel.)
+    constexpr int NW1 = 27 * 16 * F, NW2 = 27 * 8 * F;
+    for (int i = tid; i < NW1; i += 256) wst[i] = w1[i];
+    for (int i = tid; i < NW2; i += 256) wst[NW1 + i] = w2[i];
+    __syncthreads();
     i32x4 wf1[14], wf2[7];
 #pragma unroll
     for (int s = 0; s < 14; ++s) {
@@ -298,8 +305,8 @@ __global__ void __launch_bounds__(256) cost_volume_fused_kernel(const short* __r
         Vec16<short> o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float a = (l16 < F && tap < 27) ? w1[(tap * 16 + ch + 2 * e) * F + l16] : 0.f;
-            const float c = (l16 < F && tap < 27) ? w1[(tap * 16 + ch + 2 * e + 1) * F + l16] : 0.f;
+            const float a = (l16 < F && tap < 27) ? wst[(tap * 16 + ch + 2 * e) * F + l16] : 0.f;
+            const float c = (l16 < F && tap < 27) ? wst[(tap * 16 + ch + 2 * e + 1) * F + l16] : 0.f;
             o.set2(e, a, c);
         }
         wf1[s] = o.raw;
@@ -310,18 +317,40 @@ __global__ void __launch_bounds__(256) cost_volume_fused_kernel(const short* __r
         Vec16<short> o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float a = (l16 < F && tap < 27) ? w2[(tap * 8 + 2 * e) * F + l16] : 0.f;
-            const float c = (l16 < F && tap < 27) ? w2[(tap * 8 + 2 * e + 1) * F + l16] : 0.f;
+            const float a = (l16 < F && tap < 27) ? wst[NW1 + (tap * 8 + 2 * e) * F + l16] : 0.f;
+            const float c = (l16 < F && tap < 27) ? wst[NW1 + (tap * 8 + 2 * e + 1) * F + l16] : 0.f;
             o.set2(e, a, c);
         }
         wf2[s] = o.raw;
     }
+    __syncthreads();                                   // the staging area is `mid` from here on
     float sc1[4], sh1[4], sc2[4], sh2[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int o = (4 * q + e) & 7;
         sc1[e] = s1[o]; sh1[e] = t1[o]; sc2[e] = s2[o]; sh2[e] = t2[o];
     }
+    // this lane's tap of every K slice is FIXED (slice s, lane quarter q): its (kd, ky, kx) displacement and the element offset of
+    // its source pixel relative to the voxel's own pixel are computed once, not per voxel (the kernel was integer-ALU bound)
+    //   conv 1: left operand (q even): pixel (y + dy, x + dx);  right operand (q odd): pixel (y + dy, x + dx - (d + dd))
+    int g1[14], o1[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int tap = s * 2 + (q >> 1);
+        const int kd = tap / 9, ky = (tap - kd * 9) / 3, kx = tap - kd * 9 - ky * 3;
+        const int dd = kd - 1, dy = ky - 1, dx = kx - 1;
+        g1[s] = tap < 27 ? ((dd + 1) | ((dy + 1) << 2) | ((dx + 1) << 4)) : -1;
+        o1[s] = (dy * W + dx - ((q & 1) ? dd : 0)) * ips;
+    }
+    int g2[7], o2[7];
+#pragma unroll
+    for (int s = 0; s < 7; ++s) {
+        const int tap = s * 4 + q;
+        const int kd = tap / 9, ky = (tap - kd * 9) / 3, kx = tap - kd * 9 - ky * 3;
+        g2[s] = tap < 27 ? (kd - 1) : -100;
+        o2[s] = (((kd - 1) * MY + ky) * MX + kx) * 16;                  // byte offset inside `mid` relative to voxel (d, ty, tx)'s halo origin
+    }
+    const short* srcb = (q & 1) ? rb : lb;
     // ---- phase 1: first conv on the haloed tile -> mid (LDS)
     const int nmid = D * MY * MX;
     for (int g = wave; g * 16 < nmid; g += 4) {
@@ -331,30 +360,26 @@ __global__ void __launch_bounds__(256) cost_volume_fused_kernel(const short* __r
         const int mx = vv % MX, my = (vv / MX) % MY, d = vv / (MX * MY);
         const int y = y0 - 1 + my, x = x0 - 1 + mx;
         const bool img = vin && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const int base = (y * W + x - ((q & 1) ? d : 0)) * ips;         // this lane's source pixel for the centre tap
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 14; ++s) {
-            const int tap = s * 2 + (q >> 1);
-            const int kd = tap / 9, ky = (tap - kd * 9) / 3, kx = tap - kd * 9 - ky * 3;
-            const int id = d - 1 + kd, iy = y - 1 + ky, ix = x - 1 + kx;
-            const bool ok = img && tap < 27 && (unsigned)id < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ix >= id;
+            const int id = d + (g1[s] & 3) - 1, iy = y + ((g1[s] >> 2) & 3) - 1, ix = x + ((g1[s] >> 4) & 3) - 1;
+            const bool ok = img && g1[s] >= 0 && (unsigned)id < (unsigned)D && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && ix >= id;
             i32x4 frag = {0, 0, 0, 0};
-            if (ok) {
-                const short* src = (q & 1) ? rb + ((int64_t)iy * W + (ix - id)) * ips : lb + ((int64_t)iy * W + ix) * ips;
-                frag = *(const i32x4*)src;
-            }
+            if (ok) frag = *(const i32x4*)(srcb + base + o1[s]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf1[s]), __builtin_bit_cast(bf16x8, frag), acc, 0, 0, 0);
         }
         if (vin && q < 2) {
-            i32x2 o2 = {0, 0};
+            i32x2 o2v = {0, 0};
             if (img) {
                 float r[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) r[e] = fmaxf(acc[e] * sc1[e] + sh1[e], 0.f);
-                o2[0] = Fmt16<short>::pack2(r[0], r[1]);
-                o2[1] = Fmt16<short>::pack2(r[2], r[3]);
+                o2v[0] = Fmt16<short>::pack2(r[0], r[1]);
+                o2v[1] = Fmt16<short>::pack2(r[2], r[3]);
             }
-            *(i32x2*)(mid + (size_t)v * 16 + q * 8) = o2;
+            *(i32x2*)(mid + (size_t)v * 16 + q * 8) = o2v;
         }
     }
     __syncthreads();
@@ -365,14 +390,12 @@ __global__ void __launch_bounds__(256) cost_volume_fused_kernel(const short* __r
         const bool vin = v < nout;
         const int vv = vin ? v : 0;
         const int tx = vv % TX, ty = (vv / TX) % TY, d = vv / (TX * TY);
+        const char* mbase = mid + (size_t)((d * MY + ty) * MX + tx) * 16;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 7; ++s) {
-            const int tap = s * 4 + q;
-            const int kd = tap / 9, ky = (tap - kd * 9) / 3, kx = tap - kd * 9 - ky * 3;
-            const int id = d - 1 + kd;
             i32x4 frag = {0, 0, 0, 0};
-            if (vin && tap < 27 && (unsigned)id < (unsigned)D) frag = *(const i32x4*)(mid + (size_t)((id * MY + ty + ky) * MX + tx + kx) * 16);
+            if (vin && (unsigned)(d + g2[s]) < (unsigned)D) frag = *(const i32x4*)(mbase + o2[s]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf2[s]), __builtin_bit_cast(bf16x8, frag), acc, 0, 0, 0);
         }
         if (vin && q < 2) {
@@ -475,9 +498,10 @@ extern "C" int vd3d_cost_volume_fused(const void* left, const void* right, const
         return VD3D_EINVAL;
     }
     if (B == 0) return VD3D_OK;
-    constexpr int TY = 2, TX = 40;
+    constexpr int TY = 2, TX = 20;                 // 384 workgroups at 8 x 24 x 80 (2 x 40 tiles: 192 workgroups of long serial loops, 92 us)
     const int xtiles = (W + TX - 1) / TX, ytiles = (H + TY - 1) / TY;
-    const int lds = D * (TY + 2) * (TX + 2) * 16 + TY * TX * F * D * 2;
+    int lds = D * (TY + 2) * (TX + 2) * 16 + TY * TX * F * D * 2;
+    if (lds < (27 * 16 * 8 + 27 * 8 * 8) * 4) lds = (27 * 16 * 8 + 27 * 8 * 8) * 4;      // the prologue's weight staging
     const int vec_out = ((F * D) % 8 == 0) && (ops % 8 == 0) && (((uintptr_t)out & 15) == 0);
     static Vd3dLdsLimit lim;
     if (const int rc = vd3d_raise_lds_limit((const void*)cost_volume_fused_kernel<TY, TX>, lds, lim, "hipFuncSetAttribute(cost_volume_fused)")) return rc;
