@@ -122,6 +122,11 @@ int vd3d_maxpool2x2(const void* in, void* out, int B, int H, int W, int C, int i
  * out: [B][H/4][W/4][out_pix_stride >= 64] bf16.  Needs 64 output channels, H/4 % 8 == 0, W/4 % 16 == 0. */
 int vd3d_stem_conv_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out,
                         int B, int H, int W, int Kpad, int out_pix_stride, void* stream);
+/* The same fused stem reading the fp32 NCHW image(s) -- the reference's network input -- directly: batch entries [0, B0) come from img0
+ * ([B0][3][H][W]), [B0, B0 + B1) from img1 (stereo: left, right; B1 = 0: one tensor).  No packed copy, no vd3d_pack_image_nhwc4 launch;
+ * results are bit-identical to packing first (the bf16 rounding of the image is the same single rounding). */
+int vd3d_stem_conv_pool_f32(const float* img0, int B0, const float* img1, int B1, const void* weight, const float* scale,
+                            const float* shift, void* out, int H, int W, int Kpad, int out_pix_stride, void* stream);
 
 /* Depth-wise nn.ConvTranspose2d(C, C, 2f, stride f, padding f/2, groups C, bias False) on NHWC (backbones/dla_utils.py:69-71)
  * fused with the `+ layers[i-1]` that follows it (:83); weight [(2f)^2][C] fp32; add may be NULL. */

@@ -217,3 +217,22 @@ def test_conv_batch_chunking_for_large_views(monkeypatch):
     monkeypatch.setattr(ops, '_MAX_IN_BYTES', 2 * 16 * 32 * 192 * 2 + 100)
     got = ops.conv2d(xv, pc, residual=res, relu=True)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('B0,B1,H,W', [(2, 2, 128, 192), (3, 0, 96, 320), (8, 8, 384, 1280)])
+def test_fused_stem_reads_the_fp32_image_directly(B0, B1, H, W):
+    """vd3d_stem_conv_pool_f32 (conv 7x7/s2 + BN + ReLU + max pool straight from the fp32 NCHW image(s): no packed copy, no pack
+    launch) against the round-2 path (vd3d_pack_image_nhwc4 + vd3d_stem_conv_pool): the bf16 rounding of the image is the same single
+    rounding and the MFMA sequence is unchanged -> BIT-IDENTICAL pooled maps; stereo (two tensors stacked on the batch axis by the
+    kernel), one tensor, ragged last workgroup round, the bench size."""
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(B0 * 10 + B1)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    bn = (torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5, 1e-5)
+    pc = ops.pack_stem_conv(w.cuda(), tuple(t.cuda() if torch.is_tensor(t) else t for t in bn), torch.bfloat16)
+    imgs = [torch.randn(B0, 3, H, W, generator=g).cuda()] + ([torch.randn(B1, 3, H, W, generator=g).cuda()] if B1 else [])
+    a = ops.stem_conv_pool(imgs, pc, torch.bfloat16)
+    b = ops.stem_conv_pool(imgs, pc, torch.bfloat16, packed_first=True)
+    torch.cuda.synchronize()
+    assert a.shape == b.shape == (B0 + B1, H // 4, W // 4, 64)
+    assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()

@@ -84,3 +84,29 @@ def test_cost_volume_fused_launch_equals_the_three_launch_path(B, H, W, D):
     ref = orc.cost_volume(c, 'cv', xs[:B], xs[B:], 16 * D, 16)
     got = a.float().cpu().permute(0, 3, 1, 2)
     assert ((got - ref).abs().max() / ref.abs().max()).item() < 2e-2
+
+
+@pytest.mark.parametrize('B,C,H,W,D', [(2, 64, 5, 83, 24), (1, 128, 3, 160, 24), (2, 256, 2, 37, 24), (1, 64, 4, 16, 8), (1, 512, 2, 50, 32)])
+def test_psm_cosine_mfma_kernel_vs_valu_kernel_and_oracle(B, C, H, W, D):
+    """psm_cosine_mfma_kernel (banded product on v_mfma_f32_16x16x32, fragments straight from global memory; bf16, C % 32 == 0: every
+    shape the detectors launch) against the VALU kernel it replaces (VD3D_PSM_VALU=1) and the oracle: same bf16 operands, fp32
+    accumulation in a different order -> within ONE bf16 ulp (+ the fp32 summation noise); zeros for x < d exact; ragged rows
+    (W not a multiple of 16), D = 8 / 24 / 32, a channel-slice output."""
+    from visualdet3d_amd import _lib, hip_ops as ops
+    g = torch.Generator().manual_seed(C + W)
+    L = torch.randn(B, H, W, C, generator=g).cuda().to(torch.bfloat16)
+    R = torch.randn(B, H, W, C, generator=g).cuda().to(torch.bfloat16)
+    buf = torch.full((B, H, W, D + 16), 3.0, dtype=torch.bfloat16, device='cuda')
+    a = ops.psm_cosine(L, R, D, out=buf[..., 8:8 + D])
+    with _lib.test_switch('VD3D_PSM_VALU'):
+        b = ops.psm_cosine(L, R, D)
+    torch.cuda.synchronize()
+    assert bool((buf[..., :8] == 3.0).all()) and bool((buf[..., 8 + D:] == 3.0).all())
+    c = orc.Ctx({}, orc.bf16_round)
+    ref = orc.psm_cosine(c, L.float().cpu().permute(0, 3, 1, 2), R.float().cpu().permute(0, 3, 1, 2), D * 4, 4).permute(0, 2, 3, 1)
+    sc = ref.abs().max().item()
+    for got, what in ((a.float().cpu(), 'mfma'), (b.float().cpu(), 'valu')):
+        d = (got - ref).abs()
+        assert (d / (ref.abs() * 2.0 ** -7 + 3e-5 * sc)).max().item() <= 1.0, what
+        for dd in range(1, D):
+            assert bool((got[:, :, :min(dd, W), dd] == 0).all()), what

@@ -54,7 +54,8 @@ def build(c):
 
 
 def main():
-    only = sys.argv[1:]
+    eager = '--eager' in sys.argv          # no hipGraph: every dispatch visible to a rocprofv3 --pmc pass, 3 forwards
+    only = [a for a in sys.argv[1:] if a != '--eager']
     for name, c in CONFIGS.items():
         if only and not any(o in name for o in only):
             continue
@@ -63,6 +64,12 @@ def main():
             for _ in range(2):
                 m.forward_device(*inputs)
             torch.cuda.synchronize()
+            if eager:
+                for _ in range(3):
+                    m.forward_device(*inputs)
+                torch.cuda.synchronize()
+                print('%-76s eager: 3 forwards' % name, flush=True)
+                continue
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):

@@ -22,13 +22,18 @@ run() {  # name, rocprof args..., -- bench args
     timeout 600 rocprofv3 "$@" > $OUT/$name.log 2>&1
     echo "[$name] rc=$?"
 }
-run trace_overlap --kernel-trace --stats -d $OUT/trace_overlap -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline
-run trace_serial --kernel-trace --stats -d $OUT/trace_serial -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap
-run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline
-run pmc_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline
-run pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-overlap --no-cpu-baseline
+run trace_overlap --kernel-trace --stats -d $OUT/trace_overlap -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs
+run trace_serial --kernel-trace --stats -d $OUT/trace_serial -- python $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-configs --no-overlap
+run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-other-configs
+run pmc_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-other-configs
+run pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-overlap --no-cpu-baseline --no-other-configs
 run trace_c3 --kernel-trace --stats -d $OUT/trace_c3 -- python $ROOT/tools/bench_configs.py "C3 Stereo3D R50 +"
 run trace_c5 --kernel-trace --stats -d $OUT/trace_c5 -- python $ROOT/tools/bench_configs.py "fp16 (as BASELINE"
+# config 5's own SQ / traffic passes (DCN and fused-head kernels), eager launches so that every dispatch carries its counters
+run pmc_c5_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_c5_sq -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
+run pmc_c5_valu --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/pmc_c5_valu -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
+run pmc_c5_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_c5_fetch -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
+run pmc_c5_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_c5_write -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
 cd $ROOT
 db() { find $OUT/$1 -name "*.db" | sort | tail -1; }
 python tools/rocpd_stats.py $(db trace_overlap) > $OUT/${TAG}_kernel_stats.csv
@@ -38,6 +43,10 @@ grep '^{' $OUT/trace_serial.log | tail -1 > $OUT/${TAG}_serial_bench.json
 grep '^{' $OUT/trace_overlap.log | tail -1 > $OUT/${TAG}_overlap_bench_under_rocprof.json
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json
 python tools/rocpd_pmc_table.py $OUT/pmc_sq conv_ > $OUT/${TAG}_sq_pmc.txt
+{ echo "# BASELINE config 5 (KM3D DLA-34, fp16, 16 x 512 x 1760), eager launches: DCN and fused-head kernels"; echo "## SQ pass"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq "true, 32, 0, 0, true" | tail -n +2;
+  echo "## instruction mix"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu "true, 32, 0, 0, true" | tail -n +2;
+  echo "## FETCH_SIZE (x2 for bytes on gfx950: 32-byte units reported as 64)"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch "true, 32, 0, 0, true" | tail -n +2;
+  echo "## WRITE_SIZE"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write "true, 32, 0, 0, true" | tail -n +2; } > $OUT/${TAG}_c5_pmc.txt 2>&1
 python tools/serial_roofline_check.py $OUT/${TAG}_serial_kernel_stats.csv $OUT/${TAG}_serial_bench.json > $OUT/${TAG}_serial_roofline_check.txt
 cat $OUT/${TAG}_serial_roofline_check.txt
 python tools/rocpd_stats.py $(db trace_c3) > $OUT/${TAG}_c3_kernel_stats.csv
@@ -47,5 +56,5 @@ python tools/layer_table.py "C3 Stereo3D R50 +" 2>/dev/null | grep -v amdgpu > $
 python tools/layer_table.py "fp16 (as BASELINE" 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_c5_km3d_conv_layers.txt
 python tools/bench_configs.py 2>/dev/null | grep 'img/s' > $OUT/${TAG}_bench_configs.txt
 # the rocpd databases stay on the box (too big); only the summaries travel back
-rm -rf $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5
+rm -rf $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5 $OUT/pmc_c5_sq $OUT/pmc_c5_valu $OUT/pmc_c5_fetch $OUT/pmc_c5_write
 ls -la $OUT

@@ -25,7 +25,7 @@ if _NAME != 'libvd3d_hip.so':
 VD3D_BF16 = 0
 VD3D_F32 = 1
 VD3D_F16 = 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -118,6 +118,7 @@ SIGNATURES = {
     'vd3d_km3d_workspace_bytes': (c_int64, [c_int] * 5),
     'vd3d_km3d_decode': (c_int, [C.POINTER(Km3dParams), c_void_p]),
     'vd3d_stem_conv_pool': (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    'vd3d_stem_conv_pool_f32': (c_int, [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     'vd3d_kitti_postpath': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     'vd3d_preprocess_image': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vd3d_rotate_iou_eval': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

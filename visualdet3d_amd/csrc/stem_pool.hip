@@ -27,6 +27,8 @@ constexpr int kLds = kInStages * kInStage + kStaging + 512;
 constexpr uint32_t kOOB = 0x80000000u;
 
 struct StemArgs {
+    const float* img0; const float* img1; int B0;     // F32IN: the fp32 NCHW image(s): batch entries [0, B0) from img0, [B0, B) from img1
+    int H, W;
     const char* packed;
     const char* weight;
     const float* scale;
@@ -37,6 +39,10 @@ struct StemArgs {
     int ntiles;
 };
 
+// F32IN: the patch comes straight from the fp32 NCHW image (the reference's network input) -- converted to the NHWC4 16-bit LDS image
+// in registers, one tile ahead -- instead of by LDS-DMA from a packed copy: the two pack_image launches (2 x 17 us, 94 MB read + 64 MB
+// written + 64 MB re-read per step) disappear.
+template <bool F32IN>
 __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
     constexpr int NW = 8, HP = 3;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -90,6 +96,45 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + d_piece[it] * 1024), 16, off, 0, 0, 0);
         }
     };
+    // F32IN: chunk c = tid + 512 it (two NHWC4 pixels) of the patch <- 6 floats of the three image planes, prefetched into registers
+    float pre[HP][6];
+    auto load_patch = [&](int t) {
+        const bool tv = t < p.ntiles;
+        const int tt = tv ? t : 0;
+        const int b = tt / tiles_img, trem = tt - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int y0 = 4 * ty * kTPY - 5, x0 = 4 * tx * kTPX - 5;          // image coordinates of the patch origin (packed - 3)
+        const float* img = b < p.B0 ? p.img0 + (size_t)b * 3 * p.H * p.W : p.img1 + (size_t)(b - p.B0) * 3 * p.H * p.W;
+#pragma unroll
+        for (int it = 0; it < HP; ++it) {
+            const int c = tid + 512 * it;
+            const int r = c / kCPR, j = c - r * kCPR;
+            const int y = y0 + r, x = x0 + 2 * j;
+            const bool rowv = tv && c < kChunks && (unsigned)y < (unsigned)p.H;
+            const bool v0 = rowv && (unsigned)x < (unsigned)p.W, v1 = rowv && (unsigned)(x + 1) < (unsigned)p.W;
+            const float* src = img + (size_t)y * p.W + x;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                pre[it][2 * ch] = v0 ? src[(size_t)ch * p.H * p.W] : 0.f;
+                pre[it][2 * ch + 1] = v1 ? src[(size_t)ch * p.H * p.W + 1] : 0.f;
+            }
+        }
+    };
+    auto store_patch = [&](int stage) {
+        char* base = smem + stage * kInStage;
+#pragma unroll
+        for (int it = 0; it < HP; ++it) {
+            const int c = tid + 512 * it;
+            if (c < kPieces * 64) {       // the tail of the last 1 KiB piece is written too (zeros), like the DMA did
+                i32x4 o;
+                o[0] = Fmt16<short>::pack2(pre[it][0], pre[it][2]);
+                o[1] = Fmt16<short>::pack2(pre[it][4], 0.f);
+                o[2] = Fmt16<short>::pack2(pre[it][1], pre[it][3]);
+                o[3] = Fmt16<short>::pack2(pre[it][5], 0.f);
+                *(i32x4*)(base + c * 16) = o;
+            }
+        }
+    };
     // conv pixel q of block blk for this lane; fragment byte = ((2cy + ky)*36 + cx + 2ks + half)*16
     constexpr int MAXB = (kNBLK + 3) / 4;
     int q_of[MAXB], fbase[MAXB], cy_of[MAXB], cx_of[MAXB];
@@ -106,16 +151,29 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
 
     const int nwg = gridDim.x;
     int t = blockIdx.x;
-    issue_patch(t, 0);
-    issue_patch(t + nwg, 1);
+    if constexpr (F32IN) {
+        load_patch(t);
+        store_patch(0);
+    } else {
+        issue_patch(t, 0);
+        issue_patch(t + nwg, 1);
+    }
     int stage = 0;
     for (; t < p.ntiles; t += nwg) {
+        if constexpr (F32IN) {
+            // patch(k) was written to its stage by every wave at the end of tile k-1 (or in the prologue); pool phase k-1 is done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            load_patch(t + nwg);                                       // next tile's pixels travel under this tile's MFMAs
+        } else {
         // patch(k) landed for every wave; pool phase of tile k-1 finished -> staging and input stage (k-1)%3 are free
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HP) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int st2 = stage >= 1 ? stage - 1 : kInStages - 1;      // (k+2) % 3 == (k-1) % 3
         issue_patch(t + 2 * nwg, st2);
+        }
 
         const int b = t / tiles_img, trem = t - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -177,32 +235,59 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
             *(s16x8*)(p.out + (pix * p.out_pix_stride + s * 8) * 2) = m;
         }
         stage = stage + 1 == kInStages ? 0 : stage + 1;
+        if constexpr (F32IN) store_patch(stage);     // stage (k+1) % 3 was last read by the conv phase of tile k-2: long done
     }
 }
 
 }  // namespace
 
-extern "C" int vd3d_stem_conv_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out,
-                                   int B, int H, int W, int Kpad, int out_pix_stride, void* stream) {
-    if (!packed || !weight || !out) { vd3d_set_error("stem_conv_pool: null pointer"); return VD3D_EINVAL; }
-    if (B <= 0 || H <= 0 || W <= 0 || H % 4 || W % 4 || (H / 4) % kTPY || (W / 4) % kTPX || Kpad < 224 || out_pix_stride < 64 ||
-        out_pix_stride % 8 || ((uintptr_t)packed & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) {
-        vd3d_set_error("stem_conv_pool: needs H/4 % 8 == 0, W/4 % 16 == 0, Kpad >= 224, 16-byte aligned pointers / rows");
-        return VD3D_EINVAL;
-    }
-    StemArgs a;
-    a.packed = (const char*)packed; a.weight = (const char*)weight; a.scale = scale; a.shift = shift; a.out = (char*)out;
-    a.B = B; a.Hp = H + 6; a.Wp = W + 8; a.Ho = H / 2; a.Wo = W / 2; a.Hq = H / 4; a.Wq = W / 4; a.Kpad = Kpad;
+static int launch_stem(StemArgs& a, int B, int H, int W, int Kpad, int out_pix_stride, bool f32in, hipStream_t stream) {
+    a.B = B; a.H = H; a.W = W; a.Hp = H + 6; a.Wp = W + 8; a.Ho = H / 2; a.Wo = W / 2; a.Hq = H / 4; a.Wq = W / 4; a.Kpad = Kpad;
     a.out_pix_stride = out_pix_stride;
-    const int64_t in_bytes = (int64_t)B * a.Hp * a.Wp * 8;
-    if (in_bytes > 0x7ffffff0ll) { vd3d_set_error("stem_conv_pool: packed image exceeds 2 GiB; split the batch"); return VD3D_ERANGE; }
-    a.in_bytes = (uint32_t)in_bytes;
     a.ntiles = B * (a.Hq / kTPY) * (a.Wq / kTPX);
-    static Vd3dLdsLimit lim;
-    if (const int rc = vd3d_raise_lds_limit((const void*)stem_pool_kernel, kLds, lim, "hipFuncSetAttribute(stem_pool)")) return rc;
     const int num_cu = vd3d_device_cu_count();
     if (num_cu <= 0) return VD3D_ELAUNCH;
     const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
-    hipLaunchKernelGGL(stem_pool_kernel, dim3(grid), dim3(512), kLds, (hipStream_t)stream, a);
+    static Vd3dLdsLimit lim0, lim1;
+    if (f32in) {
+        if (const int rc = vd3d_raise_lds_limit((const void*)stem_pool_kernel<true>, kLds, lim1, "hipFuncSetAttribute(stem_pool)")) return rc;
+        hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(512), kLds, stream, a);
+    } else {
+        if (const int rc = vd3d_raise_lds_limit((const void*)stem_pool_kernel<false>, kLds, lim0, "hipFuncSetAttribute(stem_pool)")) return rc;
+        hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(512), kLds, stream, a);
+    }
     return vd3d_check_launch("stem_conv_pool");
+}
+
+static bool stem_shape_ok(int B, int H, int W, int Kpad, int out_pix_stride) {
+    return B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && (H / 4) % kTPY == 0 && (W / 4) % kTPX == 0 && Kpad >= 224 && out_pix_stride >= 64 &&
+           out_pix_stride % 8 == 0;
+}
+
+extern "C" int vd3d_stem_conv_pool(const void* packed, const void* weight, const float* scale, const float* shift, void* out,
+                                   int B, int H, int W, int Kpad, int out_pix_stride, void* stream) {
+    if (!packed || !weight || !out) { vd3d_set_error("stem_conv_pool: null pointer"); return VD3D_EINVAL; }
+    if (!stem_shape_ok(B, H, W, Kpad, out_pix_stride) || ((uintptr_t)packed & 15) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) {
+        vd3d_set_error("stem_conv_pool: needs H/4 % 8 == 0, W/4 % 16 == 0, Kpad >= 224, 16-byte aligned pointers / rows");
+        return VD3D_EINVAL;
+    }
+    StemArgs a = {};
+    a.packed = (const char*)packed; a.weight = (const char*)weight; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    const int64_t in_bytes = (int64_t)B * (H + 6) * (W + 8) * 8;
+    if (in_bytes > 0x7ffffff0ll) { vd3d_set_error("stem_conv_pool: packed image exceeds 2 GiB; split the batch"); return VD3D_ERANGE; }
+    a.in_bytes = (uint32_t)in_bytes;
+    return launch_stem(a, B, H, W, Kpad, out_pix_stride, false, (hipStream_t)stream);
+}
+
+extern "C" int vd3d_stem_conv_pool_f32(const float* img0, int B0, const float* img1, int B1, const void* weight, const float* scale,
+                                       const float* shift, void* out, int H, int W, int Kpad, int out_pix_stride, void* stream) {
+    if (!img0 || (B1 > 0 && !img1) || !weight || !out || B0 <= 0 || B1 < 0) { vd3d_set_error("stem_conv_pool_f32: null pointer / empty batch"); return VD3D_EINVAL; }
+    if (!stem_shape_ok(B0 + B1, H, W, Kpad, out_pix_stride) || ((uintptr_t)weight & 15) || ((uintptr_t)out & 15)) {
+        vd3d_set_error("stem_conv_pool_f32: needs H/4 % 8 == 0, W/4 % 16 == 0, Kpad >= 224, 16-byte aligned weight / output");
+        return VD3D_EINVAL;
+    }
+    StemArgs a = {};
+    a.img0 = img0; a.img1 = img1; a.B0 = B0;
+    a.weight = (const char*)weight; a.scale = scale; a.shift = shift; a.out = (char*)out;
+    return launch_stem(a, B0 + B1, H, W, Kpad, out_pix_stride, true, (hipStream_t)stream);
 }

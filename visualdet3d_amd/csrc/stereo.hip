@@ -102,6 +102,71 @@ __global__ void __launch_bounds__(256) psm_cosine_kernel(const T* __restrict__ l
     }
 }
 
+// PSM cosine volume on the matrix cores (bf16, C % 32 == 0).  cost[x, d] = (1/C) L[x] . R[x - d] is a BANDED product: for 16
+// consecutive pixels the needed right-image window is [x_g - 32, x_g + 15] = three 16-pixel blocks, so per 32-channel step a wave issues
+// v_mfma_f32_16x16x32 (A = 16 left pixels x 32 channels, B = 32 channels x 16 window pixels) three times and keeps the 16 x 24 band of the
+// 16 x 48 products (50 % of the MFMA work is discarded -- the pipe is idle anyway: the kernel streams).  Fragments come straight from
+// global memory (a lane's 16 bytes are 8 channels of one pixel; the window's 3x re-read stays in L1 / L2), no LDS staging, no workgroup
+// barrier, any number of waves in flight; the band leaves through a 1 KiB per-wave LDS tile as whole 16-byte vectors.
+// The VALU kernel above stages L / R single-buffered behind two barriers per 64-channel chunk, leaves one wave of four idle for D = 24
+// and is FMA-issue bound (2.3 TB/s at 8 x 96 x 320 x 64, 0.6-1.9 TB/s on the R50 maps); it remains the fp32 path.
+__global__ void __launch_bounds__(256) psm_cosine_mfma_kernel(const short* __restrict__ left, const short* __restrict__ right,
+                                                              short* __restrict__ cost, int W, int C, int D, int ips, int ops,
+                                                              int groups_x, int64_t ngroups, int vec_store) {
+    __shared__ __attribute__((aligned(16))) short tile[4][16][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, kg = lane >> 4;
+    const float inv = 1.0f / (float)C;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += (int64_t)gridDim.x * 4) {
+        const int64_t row = g / groups_x;                          // b * H + y
+        const int xg = (int)(g - row * groups_x) * 16;
+        const int64_t rowbase = row * W;
+        f32x4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool av = xg + n < W;
+        const short* ap = left + (rowbase + xg + n) * ips + kg * 8;
+        const short* bp[3];
+        bool bv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int wpx = xg - 32 + 16 * j + n;
+            bv[j] = wpx >= 0 && wpx < W;
+            bp[j] = right + (rowbase + wpx) * ips + kg * 8;
+        }
+        for (int k0 = 0; k0 < C; k0 += 32) {
+            i32x4 a = {0, 0, 0, 0}, b0 = {0, 0, 0, 0}, b1 = {0, 0, 0, 0}, b2 = {0, 0, 0, 0};
+            if (av) a = *(const i32x4*)(ap + k0);
+            if (bv[0]) b0 = *(const i32x4*)(bp[0] + k0);
+            if (bv[1]) b1 = *(const i32x4*)(bp[1] + k0);
+            if (bv[2]) b2 = *(const i32x4*)(bp[2] + k0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b0), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b1), acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b2), acc[2], 0, 0, 0);
+        }
+        // accumulator (col n = window pixel, rows 4 kg + e = left pixel m): disparity d = m - n + 32 - 16 j; the 16 x D band -> LDS
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = 4 * kg + e, d = m - n + 32 - 16 * j;
+                if (d >= 0 && d < D) tile[wave][m][d] = f2bf(acc[j][e] * inv);     // x < d: the window pixel was out of the row -> exact 0
+            }
+        if (vec_store) {
+            const int nvec = D >> 3;
+            for (int i = lane; i < 16 * nvec; i += 64) {
+                const int pxl = i / nvec, part = i - pxl * nvec;
+                if (xg + pxl < W) *(i32x4*)(cost + (rowbase + xg + pxl) * ops + part * 8) = *(const i32x4*)&tile[wave][pxl][part * 8];
+            }
+        } else {
+            for (int i = lane; i < 16 * D; i += 64) {
+                const int pxl = i / D, d = i - pxl * D;
+                if (xg + pxl < W) cost[(rowbase + xg + pxl) * ops + d] = tile[wave][pxl][d];
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void costvol_build_kernel(const T* __restrict__ left, const T* __restrict__ right, T* __restrict__ vol,
                                      int B, int H, int W, int F, int D, int ips) {
@@ -441,7 +506,16 @@ extern "C" int vd3d_psm_cosine(const void* left, const void* right, void* cost, 
     const int xtiles = (W + XT - 1) / XT;
     const int64_t grid = (int64_t)B * H * xtiles;
     const int lds = (XT + XT + D - 1) * 128;
-    if (dtype == VD3D_BF16)
+    if (dtype == VD3D_BF16 && C % 32 == 0 && !vd3d_switch(VD3D_SW_PSM_VALU)) {
+        const int groups_x = (W + 15) / 16;
+        const int64_t ngroups = (int64_t)B * H * groups_x;
+        const int cus = vd3d_device_cu_count();
+        if (cus <= 0) return VD3D_ELAUNCH;
+        const int64_t want = (ngroups + 3) / 4;
+        const int g2 = (int)(want < (int64_t)cus * 8 ? want : (int64_t)cus * 8);
+        hipLaunchKernelGGL(psm_cosine_mfma_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, (const short*)left, (const short*)right,
+                           (short*)cost, W, C, D, ips, ops, groups_x, ngroups, vec_store && D % 8 == 0);
+    } else if (dtype == VD3D_BF16)
         hipLaunchKernelGGL(psm_cosine_kernel<short>, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream,
                            (const short*)left, (const short*)right, (short*)cost, H, W, C, D, ips, ops, xtiles, vec_store);
     else if (dtype == VD3D_F32)

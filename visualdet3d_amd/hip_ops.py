@@ -207,13 +207,28 @@ def stem_pool_supported(H, W, dtype, Cout):
     return dtype == torch.bfloat16 and Cout == 64 and H % 4 == 0 and W % 4 == 0 and (H // 4) % 8 == 0 and (W // 4) % 16 == 0
 
 
-def stem_conv_pool(img_nchw, pc, dtype):
-    """Stem conv 7x7/s2 + BN + ReLU + MaxPool(3, 2, 1) fused (vd3d_stem_conv_pool): returns the pooled NHWC map."""
-    packed, B, H, W = _pack_stem_images(img_nchw, dtype)
+def stem_conv_pool(img_nchw, pc, dtype, packed_first=False):
+    """Stem conv 7x7/s2 + BN + ReLU + MaxPool(3, 2, 1) fused: returns the pooled NHWC map.  One or two fp32 NCHW image tensors
+    (stereo: left, right -- stacked on the batch axis by the kernel) are read DIRECTLY (vd3d_stem_conv_pool_f32);
+    ``packed_first=True``: the round-2 path (vd3d_pack_image_nhwc4 per tensor, then vd3d_stem_conv_pool on the packed copy)."""
+    imgs = list(img_nchw) if isinstance(img_nchw, (list, tuple)) else [img_nchw]
+    if packed_first or len(imgs) > 2:
+        packed, B, H, W = _pack_stem_images(img_nchw, dtype)
+        assert stem_pool_supported(H, W, dtype, pc.Cout)
+        out = torch.empty((B, H // 4, W // 4, 64), dtype=dtype, device=packed.device)
+        check(_lib.lib().vd3d_stem_conv_pool(_p(packed), _p(pc.w), _p(pc.scale) if pc.scale is not None else None, _p(pc.shift), _p(out),
+                                             B, H, W, pc.Kpad, 64, _stream()), 'vd3d_stem_conv_pool')
+        return out
+    _require_cuda(*imgs)
+    _, Cc, H, W = imgs[0].shape
+    for t in imgs:
+        assert t.shape[1:] == (3, H, W) and t.dtype == torch.float32 and t.is_contiguous()
     assert stem_pool_supported(H, W, dtype, pc.Cout)
-    out = torch.empty((B, H // 4, W // 4, 64), dtype=dtype, device=packed.device)
-    check(_lib.lib().vd3d_stem_conv_pool(_p(packed), _p(pc.w), _p(pc.scale) if pc.scale is not None else None, _p(pc.shift), _p(out),
-                                         B, H, W, pc.Kpad, 64, _stream()), 'vd3d_stem_conv_pool')
+    B0, B1 = int(imgs[0].shape[0]), (int(imgs[1].shape[0]) if len(imgs) == 2 else 0)
+    out = torch.empty((B0 + B1, H // 4, W // 4, 64), dtype=dtype, device=imgs[0].device)
+    check(_lib.lib().vd3d_stem_conv_pool_f32(_p(imgs[0]), B0, _p(imgs[1]) if B1 else None, B1, _p(pc.w),
+                                             _p(pc.scale) if pc.scale is not None else None, _p(pc.shift), _p(out), H, W, pc.Kpad, 64, _stream()),
+          'vd3d_stem_conv_pool_f32')
     return out
 
 
