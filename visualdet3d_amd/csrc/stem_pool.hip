@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
     };
     // F32IN: chunk c = tid + 512 it (two NHWC4 pixels) of the patch <- 6 floats of the three image planes, prefetched into registers
     float pre[HP][6];
+    typedef f32x2 __attribute__((aligned(4))) f32x2_u;       // a pixel pair starts at an odd x: 4-byte aligned 8-byte loads
     auto load_patch = [&](int t) {
         const bool tv = t < p.ntiles;
         const int tt = tv ? t : 0;
@@ -105,18 +106,27 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
         const int y0 = 4 * ty * kTPY - 5, x0 = 4 * tx * kTPX - 5;          // image coordinates of the patch origin (packed - 3)
         const float* img = b < p.B0 ? p.img0 + (size_t)b * 3 * p.H * p.W : p.img1 + (size_t)(b - p.B0) * 3 * p.H * p.W;
+        const size_t plane = (size_t)p.H * p.W;
 #pragma unroll
         for (int it = 0; it < HP; ++it) {
+            // UNCONDITIONAL loads (a border pixel pair is fetched from the clamped position and shifted / zeroed afterwards): no
+            // exec-masked branches in front of the MFMA phase, three 8-byte loads per chunk, lanes = consecutive pixel pairs
             const int c = tid + 512 * it;
-            const int r = c / kCPR, j = c - r * kCPR;
+            const int cc = c < kChunks ? c : kChunks - 1;
+            const int r = cc / kCPR, j = cc - r * kCPR;
             const int y = y0 + r, x = x0 + 2 * j;
-            const bool rowv = tv && c < kChunks && (unsigned)y < (unsigned)p.H;
-            const bool v0 = rowv && (unsigned)x < (unsigned)p.W, v1 = rowv && (unsigned)(x + 1) < (unsigned)p.W;
-            const float* src = img + (size_t)y * p.W + x;
+            const int yc = y < 0 ? 0 : (y >= p.H ? p.H - 1 : y);
+            const int xc = x < 0 ? 0 : (x > p.W - 2 ? p.W - 2 : x);
+            const int sh = x - xc;                                          // 0: (lo, hi); -1: (0, lo); +1: (hi, 0); else (0, 0)
+            const bool rowv = tv && c < kChunks && y == yc;
+            const float* src = img + (size_t)yc * p.W + xc;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                pre[it][2 * ch] = v0 ? src[(size_t)ch * p.H * p.W] : 0.f;
-                pre[it][2 * ch + 1] = v1 ? src[(size_t)ch * p.H * p.W + 1] : 0.f;
+                const f32x2 v = *(const f32x2_u*)(src + ch * plane);
+                const float a0 = sh == 0 ? v[0] : (sh == 1 ? v[1] : 0.f);
+                const float a1 = sh == 0 ? v[1] : (sh == -1 ? v[0] : 0.f);
+                pre[it][2 * ch] = rowv ? a0 : 0.f;
+                pre[it][2 * ch + 1] = rowv ? a1 : 0.f;
             }
         }
     };

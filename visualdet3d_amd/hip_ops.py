@@ -6,6 +6,7 @@ channel-slice view of a wider buffer (``buf[..., off:off+C]``) -- that is how ``
 fused away: producers write straight into their slice of the concat buffer.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -207,12 +208,15 @@ def stem_pool_supported(H, W, dtype, Cout):
     return dtype == torch.bfloat16 and Cout == 64 and H % 4 == 0 and W % 4 == 0 and (H // 4) % 8 == 0 and (W // 4) % 16 == 0
 
 
+_STEM_PACKED = bool(os.environ.get('VD3D_STEM_PACKED'))     # A/B: the round-2 path (pack launches + LDS-DMA stem)
+
+
 def stem_conv_pool(img_nchw, pc, dtype, packed_first=False):
     """Stem conv 7x7/s2 + BN + ReLU + MaxPool(3, 2, 1) fused: returns the pooled NHWC map.  One or two fp32 NCHW image tensors
     (stereo: left, right -- stacked on the batch axis by the kernel) are read DIRECTLY (vd3d_stem_conv_pool_f32);
     ``packed_first=True``: the round-2 path (vd3d_pack_image_nhwc4 per tensor, then vd3d_stem_conv_pool on the packed copy)."""
     imgs = list(img_nchw) if isinstance(img_nchw, (list, tuple)) else [img_nchw]
-    if packed_first or len(imgs) > 2:
+    if packed_first or len(imgs) > 2 or _STEM_PACKED:
         packed, B, H, W = _pack_stem_images(img_nchw, dtype)
         assert stem_pool_supported(H, W, dtype, pc.Cout)
         out = torch.empty((B, H // 4, W // 4, 64), dtype=dtype, device=packed.device)
