@@ -9,8 +9,8 @@ import sys
 path = sys.argv[1]
 if os.path.isdir(path):
     path = sorted(glob.glob(os.path.join(path, '**', '*.db'), recursive=True))[-1]
-first = sys.argv[2] if len(sys.argv) > 2 else 'pack_image'
-per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 2      # launches of that kernel per step (stereo: left, right)
+first = sys.argv[2] if len(sys.argv) > 2 else "stem_pool_kernel"
+per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 1      # launches of that kernel per step
 db = sqlite3.connect(path)
 cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
