@@ -246,9 +246,18 @@ def test_window_kernel_is_bit_identical_to_the_global_gather_kernel(dtype, B, H,
     with _lib.test_switch('VD3D_DCN_WINDOW'):                     # opt-in kernel (measured slower than the gather kernel: not the default)
         a = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], buf[..., 64:], 'nhwc', **kw)
     b = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
+    buf2 = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
+    with _lib.test_switch('VD3D_DCN_KSPLIT'):                     # the K-split window kernel: two partial sums added in fp32 -> not bit-identical
+        c = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], buf2[..., :64], 'nhwc', **kw)
     torch.cuda.synchronize()
-    assert bool((buf[..., :64] == 3.0).all()), 'wrote outside the channel slice'
+    assert bool((buf[..., :64] == 3.0).all()) and bool((buf2[..., 64:] == 3.0).all()), 'wrote outside the channel slice'
     assert torch.equal(a, b), 'max diff %.3e at sigma %.1f' % ((a.float() - b.float()).abs().max().item(), sigma)
+    # K-split: (sum over channels 0-31) + (sum over channels 32-63) instead of one 64-long MFMA chain per tap: same operands, fp32
+    # summation order differs -> within one ulp of the format (+ the summation noise of a 576-long dot product)
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    dd = (c.float() - b.float()).abs()
+    assert bool((dd <= b.float().abs() * ulp + 3e-5 * b.float().abs().max()).all()), 'k-split kernel: max diff %.3e' % dd.max().item()
+    assert (dd > 0).float().mean().item() < 0.05
     # and against the oracle (pinned to the reference's own im2col code): same bar as the engine-path test above
     rnd = lambda t: t.to(dtype).float()                             # noqa: E731
     y = dcn_ref.deform_conv_forward(rnd(x).permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), torch.sigmoid(msk).permute(0, 3, 1, 2), wt, bias,

@@ -19,8 +19,14 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
+
+// compile-time loop (a `#pragma unroll` over a register array indexed by the loop variable may stay rolled and move the array to scratch)
+template <int I> struct DIntC { static constexpr int value = I; };
+template <int... Is, class F> VD3D_DEV void d_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(DIntC<Is>{}), ...); }
+template <int N, class F> VD3D_DEV void static_for(F&& f) { d_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 struct DcnArgs {
     const void* in; const void* w; const float* bias; const float* scale; const float* shift;
@@ -767,6 +773,304 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// ---- 64 -> 64 channel DCNv2, second design: the window kernel above with TWO waves per SIMD ---------------------------------------
+// dcn_win64_kernel lost to the gather kernel because 151 KB of LDS (74 KB of it weights) left one wave per SIMD.  Here the weights live
+// in REGISTERS, split over K: a workgroup is 8 waves = 4 pixel groups (16 pixels of the 8 x 8 tile) x 2 K halves; wave (pg, kh) keeps the
+// A fragments of all 64 output channels x its 32 input channels x 9 taps (36 fragments = 144 VGPRs, as conv_resident64), blends ONLY its
+// 32 channels (one 16-byte vector per lane and tap: 4 corner ds_read_b128, 32 FMAs) and issues 4 MFMAs per tap.  The two K partial sums
+// of a pixel group meet in LDS: the tile's non-owner parks its 16 accumulators, the OWNER (alternating with the tile index, so both waves
+// pay the epilogue on every other tile) adds them at the start of the NEXT iteration -- after that iteration's barrier, so a tile still
+// costs ONE barrier -- and stores whole 128-byte lines (BOTH waves park their partial sums: keeping the owner's in registers across the
+// iteration spilled).  LDS: two 29 KiB windows + geometry + partials = 159 KB, no weights.  Geometry entries carry the four corner
+// addresses (swizzle key included) and the four modulated weights, computed once per (pixel, tap) instead of by the 8 lanes sharing it.
+// MEASURED (round 3, 16 x 128 x 440 fp16, sigma 0.5 px): 329 us against 350 us for the gather kernel on the same box (361 before the
+// precomputed addresses); bf16 537 us (26 spilled registers).  Ablations (runtime flags, removed again): no blend -42 us, no corner
+// reads -26, neither -73, no MFMA 0, no window DMA -32, no logit loads -29, no reduction / epilogue -50, ALL of them off: 188 us --
+// i.e. 3.4 us per 64-pixel tile of barrier, geometry, tile decode and hand-over that no amount of gather tuning removes.  An 8 x 8 tile
+// is too small a unit of work per barrier for a persistent design, and larger tiles do not fit two windows in LDS.  OPT-IN
+// (VD3D_DCN_KSPLIT=1); results differ from the gather kernel by the fp32 order of the two K halves (<= 1 ulp, tests/test_dcn_gpu.py).
+constexpr int kKsGeoGrp = 9 * 16 * 32;                                     // per pixel group: 9 taps x 16 pixels x 32 B
+constexpr int kKsGeo = 4 * kKsGeoGrp, kKsRed = 4 * 2 * 4096;               // per buffer: 4 pixel groups x 2 K halves x 16 accumulators
+constexpr int kKsLdsWin = 0, kKsLdsGeo = 2 * kWinBytes, kKsLdsRed = kKsLdsGeo + 2 * kKsGeo, kKsLdsFlag = kKsLdsRed + 2 * kKsRed;
+constexpr int kKsLdsTab = kKsLdsFlag + 64, kKsLds = kKsLdsTab + 3 * 64 * 4;
+
+template <typename T>
+__global__ void __launch_bounds__(512) dcn_ks64_kernel(const DcnArgs p, int ntiles, int tiles_x, int tiles_y) {
+    static_assert(sizeof(T) == 2, "16-bit formats only");
+    constexpr uint32_t kOOBw = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* win = smem + kKsLdsWin;
+    char* geo = smem + kKsLdsGeo;
+    char* red = smem + kKsLdsRed;
+    int* flags = (int*)(smem + kKsLdsFlag);            // [2 buffers][4 groups][2 waves]
+    float* ctab = (float*)(smem + kKsLdsTab);          // bias | scale | shift
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave >> 1, kh = wave & 1;
+    const int n = lane & 15, g = lane >> 4;
+    const int vsel = kh * 4 + g;                        // this lane's 16-byte vector (8 channels) of a pixel
+    const uint32_t vsel2 = (uint32_t)vsel | ((uint32_t)vsel << 16);
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_xcd = nwg >> 3;
+    const int chunk = (ntiles + 7) >> 3;
+    auto tile_of = [&](int k) { const int i = jx + k * per_xcd; return i < chunk ? xcd * chunk + i : ntiles; };
+    const int tiles_img = tiles_x * tiles_y;
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7fffffff, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    if (tid < 64) {
+        ctab[tid] = p.bias ? p.bias[tid] : 0.f;
+        ctab[64 + tid] = p.scale ? p.scale[tid] : 1.f;
+        ctab[128 + tid] = p.shift ? p.shift[tid] : 0.f;
+    }
+    // ---- weights -> registers: fragment (tap, blk): row blk*16 + n, k = tap*64 + kh*32 + g*8 .. +7
+    i32x4 wf[9][4];
+    {
+        const char* wbase = (const char*)p.w + ((size_t)n * p.Kpad + kh * 32 + g * 8) * 2;
+        static_for<36>([&](auto ic) {
+            constexpr int i = decltype(ic)::value, tap = i / 4, blk = i % 4;
+            wf[tap][blk] = *(const i32x4*)(wbase + ((size_t)blk * 16 * p.Kpad + tap * 64) * 2);
+        });
+    }
+    constexpr int NIT = (kWinPieces + 7) / 8;
+    int d_rel[NIT], d_yx[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = wave + 8 * it, c = q * 64 + lane, pp = c >> 3, sl = c & 7;
+        const int v = sl ^ ((pp >> 1) & 7);
+        const int wy = pp / kWinD, wx = pp - wy * kWinD;
+        d_rel[it] = (int)((wy * p.in_sy + wx * p.in_sx + v * 8) * 2);
+        d_yx[it] = (q < kWinPieces && pp < kWinPix) ? (wy | (wx << 8)) : -1;
+    }
+    auto decode = [&](int t, int& b, int& ty0, int& tx0) {
+        b = t / tiles_img;
+        const int r = t - b * tiles_img, ty = r / tiles_x;
+        ty0 = ty * 8;
+        tx0 = (r - ty * tiles_x) * 8;
+    };
+    auto issue_window = [&](int t, int buf) {
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+        const int base = (int)((b * p.in_sb + (ty0 - kWinP) * p.in_sy + (tx0 - kWinP) * p.in_sx) * 2);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int q = wave + 8 * it;
+            if (q < kWinPieces) {
+                const int wy = d_yx[it] & 255, wx = (d_yx[it] >> 8) & 255;
+                const bool ok = d_yx[it] >= 0 && (unsigned)(ty0 - kWinP + wy) < (unsigned)p.H && (unsigned)(tx0 - kWinP + wx) < (unsigned)p.W;
+                const uint32_t off = ok ? (uint32_t)(base + d_rel[it]) : kOOBw;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(win + buf * kWinBytes + q * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    // geometry entries of this pixel group: e = r*128 + kh*64 + lane (tap e >> 4, pixel e & 15), split between the pair's two waves
+    float l_oh[2], l_ow[2], l_ml[2];
+    auto issue_logits = [&](int t) {
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = r * 128 + kh * 64 + lane, tap = e >> 4, nn = e & 15;
+            const int y = ty0 + 2 * pg + (nn >> 3), x = tx0 + (nn & 7);
+            l_oh[r] = l_ow[r] = l_ml[r] = 0.f;
+            if (e < 144 && y < p.Ho && x < p.Wo) {
+                const int64_t ob = b * p.off_sb + y * p.off_sy + x * p.off_sx;
+                l_oh[r] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
+                l_ow[r] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+                if (p.mask) l_ml[r] = p.mask[b * p.msk_sb + y * p.msk_sy + x * p.msk_sx + (int64_t)tap * p.msk_sc];
+            }
+        }
+    };
+    auto write_geometry = [&](int t, int buf) {
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+        bool leaves = false;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int e = r * 128 + kh * 64 + lane, tap = e >> 4, nn = e & 15;
+            if (e < 144) {
+                const int y = ty0 + 2 * pg + (nn >> 3), x = tx0 + (nn & 7);
+                const int ti = tap / 3, tj = tap - ti * 3;
+                int hl = ty0, wl = tx0;
+                float lh = 0.f, lw = 0.f, m = 0.f;
+                if (y < p.Ho && x < p.Wo) {
+                    const float h_im = (float)(y - 1 + ti) + l_oh[r];
+                    const float w_im = (float)(x - 1 + tj) + l_ow[r];
+                    if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
+                        m = 1.f;
+                        if (p.mask) {
+                            m = l_ml[r];
+                            if (p.mask_sigmoid) m = __frcp_rn(1.0f + __expf(-m));
+                        }
+                        hl = (int)floorf(h_im);
+                        wl = (int)floorf(w_im);
+                        lh = h_im - (float)hl;
+                        lw = w_im - (float)wl;
+                    }
+                }
+                // entry (32 B): { (h_low + 1) | (w_low + 1) << 16,  a0 | a1 << 16,  a2 | a3 << 16,  0,  w0, w1, w2, w3 } with a_c = LDS
+                // address of corner c's pixel in 16-byte units INCLUDING its swizzle key (a lane adds its own vector by XOR) and
+                // w_c = bilinear weight x modulation: computed ONCE per (pixel, tap) here instead of by all 8 lanes that share it
+                const int wy = hl - (ty0 - kWinP), wx = wl - (tx0 - kWinP);
+                const bool inw = (unsigned)wy <= (unsigned)(kWinD - 2) && (unsigned)wx <= (unsigned)(kWinD - 2);
+                leaves |= !inw;
+                uint32_t ac[4] = {0, 0, 0, 0};
+                if (inw) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int q = (wy + (c >> 1)) * kWinD + wx + (c & 1);
+                        ac[c] = (uint32_t)(q * 8 + ((q >> 1) & 7));
+                    }
+                }
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) w4[c] *= m;
+                char* ge = geo + buf * kKsGeo + pg * kKsGeoGrp + e * 32;
+                *(i32x4*)ge = i32x4{(hl + 1) | ((wl + 1) << 16), (int)(ac[0] | (ac[1] << 16)), (int)(ac[2] | (ac[3] << 16)), 0};
+                *(f32x4*)(ge + 16) = f32x4{w4[0], w4[1], w4[2], w4[3]};
+            }
+        }
+        const int any = __builtin_amdgcn_ballot_w64(leaves) != 0;
+        if (lane == 0) flags[(buf * 4 + pg) * 2 + kh] = any;
+    };
+
+    int t = tile_of(0);
+    if (t < ntiles) {
+        issue_window(t, 0);
+        issue_logits(t);
+        write_geometry(t, 0);
+    }
+    int t_prev = ntiles;                                // tile whose reduction + epilogue is still due
+    // finish tile `tp` (iteration kp): the owner adds the partner's parked partial sums, applies bias / BN / ReLU, parks the 16 pixels x
+    // 64 channels in the same LDS region and stores whole lines
+    auto finish = [&](int tp, int kp) {
+        if (kh != (kp & 1)) return;                    // wave-uniform: not the owner of that tile
+        int b, ty0, tx0;
+        decode(tp, b, ty0, tx0);
+        char* R0 = red + (kp & 1) * kKsRed + pg * 8192;
+        f32x4 fin[4];
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const f32x4 mine = *(const f32x4*)(R0 + kh * 4096 + (blk * 64 + lane) * 16);
+            const f32x4 other = *(const f32x4*)(R0 + (kh ^ 1) * 4096 + (blk * 64 + lane) * 16);
+            const f32x4 bz = *(const f32x4*)(ctab + blk * 16 + g * 4), sc = *(const f32x4*)(ctab + 64 + blk * 16 + g * 4),
+                        sh = *(const f32x4*)(ctab + 128 + blk * 16 + g * 4);
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = ((mine[e] + other[e]) + bz[e]) * sc[e] + sh[e];
+                if (p.relu) x = fmaxf(x, 0.f);
+                v[e] = x;
+            }
+            fin[blk] = f32x4{v[0], v[1], v[2], v[3]};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the partner's partials are in registers: the region becomes the parking tile
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            i32x2 o2;
+            o2[0] = Fmt16<T>::pack2(fin[blk][0], fin[blk][1]);
+            o2[1] = Fmt16<T>::pack2(fin[blk][2], fin[blk][3]);
+            *(i32x2*)(R0 + n * 128 + (blk * 16 + g * 4) * 2) = o2;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int j = lane + 64 * r, px = j >> 3, part = j & 7;
+            const int y = ty0 + 2 * pg + (px >> 3), x = tx0 + (px & 7);
+            const i32x4 val = *(const i32x4*)(R0 + px * 128 + part * 16);
+            const uint32_t off = (y < p.Ho && x < p.Wo) ? (uint32_t)((b * p.out_sb + y * p.out_sy + x * p.out_sx) * 2 + part * 16) : kOOBw;
+            __builtin_amdgcn_raw_buffer_store_b128(val, out_rsrc, off, 0, 0);
+        }
+    };
+    int k = 0;
+    for (; t < ntiles; ++k) {
+        const int buf = k & 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t_prev < ntiles) finish(t_prev, k - 1);
+        const int tn = tile_of(k + 1);
+        if (tn < ntiles) {
+            issue_window(tn, buf ^ 1);
+            issue_logits(tn);
+        }
+        int b, ty0, tx0;
+        decode(t, b, ty0, tx0);
+        const char* W0 = win + buf * kWinBytes;
+        const char* G0 = geo + buf * kKsGeo + pg * kKsGeoGrp;
+        const bool slow = (flags[(buf * 4 + pg) * 2] | flags[(buf * 4 + pg) * 2 + 1]) != 0;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto taps = [&](auto slow_c) {
+            constexpr bool SLOW = decltype(slow_c)::value;
+            static_for<9>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+                const i32x4 ge = *(const i32x4*)(G0 + (tap * 16 + n) * 32);
+                const f32x4 gw = *(const f32x4*)(G0 + (tap * 16 + n) * 32 + 16);
+                const float w[4] = {gw[0], gw[1], gw[2], gw[3]};
+                const int hl = (ge[0] & 0xffff) - 1, wl = (int)((uint32_t)ge[0] >> 16) - 1;
+                bool inwin = true;
+                if constexpr (SLOW) {
+                    const int wy = hl - (ty0 - kWinP), wx = wl - (tx0 - kWinP);
+                    inwin = (unsigned)wy <= (unsigned)(kWinD - 2) && (unsigned)wx <= (unsigned)(kWinD - 2);
+                }
+                i32x4 cv[4];
+                if (!SLOW || __builtin_amdgcn_ballot_w64(!inwin) == 0) {
+                    const uint32_t a01 = (uint32_t)ge[1] ^ vsel2, a23 = (uint32_t)ge[2] ^ vsel2;      // both corners of a pair get the lane's vector
+                    cv[0] = *(const i32x4*)(W0 + ((a01 & 0xffffu) << 4));
+                    cv[1] = *(const i32x4*)(W0 + ((a01 >> 16) << 4));
+                    cv[2] = *(const i32x4*)(W0 + ((a23 & 0xffffu) << 4));
+                    cv[3] = *(const i32x4*)(W0 + ((a23 >> 16) << 4));
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int y = hl + (c >> 1), x = wl + (c & 1);
+                        const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                        const uint32_t off = ok ? (uint32_t)((b * p.in_sb + y * p.in_sy + x * p.in_sx + vsel * 8) * 2) : kOOBw;
+                        cv[c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));
+                    }
+                }
+                float vals[8];
+                if constexpr (std::is_same<T, hf16>::value) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        vals[2 * d] = mix_fma_lo(cv[3][d], w[3], mix_fma_lo(cv[2][d], w[2], mix_fma_lo(cv[1][d], w[1], mix_mul_lo(cv[0][d], w[0]))));
+                        vals[2 * d + 1] = mix_fma_hi(cv[3][d], w[3], mix_fma_hi(cv[2][d], w[2], mix_fma_hi(cv[1][d], w[1], mix_mul_hi(cv[0][d], w[0]))));
+                    }
+                } else {
+                    Vec16<T> c1, c2, c3, c4;
+                    c1.raw = cv[0]; c2.raw = cv[1]; c3.raw = cv[2]; c4.raw = cv[3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vals[e] = fmaf(w[3], c4.get(e), fmaf(w[2], c3.get(e), fmaf(w[1], c2.get(e), w[0] * c1.get(e))));
+                }
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk) Fmt16<T>::mfma16(wf[tap][blk], o.raw, acc[blk]);
+            });
+        };
+        if (slow) taps(std::true_type{});
+        else taps(std::false_type{});
+        // hand-over: both waves of the pair park their partial sums; the tile's owner adds them after the next barrier
+        {
+            char* R0 = red + buf * kKsRed + pg * 8192 + kh * 4096;
+#pragma unroll
+            for (int blk = 0; blk < 4; ++blk) *(f32x4*)(R0 + (blk * 64 + lane) * 16) = acc[blk];
+        }
+        t_prev = t;
+        if (tn < ntiles) write_geometry(tn, buf ^ 1);
+        t = tn;
+    }
+    if (t_prev < ntiles) {                             // the last tile's reduction (uniform over the workgroup: every wave ran k iterations)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        finish(t_prev, k - 1);
+    }
+}
+
 // ---- sampled columns in HBM (large output-channel counts) -------------------------------------------------------------
 // The fused kernel above produces a pixel tile's sampled columns once per BN <= 256 output channels: with O = 2176 (the DCNv2
 // head of BASELINE config 3) the gather + blend is repeated 9 times and the launch takes 12 ms.  For such layers the columns
@@ -959,13 +1263,15 @@ int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
 }
 
 // the LDS-window kernel: 16-bit, 3x3 / s1 / p1 / d1, C = O = 64, line-aligned NHWC output, tensors addressable with 32-bit offsets
-static bool dcn_win64_ok(const DcnArgs& a, int es) {
+static bool dcn_win64_shape_ok(const DcnArgs& a, int es);
+static bool dcn_win64_ok(const DcnArgs& a, int es) { return dcn_win64_shape_ok(a, es) && vd3d_switch(VD3D_SW_DCN_WINDOW); }
+static bool dcn_win64_shape_ok(const DcnArgs& a, int es) {
     const int64_t in_span = ((int64_t)(a.B - 1) * a.in_sb + (int64_t)(a.H - 1) * a.in_sy + (int64_t)(a.W - 1) * a.in_sx + a.C) * es;
     return es == 2 && a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.dh == 1 && a.dw == 1 && a.Cg == 64 &&
            a.C == 64 && a.O == 64 && a.Kpad >= 576 && a.H < 32768 && a.W < 32768 && in_span < 0x7ffffff0ll &&
            a.out_sx % 8 == 0 && a.out_sy % 8 == 0 && a.out_sb % 8 == 0 && ((uintptr_t)a.out & 15) == 0 &&
            ((int64_t)(a.B - 1) * a.out_sb + (int64_t)(a.H - 1) * a.out_sy + (int64_t)(a.W - 1) * a.out_sx + a.O) * es < 0x7ffffff0ll &&
-           vd3d_switch(VD3D_SW_DCN_WINDOW);       // OPT-IN (measured slower than the gather kernel, see the kernel's header)
+           true;
 }
 
 template <typename T>
@@ -984,8 +1290,24 @@ int launch_dcn_win64(const DcnArgs& a, hipStream_t s) {
 }
 
 template <typename T>
+int launch_dcn_ks64(const DcnArgs& a, hipStream_t s) {
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)dcn_ks64_kernel<T>, kKsLds, lim, "hipFuncSetAttribute(dcn_ks64)")) return rc;
+    const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
+    const int64_t ntiles = (int64_t)a.B * tiles_x * tiles_y;
+    if (ntiles > 0x7fffffff) return VD3D_ERANGE;
+    const int cus = vd3d_device_cu_count();
+    if (cus < 8) return VD3D_ELAUNCH;
+    int64_t grid = (ntiles + 7) / 8 * 8;
+    if (grid > cus / 8 * 8) grid = cus / 8 * 8;
+    hipLaunchKernelGGL(dcn_ks64_kernel<T>, dim3((unsigned)grid), dim3(512), kKsLds, s, a, (int)ntiles, tiles_x, tiles_y);
+    return vd3d_check_launch("deform_conv(k-split window)");
+}
+
+template <typename T>
 int dispatch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
+        if (dcn_win64_shape_ok(a, 2) && vd3d_switch(VD3D_SW_DCN_KSPLIT)) return launch_dcn_ks64<T>(a, s);
         if (dcn_win64_ok(a, 2)) return launch_dcn_win64<T>(a, s);
     }
     if (a.O > 128) return launch_dcn_nhwc<T, 256>(a, s);
