@@ -160,78 +160,138 @@ VD3D_DEV void decode_candidate(const HeadArgs& p, int b, int n, float* o, float&
     zok = ms[0] > 0.0f;
 }
 
-// ---- stage 2, single-wave path: at most 64 candidates (the common case: a frame has a few dozen) ---------------------------------
+// ---- stage 2, single-wave path: at most 256 candidates (the common case: a frame has a few dozen to ~200) -----------------------
 // The block-wide path below costs ~70 workgroup barriers of 16 waves (two bitonic sorts, two compactions, chunked NMS): 52 us per
-// step for a dozen boxes.  With <= 64 candidates ONE wave does the same steps with no barrier at all: lane i owns candidate i; both
-// orderings are rank computations over 64 shuffles (keys are unique: anchor index / (score, list position)), compactions are
-// ballots + popcounts, NMS is the wave-synchronous loop of nms_sorted's chunk step.  Same decode function, same comparisons, same
-// tie rule -> the same detections in the same order.
+// step for a dozen boxes.  With <= 256 candidates ONE wave does the same steps with no barrier at all: lane l owns list slots
+// l, l + 64, l + 128, l + 192; both orderings are RANK computations (keys are unique: anchor index / (score, list position)): every
+// lane counts the smaller keys while the key list streams through LDS broadcast reads; compactions are ballots + popcounts; NMS walks
+// the sorted list once, paying the IoU tests only for boxes that are still alive (= the kept ones).  Same decode function, same
+// comparisons, same tie rule -> the same detections in the same order as the block-wide path and the oracle.
+constexpr int kWaveCand = 256, kWaveR = kWaveCand / 64;
 __device__ void head_nms_wave(const HeadArgs& p, int b, int K, char* smem) {
     const int lane = threadIdx.x;                          // wave 0 only
-    float* lbox = (float*)smem;                            // [64][11]   decoded boxes, anchor order
-    float* lscore = lbox + 64 * 11;                        // [64]
-    int* llabel = (int*)(lscore + 64);                     // [64]
-    int* lanchor = llabel + 64;                            // [64]
-    int* perm = lanchor + 64;                              // [64]
+    uint64_t* keys2 = (uint64_t*)smem;                     // [256]
+    f32x4* sbox = (f32x4*)(keys2 + kWaveCand);             // [256]   2D boxes in NMS order
+    float* lbox = (float*)(sbox + kWaveCand);              // [256][11] decoded boxes, anchor order
+    float* lscore = lbox + kWaveCand * 11;                 // [256]
+    int* llabel = (int*)(lscore + kWaveCand);              // [256]
+    int* lanchor = llabel + kWaveCand;                     // [256]
+    uint32_t* list = (uint32_t*)(lanchor + kWaveCand);     // [256]   candidate anchors, list order
+    int* sorted = (int*)(list + kWaveCand);                // [256]   anchor order
+    int* perm = sorted + kWaveCand;                        // [256]   NMS position -> anchor-order slot
+    int* qof = perm + kWaveCand;                           // [256]   anchor-order slot -> filtered position
+    unsigned char* alive = (unsigned char*)(qof + kWaveCand);   // [256]
     const int64_t cb = (int64_t)b * p.max_cand;
-    const bool in = lane < K;
+    const uint64_t lt = (1ull << lane) - 1ull;
     // 1. anchor order
-    const uint32_t n0 = in ? (uint32_t)p.ws.cand_idx[cb + lane] : 0xffffffffu;
-    int r = 0;
-    for (int j = 0; j < 64; ++j) r += (uint32_t)__shfl((int)n0, j) < n0;
-    if (in) perm[r] = (int)n0;
-    const int n = in ? perm[lane] : 0;                     // lane i: the i-th candidate in anchor order
-    // 2. decode
-    float box[11], best = 0.f;
-    int label = 0;
-    bool zok = false;
-    if (in) {
-        decode_candidate(p, b, n, box, best, label, zok);
+    uint32_t n0[kWaveR];
 #pragma unroll
-        for (int e = 0; e < 11; ++e) lbox[lane * 11 + e] = box[e];
-        lscore[lane] = best;
-        llabel[lane] = label;
-        lanchor[lane] = n;
+    for (int r = 0; r < kWaveR; ++r) {
+        const int i = lane + 64 * r;
+        n0[r] = i < K ? (uint32_t)p.ws.cand_idx[cb + i] : 0xffffffffu;
+        list[i] = n0[r];
     }
-    // 3. z-prior filter (order preserving): filtered position q
-    const uint64_t fmask = __builtin_amdgcn_ballot_w64(in && zok);
-    const int q = __builtin_popcountll(fmask & ((1ull << lane) - 1ull));
-    const int Kc = __builtin_popcountll(fmask);
-    // 4. NMS order: score descending, then list position
-    const uint64_t key = (in && zok) ? (((uint64_t)orderable_desc(best) << 32) | (uint32_t)q) : ~0ull;
-    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-    int r2 = 0;
-    for (int j = 0; j < 64; ++j) {
-        const uint64_t kj = ((uint64_t)(uint32_t)__shfl((int)khi, j) << 32) | (uint32_t)__shfl((int)klo, j);
-        r2 += kj < key;
+    int rk[kWaveR] = {0, 0, 0, 0};
+    for (int j = 0; j < K; ++j) {
+        const uint32_t v = list[j];                        // same address in every lane: an LDS broadcast
+#pragma unroll
+        for (int r = 0; r < kWaveR; ++r) rk[r] += v < n0[r];
     }
-    if (in && zok) perm[r2] = lane;
-    const int src = lane < Kc ? perm[lane] : 0;            // lane j: the j-th box in NMS order lives in anchor-order slot src
-    f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-    if (lane < Kc) bj = f32x4{lbox[src * 11 + 0], lbox[src * 11 + 1], lbox[src * 11 + 2], lbox[src * 11 + 3]};
-    const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
-    bool a = lane < Kc;
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r)
+        if (lane + 64 * r < K) sorted[rk[r]] = (int)n0[r];
+    // 2. decode slot i = lane + 64 r of the anchor-ordered list; 3. z-prior filter (order preserving): filtered position q
+    float best[kWaveR];
+    bool zok[kWaveR];
+    int qbase = 0;
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r) {
+        const int i = lane + 64 * r;
+        best[r] = 0.f;
+        zok[r] = false;
+        if (i < K) {
+            const int n = sorted[i];
+            int label;
+            decode_candidate(p, b, n, lbox + i * 11, best[r], label, zok[r]);
+            lscore[i] = best[r];
+            llabel[i] = label;
+            lanchor[i] = n;
+        }
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(i < K && zok[r]);
+        const int q = qbase + __builtin_popcountll(fm & lt);
+        qbase += __builtin_popcountll(fm);
+        if (i < K && zok[r]) {
+            qof[i] = q;
+            keys2[q] = ((uint64_t)orderable_desc(best[r]) << 32) | (uint32_t)q;      // score descending, then list position
+            perm[q] = i;                                                             // (for now: filtered position -> slot)
+        }
+    }
+    const int Kc = qbase;
+    // 4. NMS order: rank of every filtered candidate's key
+    uint64_t myk[kWaveR];
+    int rk2[kWaveR] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r) myk[r] = lane + 64 * r < Kc ? keys2[lane + 64 * r] : ~0ull;      // lane owns filtered positions q = lane + 64 r
+    for (int j = 0; j < Kc; ++j) {
+        const uint64_t v = keys2[j];
+#pragma unroll
+        for (int r = 0; r < kWaveR; ++r) rk2[r] += v < myk[r];
+    }
+    int slot_of[kWaveR];
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r) slot_of[r] = lane + 64 * r < Kc ? perm[lane + 64 * r] : 0;
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r) {
+        if (lane + 64 * r < Kc) {
+            const float* o = lbox + slot_of[r] * 11;
+            sbox[rk2[r]] = f32x4{o[0], o[1], o[2], o[3]};
+        }
+    }
+    // perm is rewritten as NMS position -> anchor-order slot (every lane has read its old entries above: same wave, program order)
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r)
+        if (lane + 64 * r < Kc) perm[rk2[r]] = slot_of[r];
+    // greedy NMS over the sorted list: lane owns sorted positions j = lane + 64 r
+    f32x4 bj[kWaveR];
+    float aj[kWaveR];
+    bool a[kWaveR];
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r) {
+        const int j = lane + 64 * r;
+        a[r] = j < Kc;
+        bj[r] = a[r] ? sbox[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        aj[r] = (bj[r][2] - bj[r][0]) * (bj[r][3] - bj[r][1]);
+        alive[j] = a[r];
+    }
     for (int i = 0; i < Kc; ++i) {
-        const bool ai = __shfl((int)a, i) != 0;
-        if (!ai) continue;  // wave-uniform
-        f32x4 bi;
-        bi[0] = __shfl(bj[0], i); bi[1] = __shfl(bj[1], i); bi[2] = __shfl(bj[2], i); bi[3] = __shfl(bj[3], i);
-        const float areai = __shfl(aj, i);
-        if (lane > i && a && iou_gt(bi, areai, bj, aj, p.nms_thr)) a = false;
-    }
-    const uint64_t kmask = __builtin_amdgcn_ballot_w64(a);
-    const int kept = __builtin_popcountll(kmask);
-    const int o_ = __builtin_popcountll(kmask & ((1ull << lane) - 1ull));
-    const int nout = min(kept, p.max_det);
-    if (a && o_ < nout) {
-        const int64_t ob = (int64_t)b * p.max_det + o_;
+        if (!alive[i]) continue;                           // broadcast read, wave-uniform
+        const f32x4 bi = sbox[i];
+        const float areai = (bi[2] - bi[0]) * (bi[3] - bi[1]);
 #pragma unroll
-        for (int e = 0; e < 11; ++e) p.out_boxes[ob * 11 + e] = lbox[src * 11 + e];
-        p.out_scores[ob] = lscore[src];
-        // the reference's unfiltered-label quirk: the label of the q-th UNFILTERED candidate, q = filtered position of this box
-        const int qs = __builtin_popcountll(fmask & ((1ull << src) - 1ull));
-        p.out_labels[ob] = llabel[qs];
-        p.out_anchor[ob] = lanchor[src];
+        for (int r = 0; r < kWaveR; ++r) {
+            const int j = lane + 64 * r;
+            if (j > i && a[r] && iou_gt(bi, areai, bj[r], aj[r], p.nms_thr)) { a[r] = false; alive[j] = 0; }
+        }
+    }
+    // output compaction in sorted order
+    int obase = 0, kept = 0;
+    uint64_t km[kWaveR];
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r) { km[r] = __builtin_amdgcn_ballot_w64(a[r]); kept += __builtin_popcountll(km[r]); }
+    const int nout = min(kept, p.max_det);
+#pragma unroll
+    for (int r = 0; r < kWaveR; ++r) {
+        const int o_ = obase + __builtin_popcountll(km[r] & lt);
+        obase += __builtin_popcountll(km[r]);
+        if (a[r] && o_ < nout) {
+            const int src = perm[lane + 64 * r];
+            const int64_t ob = (int64_t)b * p.max_det + o_;
+#pragma unroll
+            for (int e = 0; e < 11; ++e) p.out_boxes[ob * 11 + e] = lbox[src * 11 + e];
+            p.out_scores[ob] = lscore[src];
+            p.out_labels[ob] = llabel[qof[src]];           // the reference's unfiltered-label quirk: label of the q-th UNFILTERED candidate
+            p.out_anchor[ob] = lanchor[src];
+        }
     }
     if (lane == 0) p.out_count[b] = kept > p.max_det ? -2 : kept;
 }
@@ -251,7 +311,7 @@ __global__ void __launch_bounds__(kNmsThreads) head_nms_kernel(const HeadArgs p)
         return;
     }
     const int K = cnt;
-    if (K <= 64) {                                         // block-uniform
+    if (K <= kWaveCand) {                                  // block-uniform
         if (threadIdx.x < 64) head_nms_wave(p, b, K, smem);
         return;
     }
@@ -355,7 +415,9 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(const float* __restric
 }
 
 inline int64_t head_nms_lds(int max_cand) {
-    return (int64_t)max_cand * 8 + (int64_t)max_cand * 8 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + max_cand * 2 + 64 + 16;
+    const int64_t block_path = (int64_t)max_cand * 8 + (int64_t)max_cand * 8 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + max_cand * 2 + 64 + 16;
+    const int64_t wave_path = kWaveCand * (8 + 16 + 44 + 4 * 7 + 1) + 64;      // head_nms_wave's carve (24.3 KB)
+    return block_path > wave_path ? block_path : wave_path;
 }
 inline int64_t nms_lds(int n) {
     int P = 1;
