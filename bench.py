@@ -454,6 +454,8 @@ def main():
         model.core.overlap_neck = False
     if os.environ.get('VD3D_BENCH_NOTOWER') or args.no_overlap:
         model.bbox_head.overlap_towers = False
+    if os.environ.get('VD3D_BENCH_NOSELECT'):
+        model.bbox_head.overlap_select = False      # A/B: candidate selection after the towers instead of on the cls tower's stream
     from visualdet3d_amd import hip_ops
 
     feed = None

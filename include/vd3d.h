@@ -211,6 +211,12 @@ typedef struct vd3d_head_params {
 } vd3d_head_params;
 int64_t vd3d_head_workspace_bytes(int B, int max_cand);
 int vd3d_head_postprocess(const vd3d_head_params* p, void* stream);
+/* The two stages of vd3d_head_postprocess as separate entries (ABI >= 3).  vd3d_head_select: ground filter + sigmoid + threshold ->
+ * candidate lists in `workspace`; reads only `cls` (reg / out_* may be NULL), so it can run on the stream of the cls tower while the reg
+ * tower is still computing.  vd3d_head_nms: decode + clip + z-prior filter + NMS over those lists; same parameters, stream-ordered
+ * after the select.  vd3d_head_postprocess == select then nms on one stream. */
+int vd3d_head_select(const vd3d_head_params* p, void* stream);
+int vd3d_head_nms(const vd3d_head_params* p, void* stream);
 
 /* Multi-GPU result record (the only cross-rank traffic is the gather of the padded detections): packs the
  * padded outputs of vd3d_head_postprocess / vd3d_km3d_decode of B frames into ONE contiguous fp32 block

@@ -98,6 +98,8 @@ SIGNATURES = {
     'vd3d_cost_volume_fused': (c_int, [c_void_p] * 9 + [c_int] * 8 + [c_void_p]),
     'vd3d_head_workspace_bytes': (c_int64, [c_int, c_int]),
     'vd3d_head_postprocess': (c_int, [C.POINTER(HeadParams), c_void_p]),
+    'vd3d_head_select': (c_int, [C.POINTER(HeadParams), c_void_p]),
+    'vd3d_head_nms': (c_int, [C.POINTER(HeadParams), c_void_p]),
     'vd3d_pack_detections': (c_int, [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),
     'vd3d_nms': (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     'vd3d_nms_workspace_bytes': (c_int64, [c_int]),

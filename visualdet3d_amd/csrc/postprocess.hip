@@ -429,39 +429,57 @@ inline int64_t nms_lds(int n) {
 
 extern "C" int64_t vd3d_head_workspace_bytes(int B, int max_cand) { return ws_bytes(B, max_cand); }
 
-extern "C" int vd3d_head_postprocess(const vd3d_head_params* q, void* stream) {
-    if (!q || !q->cls || !q->reg || !q->anchors || !q->prior_mean_std || !q->P2 || !q->workspace || !q->out_scores ||
-        !q->out_boxes || !q->out_labels || !q->out_anchor || !q->out_count) {
+static int head_args(const vd3d_head_params* q, HeadArgs& a, bool need_select, bool need_nms) {
+    if (!q || !q->cls || !q->anchors || !q->prior_mean_std || !q->P2 || !q->workspace ||
+        (need_nms && (!q->reg || !q->out_scores || !q->out_boxes || !q->out_labels || !q->out_anchor || !q->out_count))) {
         vd3d_set_error("head_postprocess: null pointer");
         return VD3D_EINVAL;
     }
+    (void)need_select;
     if (q->B <= 0 || q->N <= 0 || q->A <= 0 || q->N % q->A || q->n_cls < 1 || q->n_types < q->n_cls ||
         q->max_cand < 1 || q->max_cand > kMaxSort || (q->max_cand & (q->max_cand - 1)) || q->max_det < 1 ||
         ((uintptr_t)q->anchors & 15)) {
         vd3d_set_error("head_postprocess: bad sizes (max_cand must be a power of two <= 8192)");
         return VD3D_EINVAL;
     }
-    HeadArgs a;
     a.cls = q->cls; a.reg = q->reg; a.anchors = q->anchors; a.prior = q->prior_mean_std; a.P2 = q->P2;
     a.B = q->B; a.N = q->N; a.A = q->A; a.n_cls = q->n_cls; a.n_types = q->n_types; a.img_h = q->img_h; a.img_w = q->img_w;
     a.score_thr = q->score_thr; a.nms_thr = q->nms_iou_thr; a.y_min = q->filter_y_min; a.y_max = q->filter_y_max; a.x_max = q->filter_x_max;
     a.use_filter = q->use_filter; a.max_cand = q->max_cand; a.max_det = q->max_det;
     a.ws = carve(q->workspace, q->B, q->max_cand);
     a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_labels = q->out_labels; a.out_anchor = q->out_anchor; a.out_count = q->out_count;
+    return VD3D_OK;
+}
+
+// stage 1 alone: ground filter + sigmoid + threshold -> the per-sample candidate lists in `workspace`.  Needs only the CLASS logits
+// (reg / out_* may be NULL), so a caller whose cls tower finishes before its reg tower can run it early, on the cls tower's stream.
+extern "C" int vd3d_head_select(const vd3d_head_params* q, void* stream) {
+    HeadArgs a;
+    if (const int rc = head_args(q, a, true, false)) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(zero_counts_kernel, dim3((q->B + 63) / 64), dim3(64), 0, s, a.ws.count, q->B);
     const int64_t total = (int64_t)q->B * q->N;
     int64_t g = (total + kSelThreads - 1) / kSelThreads;
     if (g > 4096) g = 4096;
     hipLaunchKernelGGL(head_select_kernel, dim3((unsigned)g), dim3(kSelThreads), 0, s, a);
-    int rc = vd3d_check_launch("head_select");
-    if (rc) return rc;
+    return vd3d_check_launch("head_select");
+}
+
+// stage 2 alone: decode + clip + z-prior filter + NMS over the candidate lists a vd3d_head_select call with the SAME parameters left
+// in `workspace` (stream-ordered after it).
+extern "C" int vd3d_head_nms(const vd3d_head_params* q, void* stream) {
+    HeadArgs a;
+    if (const int rc = head_args(q, a, false, true)) return rc;
     const int lds = (int)head_nms_lds(q->max_cand);
     static Vd3dLdsLimit lim;
-    rc = vd3d_raise_lds_limit((const void*)head_nms_kernel, lds, lim, "hipFuncSetAttribute(head_nms)");
-    if (rc) return rc;
-    hipLaunchKernelGGL(head_nms_kernel, dim3(q->B), dim3(kNmsThreads), lds, s, a);
+    if (const int rc = vd3d_raise_lds_limit((const void*)head_nms_kernel, lds, lim, "hipFuncSetAttribute(head_nms)")) return rc;
+    hipLaunchKernelGGL(head_nms_kernel, dim3(q->B), dim3(kNmsThreads), lds, (hipStream_t)stream, a);
     return vd3d_check_launch("head_nms");
+}
+
+extern "C" int vd3d_head_postprocess(const vd3d_head_params* q, void* stream) {
+    if (const int rc = vd3d_head_select(q, stream)) return rc;
+    return vd3d_head_nms(q, stream);
 }
 
 __global__ void pack_detections_kernel(const float* __restrict__ scores, const float* __restrict__ boxes, const int32_t* __restrict__ labels,

@@ -422,10 +422,40 @@ def cost_volume_fused(left, right, p0, p1, D, out=None):
     return out
 
 
+def _head_params(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr, use_filter, y_min_max, x_max, max_cand,
+                 max_det, workspace):
+    p = HeadParams()
+    B, N, _ = cls.shape
+    p.cls, p.anchors, p.prior_mean_std, p.P2 = cls.data_ptr(), anchors.data_ptr(), prior.data_ptr(), P2.data_ptr()
+    p.reg = reg.data_ptr() if reg is not None else None
+    p.B, p.N, p.A, p.n_cls, p.n_types = B, N, A, n_cls, n_types
+    p.img_h, p.img_w = int(img_hw[0]), int(img_hw[1])
+    p.score_thr, p.nms_iou_thr = float(score_thr), float(nms_iou_thr)
+    p.filter_y_min, p.filter_y_max, p.filter_x_max = float(y_min_max[0]), float(y_min_max[1]), float(x_max)
+    p.use_filter, p.max_cand, p.max_det = int(use_filter), int(max_cand), int(max_det)
+    p.workspace = workspace.data_ptr()
+    return p
+
+
+def head_select(cls, anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr, use_filter=True, y_min_max=(-0.5, 1.8),
+                x_max=40.0, max_cand=4096, max_det=None, workspace=None):
+    """Stage 1 of the head post-processing on the CURRENT stream (vd3d_head_select): needs only the class logits, so the detector
+    runs it on the cls tower's side stream under the reg tower.  ``P2`` must be fp32 contiguous on the device; ``workspace`` as for
+    ``head_postprocess``.  Finish with ``head_postprocess(..., preselected=True)`` (same arguments) once the streams have joined."""
+    _require_cuda(cls, anchors, prior, P2, workspace)
+    B, N, nc1 = cls.shape
+    assert nc1 == n_cls + 1 and cls.dtype == torch.float32 and cls.is_contiguous() and P2.dtype == torch.float32 and P2.is_contiguous()
+    assert workspace.numel() >= _lib.lib().vd3d_head_workspace_bytes(B, max_cand)
+    p = _head_params(cls, None, anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr, use_filter, y_min_max, x_max,
+                     max_cand, max_det or max_cand, workspace)
+    check(_lib.lib().vd3d_head_select(C.byref(p), _stream()), 'vd3d_head_select')
+
+
 def head_postprocess(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr,
-                     use_filter=True, y_min_max=(-0.5, 1.8), x_max=40.0, max_cand=4096, max_det=None, workspace=None):
+                     use_filter=True, y_min_max=(-0.5, 1.8), x_max=40.0, max_cand=4096, max_det=None, workspace=None, preselected=False):
     """Device-side get_bboxes for a whole batch.  Returns padded (scores [B,K], boxes [B,K,11], labels [B,K] i32,
-    anchor_idx [B,K] i32, count [B] i32) -- all on the device, no host sync."""
+    anchor_idx [B,K] i32, count [B] i32) -- all on the device, no host sync.  ``preselected``: ``head_select`` already ran with the
+    same arguments and workspace (stream-ordered before this call): only the decode / NMS stage is launched."""
     _require_cuda(cls, reg, anchors, prior, P2)
     B, N, nc1 = cls.shape
     assert nc1 == n_cls + 1 and reg.shape == (B, N, 12) and cls.dtype == torch.float32 and reg.dtype == torch.float32
@@ -436,23 +466,21 @@ def head_postprocess(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, sc
     dev = cls.device
     need = _lib.lib().vd3d_head_workspace_bytes(B, max_cand)
     if workspace is None or workspace.numel() < need:
+        assert not preselected, 'preselected=True needs the workspace head_select wrote'
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     scores = torch.empty((B, max_det), dtype=torch.float32, device=dev)
     boxes = torch.empty((B, max_det, 11), dtype=torch.float32, device=dev)
     labels = torch.empty((B, max_det), dtype=torch.int32, device=dev)
     aidx = torch.empty((B, max_det), dtype=torch.int32, device=dev)
     count = torch.empty((B,), dtype=torch.int32, device=dev)
-    p = HeadParams()
-    p.cls, p.reg, p.anchors, p.prior_mean_std, p.P2 = cls.data_ptr(), reg.data_ptr(), anchors.data_ptr(), prior.data_ptr(), P2.data_ptr()
-    p.B, p.N, p.A, p.n_cls, p.n_types = B, N, A, n_cls, n_types
-    p.img_h, p.img_w = int(img_hw[0]), int(img_hw[1])
-    p.score_thr, p.nms_iou_thr = float(score_thr), float(nms_iou_thr)
-    p.filter_y_min, p.filter_y_max, p.filter_x_max = float(y_min_max[0]), float(y_min_max[1]), float(x_max)
-    p.use_filter, p.max_cand, p.max_det = int(use_filter), int(max_cand), int(max_det)
-    p.workspace = workspace.data_ptr()
+    p = _head_params(cls, reg, anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr, use_filter, y_min_max, x_max,
+                     max_cand, max_det, workspace)
     p.out_scores, p.out_boxes, p.out_labels, p.out_anchor, p.out_count = (
         scores.data_ptr(), boxes.data_ptr(), labels.data_ptr(), aidx.data_ptr(), count.data_ptr())
-    check(_lib.lib().vd3d_head_postprocess(C.byref(p), _stream()), 'vd3d_head_postprocess')
+    if preselected:
+        check(_lib.lib().vd3d_head_nms(C.byref(p), _stream()), 'vd3d_head_nms')
+    else:
+        check(_lib.lib().vd3d_head_postprocess(C.byref(p), _stream()), 'vd3d_head_postprocess')
     return scores, boxes, labels, aidx, count
 
 

@@ -71,7 +71,7 @@ class Yolo3D(nn.Module):
             raise RuntimeError('Yolo3D runs on the MI355X HIP path only: move the model and inputs to cuda')
         dtype = self.compute_dtype or fused.default_compute_dtype()
         feat = self.core.forward_nhwc(img_batch, dtype)
-        cls_preds, reg_preds = self.bbox_head.forward_nhwc(dict(features=feat, P2=P2))
+        cls_preds, reg_preds = self.bbox_head.forward_nhwc(dict(features=feat, P2=P2, image=img_batch))
         self._last_raw = (cls_preds, reg_preds)
         return self.bbox_head.get_bboxes_batched(cls_preds, reg_preds, P2, img_batch.shape[2:])
 

@@ -62,6 +62,8 @@ class AnchorBasedDetection3DHead(nn.Module):
         self.overlap_towers = True   # False: run the towers back to back on one stream (per-kernel profiling)
         self.max_candidates = 4096   # per-sample capacity of the device candidate list (power of two <= 8192)
         self._workspace = None
+        self.overlap_select = True   # candidate selection (needs only the cls logits) on the cls tower's side stream, under the reg tower
+        self._preselected = None
 
     # ---- layers ---------------------------------------------------------------------------------------------
     def _cls_tower(self, num_features_in, cls_feature_size, num_anchors, num_cls_output):
@@ -130,12 +132,19 @@ class AnchorBasedDetection3DHead(nn.Module):
         if side is None:
             side = self._side_streams[feat.device] = torch.cuda.Stream(device=feat.device)
         side.wait_stream(main)
+        self._preselected = None
         with torch.cuda.stream(side):
             cls_preds = self._cls_forward_nhwc(feat)
+            if self.overlap_select and not self.training and inputs.get('P2') is not None and inputs.get('image') is not None:
+                # stage 1 of get_bboxes (ground filter + sigmoid + threshold -> candidate lists) only reads the class logits: it runs
+                # here, behind the cls tower, while the reg tower still computes on the main stream (-20 us on the critical path)
+                self._preselected = self._select(cls_preds, inputs['P2'], inputs['image'].shape[2:], clip=True)
         reg_preds = self._reg_forward_nhwc(feat, inputs)
         main.wait_stream(side)
         cls_preds.record_stream(main)
         feat.record_stream(side)
+        if self._workspace is not None:
+            self._workspace.record_stream(side)
         return cls_preds, reg_preds
 
     def forward(self, inputs):
@@ -165,25 +174,47 @@ class AnchorBasedDetection3DHead(nn.Module):
             # the reference's per-class NMS branch cannot run either (`label.float().unsqueeze()` without a dim, :388-389)
             raise NotImplementedError('test_cfg.cls_agnositc=False (per-class NMS) is not implemented: the reference branch '
                                       'itself raises TypeError (detection_3d_head.py:388); only class-agnostic NMS is on the path')
-        dev = cls_preds.device
         self._last_img_hw = (int(img_hw[0]), int(img_hw[1]))
+        args, kw = self._post_args(cls_preds, P2s, img_hw, clip)
+        pre = self._preselected
+        self._preselected = None
+        preselected = pre is not None and pre == self._select_key(cls_preds, args, kw)
+        padded = ops.head_postprocess(cls_preds, reg_preds, *args, preselected=preselected, **kw)
+        if getattr(self.test_cfg, 'post_optimization', False):
+            # detection_3d_head.py:396-398 -> _post_process, here on the padded batch (count < 0 rows are skipped)
+            from ..lib.fast_utils.hill_climbing import post_opt_batch
+            post_opt_batch(padded[1], padded[2], P2s, counts=padded[4])
+        return padded
+
+    def _post_args(self, cls_preds, P2s, img_hw, clip):
+        """positional (anchors, prior, P2, A, n_cls, n_types, img_hw, score_thr, nms_iou_thr) + keyword arguments shared by
+        ops.head_select / ops.head_postprocess; (re)allocates the candidate workspace."""
+        dev = cls_preds.device
         anchors, prior, A = self.anchors.device_tables(img_hw, dev)
         B = cls_preds.shape[0]
         need = ops._lib.lib().vd3d_head_workspace_bytes(B, self.max_candidates)
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
         lo, hi = self.anchors.filter_y_threshold_min_max
-        P2s = P2s.to(dev)
-        padded = ops.head_postprocess(
-            cls_preds, reg_preds, anchors, prior, P2s, A, self.num_classes, len(self.anchors.obj_types), img_hw if clip else (0, 0),
-            getattr(self.test_cfg, 'score_thr', 0.5), getattr(self.test_cfg, 'nms_iou_thr', 0.5),
-            use_filter=bool(self._is_filtering() and self.anchors.readConfigFile), y_min_max=(lo, hi),
-            x_max=self.anchors.filter_x_threshold, max_cand=self.max_candidates, workspace=self._workspace)
-        if getattr(self.test_cfg, 'post_optimization', False):
-            # detection_3d_head.py:396-398 -> _post_process, here on the padded batch (count < 0 rows are skipped)
-            from ..lib.fast_utils.hill_climbing import post_opt_batch
-            post_opt_batch(padded[1], padded[2], P2s, counts=padded[4])
-        return padded
+        P2s = P2s.to(device=dev, dtype=torch.float32).contiguous()
+        args = (anchors, prior, P2s, A, self.num_classes, len(self.anchors.obj_types), tuple(int(v) for v in img_hw) if clip else (0, 0),
+                getattr(self.test_cfg, 'score_thr', 0.5), getattr(self.test_cfg, 'nms_iou_thr', 0.5))
+        kw = dict(use_filter=bool(self._is_filtering() and self.anchors.readConfigFile), y_min_max=(lo, hi),
+                  x_max=self.anchors.filter_x_threshold, max_cand=self.max_candidates, workspace=self._workspace)
+        return args, kw
+
+    @staticmethod
+    def _select_key(cls_preds, args, kw):
+        """what a preselection is valid for: the very logits tensor, calibration tensor, tables and thresholds"""
+        anchors, prior, P2s = args[0], args[1], args[2]
+        return (cls_preds.data_ptr(), tuple(cls_preds.shape), anchors.data_ptr(), prior.data_ptr(), P2s.data_ptr(), args[3:],
+                kw['use_filter'], kw['y_min_max'], kw['x_max'], kw['max_cand'], kw['workspace'].data_ptr())
+
+    def _select(self, cls_preds, P2s, img_hw, clip):
+        args, kw = self._post_args(cls_preds, P2s, img_hw, clip)
+        self._select_p2 = args[2]                    # keep the (possibly converted) calibration tensor alive until the NMS stage
+        ops.head_select(cls_preds, *args, **kw)
+        return self._select_key(cls_preds, args, kw)
 
     @staticmethod
     def unpad(padded):
