@@ -31,8 +31,6 @@ def run(model, inputs, dtype):
         setattr(ops, n, wrap(n))
     try:
         model.compute_dtype = dtype
-        for attr_owner, attr in ((getattr(model, 'bbox_head', None), 'fuse_head'),):
-            pass
         with torch.no_grad():
             model.forward_device(*inputs)
         torch.cuda.synchronize()
