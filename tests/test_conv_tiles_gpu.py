@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79, 73, 61, 68, 69, 58}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 76, 79, 73, 61, 68, 69, 58, 70}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58]
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70]
 
 
 class forced_tile:
@@ -129,6 +129,17 @@ def _shapes_for(cfg):
             (3, 512, 1024, 16, 32, dict(stride=2)),                          # 1536 tiles, DLA level 1 (stride 2)
             (2, 320, 512, 32, 32, dict(relu=False)),                          # 1280 tiles, Cin 32 (NF = 18)
             (5, 128, 440, 64, 32, dict(out_f32=True, bn=False, relu=False)),  # 1120 tiles, DCN offset conv at the KM3D s4 shape
+        ]
+    if cfg == 70:       # narrow-output streaming kernel: 3x3 / s1 / p1, Cin % 64 == 0 (>= 128), Cout = 32 (w_frag needs 32 filters)
+        return [
+            (1, 13, 45, 128, 32, dict(out_f32=True, bn=False, relu=False)),   # ragged tile grid, two chunks; DCN offset conv form
+            (2, 16, 55, 512, 32, dict(out_f32=True, bn=False, relu=False)),   # DLA level 5 shape: eight chunks, one tile per workgroup
+            (1, 9, 40, 192, 32, dict()),                                      # 16-bit output, BN + ReLU epilogue, three chunks
+            (1, 17, 33, 256, 32, dict(relu=False, in_extra=64, out_extra=32)),  # channel-slice views
+            (2, 18, 80, 2176, 32, dict(out_f32=True, bn=False, relu=False)),  # stereo base head: 34 chunks
+            # MORE tiles than workgroup slots (256): every workgroup walks 4 - 5 tiles x chunks, the carried accumulator is re-zeroed
+            (5, 64, 220, 128, 32, dict(out_f32=True, bn=False, relu=False)),  # 1120 tiles, KM3D s8 offset conv
+            (9, 32, 110, 256, 32, dict()),                                    # 576 tiles, 16-bit output
         ]
     if cfg == 61:       # register-resident weights: Cin 128 (128-channel slices) | 256 (64-channel slices, K halves added in LDS)
         return [

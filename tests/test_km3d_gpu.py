@@ -47,6 +47,32 @@ def test_dla_helper_kernels():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,W,C,f', [(2, 9, 23, 64, 2), (3, 16, 55, 256, 2), (1, 7, 31, 128, 2), (2, 8, 27, 64, 4), (1, 5, 9, 512, 2),
+                                       (1, 6, 70, 8, 4), (16, 64, 220, 64, 2)])
+def test_ida_up_phase_kernel_is_bit_identical_to_the_generic_one(dtype, B, H, W, C, f):
+    """IDA-Up's depth-wise ConvTranspose2d(2f, f, f/2) + add (backbones/dla.py IDAUp.forward): the phase kernel (weights in registers, one
+    wave per output phase) against the generic per-element kernel (VD3D_DWCONVT_GENERIC) -- same terms, same order, same rounding
+    points -> identical bits; the generic kernel is the one test_dla_helper_kernels pins to torch's conv_transpose2d."""
+    from visualdet3d_amd import _lib, hip_ops as ops
+    g = torch.Generator().manual_seed(C * 10 + f)
+    x = torch.randn(B, H, W, C, generator=g).cuda().to(dtype)
+    wk = (torch.randn(4 * f * f, C, generator=g) * 0.3).cuda()
+    add = torch.randn(B, H * f, W * f, C, generator=g).cuda().to(dtype)
+    for a in (None, add):
+        got = ops.dwconv_transpose(x, wk, f, add=a)
+        with _lib.test_switch('VD3D_DWCONVT_GENERIC'):
+            want = ops.dwconv_transpose(x, wk, f, add=a)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    if B * H * W < 4000:                                    # and against torch on the small cases
+        xr = x.float().cpu().permute(0, 3, 1, 2)
+        w4 = wk.cpu().t().reshape(C, 1, 2 * f, 2 * f)
+        ref = F.conv_transpose2d(xr, w4, None, stride=f, padding=f // 2, groups=C)
+        got = ops.dwconv_transpose(x, wk, f).float().cpu().permute(0, 3, 1, 2)
+        assert rel_err(got, ref) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('B,H,W,O', [(2, 21, 100, 16), (1, 64, 192, 16), (1, 9, 70, 12)])
 def test_image_conv7x7_base_layer_kernel(dtype, B, H, W, O):
     """vd3d_image_conv7x7 (DLA base layer, backbones/dla.py:116-117: 7x7 / s1 / p3 conv + BN + ReLU on the fp32 image) against

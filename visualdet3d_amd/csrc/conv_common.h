@@ -46,6 +46,8 @@ bool ksplit_shape_ok(const ConvArgs& a);                               // Cin 25
 int launch_ksplit(ConvArgs& a, hipStream_t stream, int fmt);          // 8-wave K-split resident-weight kernel (layer3)
 bool small_shape_ok(const ConvArgs& a);                                // 3x3, stride 1 | 2, Cin 16 | 32 | 64, Cout <= 32, no residual
 int launch_small(ConvArgs& a, hipStream_t stream, int fmt);           // small-channel streaming kernel
+bool narrow_shape_ok(const ConvArgs& a);                               // 3x3 / s1 / p1, Cin % 64 == 0 (>= 128), Cout <= 32, weight_frag given
+int launch_narrow(ConvArgs& a, hipStream_t stream, int fmt);          // narrow-output streaming kernel (chunked small-channel kernel)
 bool pw_shape_ok(const ConvArgs& a);                                   // 1x1 / stride 1, Cin 64 | 128 | 256, Cout % 256 == 0, weight_frag given
 int launch_pw(ConvArgs& a, hipStream_t stream, int fmt);              // point-wise expansion streaming kernel (no LDS)
 

@@ -1181,6 +1181,11 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
                 if (!small_shape_ok(a)) return forced_tile_error("needs a 16-bit 3x3 / stride 1 | 2 conv with Cin 16 | 32 | 64, Cout <= 32, no residual");
                 return launch_small(a, stream, std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16);
             } else return forced_tile_error("is a 16-bit-only tile");
+        case 70:
+            if constexpr (kBf16) {
+                if (!narrow_shape_ok(a)) return forced_tile_error("needs a 16-bit 3x3 / stride 1 / pad 1 conv with Cin a multiple of 64 (>= 128), Cout <= 32, weight_frag, no residual");
+                return launch_narrow(a, stream, std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16);
+            } else return forced_tile_error("is a 16-bit-only tile");
         case 58:
             if constexpr (kBf16) {
                 if (!pw_shape_ok(a)) return forced_tile_error("needs a 16-bit 1x1 / stride 1 conv over a dense NHWC input with Cin 64 | 128, Cout a multiple of 256");
@@ -1242,6 +1247,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         if (g_force_cfg != 60 && ksplit_shape_ok(a)) return launch_ksplit(a, stream, fmt);
         // small-channel streaming kernel (DLA level 0 / 1, DCN offset convs): input staged once, HBM-bound instead of LDS-fill-bound
         if (g_force_cfg != 60 && small_shape_ok(a)) return launch_small(a, stream, fmt);
+        // the same tile walked over 64-channel chunks for the deep offset convs (Cin 128 ... 2176 -> 27): 2-4x over the 256 x 32 tiles
+        if (g_force_cfg != 60 && narrow_shape_ok(a) && !vd3d_switch(VD3D_SW_NO_NARROW)) return launch_narrow(a, stream, fmt);
         // point-wise expansions with one or two K slices (ResNet-50 conv3 / down-sample of the first two stages): streaming kernel
         if (g_force_cfg != 60 && pw_shape_ok(a)) return launch_pw(a, stream, fmt);
         if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
@@ -1356,7 +1363,7 @@ extern "C" int vd3d_test_force_conv_tile(int cfg) {
 
 extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
     // keep in step with the "production tiles" block of dispatch()
-    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58};
+    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70};
     const int n = (int)(sizeof(kIds) / sizeof(kIds[0]));
     for (int i = 0; i < n && i < cap; ++i) ids[i] = kIds[i];
     return n;

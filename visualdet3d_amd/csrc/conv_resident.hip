@@ -1122,6 +1122,167 @@ int launch_small(ConvArgs& a, hipStream_t stream, int fmt) {
 }
 
 
+// =====================================================================================================
+// "narrow-output streaming" kernel (tile id 70): 3x3 / s1 / p1, Cin a multiple of 64 (>= 128), Cout <= 32 -- the DCN offset convs of the
+// deeper DLA-Up levels (128 | 256 | 512 -> 27) and of the stereo base head (2176 -> 27).  The generic 256 x 32 tile kernel re-stages
+// every input pixel nine times (once per tap) and ran these at 3-19x their HBM bound (512 -> 32 at 16 x 16 x 55: 60 us for 14 MB).
+// Here: the small-channel kernel's tile (8 waves x one 32-pixel row, 8 x 32 output pixels, halo staged ONCE) walked over 64-channel
+// CHUNKS: an item = (tile, chunk); per item the 10 x 34-pixel halo of that chunk (43 KiB) and the chunk's 36 weight fragments (36 KiB,
+// straight from the register image `weight_frag` -- lane-linear, conflict-free ds_read_b128) arrive by LDS-DMA into one of two stages
+// while the previous item computes: 36 MFMAs per wave and item, accumulators carried over the chunks of a tile, epilogue on the last.
+constexpr int kNwTH = 8, kNwTW = 32, kNwHW = kNwTW + 2, kNwHR = (kNwTH + 2) * kNwHW;      // 10 x 34 halo pixels
+constexpr int kNwHP = (kNwHR + 7) / 8, kNwWP = 36, kNwPieces = kNwHP + kNwWP;             // 43 + 36 DMA pieces of 1 KiB
+constexpr int kNwStage = kNwPieces * 1024, kNwLds = 2 * kNwStage + 512;
+
+template <typename T, bool OUTF32>
+__global__ void __launch_bounds__(512) conv_narrow_kernel(const ConvArgs p, int ntiles, int nchunks) {
+    constexpr int P = (kNwPieces + 7) / 8;             // per wave (overshoot repeats the wave's previous piece)
+    constexpr int NS = OUTF32 ? 4 : 2;
+    (void)NS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, half = lane >> 5;
+    const int tiles_x = (p.Wo + kNwTW - 1) / kNwTW, tiles_y = (p.Ho + kNwTH - 1) / kNwTH, tiles_img = tiles_x * tiles_y;
+    auto key = [](int row) { return (row >> 1) & 7; };
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wfrag, 0, (uint32_t)nchunks * kNwWP * 1024u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x80000000u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int in_bs = (int)p.in_batch_stride;
+    // item u of this workgroup = (its k-th tile, chunk c): u = k * nchunks + c
+    const int nwg = gridDim.x;
+    auto issue_item = [&](int t, int c, int stage) {
+        const bool tv = t < ntiles;
+        const int tt = tv ? t : 0;
+        const int b = tt / tiles_img, trem = tt - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        char* base = smem + stage * kNwStage;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int it = 0; it < P; ++it) {
+            int q = wave + it * 8;
+            if (q >= kNwPieces) q -= 8;               // branch-free partial round: repeat the previous piece (same data)
+            uint32_t off;
+            if (q < kNwHP) {                          // wave-uniform: a halo piece (8 pixels x 128 B of chunk c)
+                const int hr = q * 8 + (ln >> 3);
+                const int hy = hr / kNwHW, hx = hr - hy * kNwHW;
+                const int iy = ty * kNwTH - 1 + hy, ix = tx * kNwTW - 1 + hx;
+                const bool v = tv && hr < kNwHR && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const int sl = (ln & 7) ^ key(hr);
+                off = ((uint32_t)(b * in_bs + iy * p.in_row_stride + ix * p.in_pix_stride + c * 64 + sl * 8) * 2u) | (v ? 0u : kOOB);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + q * 1024), 16, off, 0, 0, 0);
+            } else {                                  // a weight fragment of chunk c: 1 KiB, lane-linear
+                off = tv ? (uint32_t)((c * kNwWP + (q - kNwHP)) * 1024 + ln * 16) : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(base + q * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    int a_tap[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int row = (wave + tap / 3) * kNwHW + lr + tap % 3;
+        a_tap[tap] = row * 128 + ((half ^ key(row)) << 4);
+    }
+    float* ss = (float*)(smem + 2 * kNwStage);
+    if (tid < 32) {
+        ss[tid] = (p.scale && tid < p.Cout) ? p.scale[tid] : 1.f;
+        ss[32 + tid] = (p.shift && tid < p.Cout) ? p.shift[tid] : 0.f;
+    }
+    int t = blockIdx.x, c = 0, stage = 0;
+    issue_item(t, 0, 0);
+    f32x16 acc;
+    for (; t < ntiles;) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this item's DMA was issued a whole item ago
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int cn = c + 1 == nchunks ? 0 : c + 1, tn = cn == 0 ? t + nwg : t;
+        issue_item(tn, cn, stage ^ 1);
+        const char* H0 = smem + stage * kNwStage;
+        const char* W0 = H0 + kNwHP * 1024;
+        static_for<36>([&](auto fc) {
+            constexpr int f = decltype(fc)::value, tap = f / 4, ks = f % 4;
+            const i32x4 fa = *(const i32x4*)(W0 + (f * 64 + lane) * 16);
+            const i32x4 fb = *(const i32x4*)(H0 + (a_tap[tap] ^ (ks << 5)));
+            if (f == 0 && c == 0) {
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                Fmt16<T>::mfma32z(fa, fb, zero, acc);
+            } else
+                Fmt16<T>::mfma32(fa, fb, acc);
+        });
+        if (cn == 0) {
+            // ---- epilogue (as conv_small): lane (lr = pixel, half) holds channels 8g + 4 half + e of its pixel
+            const int b = t / tiles_img, trem = t - b * tiles_img;
+            const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+            const int y = ty * kNwTH + wave, x = tx * kNwTW + lr;
+            const bool pin = y < p.Ho && x < p.Wo;
+            const uint32_t obase = (uint32_t)(((b * p.Ho + y) * p.Wo + x) * p.out_pix_stride);
+            const float relu_lo = p.relu ? 0.f : -3.0e38f;
+            auto chan4 = [&](int g, float (&v)[4]) {
+                const f32x4 sc = *(const f32x4*)(ss + 8 * g + 4 * half), sh = *(const f32x4*)(ss + 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * g + e] * sc[e] + sh[e], relu_lo);
+            };
+            if constexpr (OUTF32) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+                    chan4(g, v);
+                    const int n = 8 * g + 4 * half;
+                    const uint32_t off = ((obase + n) * 4u) | (pin && n < p.Cout ? 0u : kOOB);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{v[0], v[1], v[2], v[3]}), out_rsrc, off, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    float va[4], vb[4];
+                    chan4(g, va);
+                    chan4(g + 1, vb);
+                    const int x0 = Fmt16<T>::pack2(va[0], va[1]), x1 = Fmt16<T>::pack2(va[2], va[3]);
+                    const int y0 = Fmt16<T>::pack2(vb[0], vb[1]), y1 = Fmt16<T>::pack2(vb[2], vb[3]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                    i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
+                    const int n = 8 * (g + half);
+                    const uint32_t off = ((obase + n) * 2u) | (pin && n < p.Cout ? 0u : kOOB);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
+                }
+            }
+        }
+        t = tn;
+        c = cn;
+        stage ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMA must not land in a successor workgroup's LDS
+}
+
+bool narrow_shape_ok(const ConvArgs& a) {
+    const bool out16 = !a.out_f32;
+    return a.Cin % 64 == 0 && a.Cin >= 128 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cout <= 32 &&
+           a.Cout % (out16 ? 16 : 4) == 0 && !a.residual && a.wfrag && a.in_pix_stride % 8 == 0 && a.out_pix_stride % (out16 ? 8 : 4) == 0 &&
+           (!a.scale || ((uintptr_t)a.scale & 15) == 0) && (!a.shift || ((uintptr_t)a.shift & 15) == 0) && ((uintptr_t)a.out & 15) == 0 &&
+           ((uintptr_t)a.wfrag & 15) == 0 && (int64_t)a.M * a.out_pix_stride * (out16 ? 2 : 4) < 0x7ffffff0ll && a.Ho == a.H && a.Wo == a.W;
+}
+
+template <typename T, bool OUTF32>
+static int launch_narrow_t(ConvArgs& a, hipStream_t stream) {
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)conv_narrow_kernel<T, OUTF32>, kNwLds, lim, "hipFuncSetAttribute(conv_narrow)")) return rc;
+    const int num_cu = vd3d_device_cu_count();
+    if (num_cu <= 0) return VD3D_ELAUNCH;
+    const int ntiles = a.B * ((a.Ho + kNwTH - 1) / kNwTH) * ((a.Wo + kNwTW - 1) / kNwTW);
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    hipLaunchKernelGGL((conv_narrow_kernel<T, OUTF32>), dim3(grid), dim3(512), kNwLds, stream, a, ntiles, a.Cin / 64);
+    return vd3d_check_launch("conv_narrow");
+}
+
+int launch_narrow(ConvArgs& a, hipStream_t stream, int fmt) {
+    if (fmt == VD3D_F16) return a.out_f32 ? launch_narrow_t<hf16, true>(a, stream) : launch_narrow_t<hf16, false>(a, stream);
+    return a.out_f32 ? launch_narrow_t<short, true>(a, stream) : launch_narrow_t<short, false>(a, stream);
+}
+
+
 bool pw_shape_ok(const ConvArgs& a) {
     return (a.Cin == 64 || a.Cin == 128 || a.Cin == 256) && a.kh == 1 && a.kw == 1 && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W &&
            a.Cout % 256 == 0 && a.Cout / 256 <= 16 && a.wide_store && !a.out_f32 && a.wfrag && a.in_pix_stride % 8 == 0 &&

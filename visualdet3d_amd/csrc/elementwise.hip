@@ -430,6 +430,67 @@ __global__ void dwconvT_kernel(const T* __restrict__ in, const float* __restrict
     }
 }
 
+// The same op for the IDA-Up shapes of the DLA networks (F = 2 | 4, C a power of two, 16-bit): a workgroup is F*F waves, wave = output
+// PHASE (y mod F, x mod F) -- every output of one phase uses the same 2 x 2 kernel taps, so a lane keeps its four weight vectors
+// (its 8 channels) in registers for the whole launch; the F*F waves walk the same input row segment at the same time (the 2 x 2 input
+// neighbourhoods come from the CU's L1), rows are handed out per workgroup (no per-element 64-bit div / mod: the generic kernel
+// spends most of its time there).  Term order and rounding points are the generic kernel's: results are bit-identical.
+template <typename T, int F>
+__global__ void __launch_bounds__(64 * F * F) dwconvT_phase_kernel(const T* __restrict__ in, const float* __restrict__ w, const T* __restrict__ add,
+                                                                   T* __restrict__ out, int B, int H, int W, int C, int lcv, int ips, int aps, int ops) {
+    constexpr int K = 2 * F, HALF = F / 2;
+    const int lane = threadIdx.x & 63, phase = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int py = phase / F, px = phase % F;
+    const int c = (lane & ((1 << lcv) - 1)) * 8, pl = lane >> lcv, ppw = 64 >> lcv;     // this lane's channels; pixels per wave and step
+    // output (F j + py, F i + px) <- inputs (ja, ia), (ja, ia - 1), (ja - 1, ia), (ja - 1, ia - 1) with taps (ky0 | ky0 + F) x (kx0 | kx0 + F)
+    const int dy = py >= HALF, dx = px >= HALF;
+    const int ky0 = dy ? py - HALF : py + HALF, kx0 = dx ? px - HALF : px + HALF;
+    float wt[4][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float* wp = w + ((ky0 + (t >> 1) * F) * K + kx0 + (t & 1) * F) * C + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wt[t][e] = wp[e];
+    }
+    const int Ho = F * H, Wo = F * W;
+    for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+        const int b = row / H, j = row - b * H;
+        const int ja = j + dy;
+        const bool ra = ja < H, rb = ja >= 1;                          // wave-uniform: the two input rows exist
+        const T* rowa = in + (int64_t)((b * H + ja) * W) * ips + c;
+        const T* rowb = rowa - (int64_t)W * ips;
+        const int64_t obase = (int64_t)((b * Ho + F * j + py) * Wo + px);
+        for (int i = pl + blockIdx.y * ppw; i < W; i += ppw * gridDim.y) {      // blockIdx.y: column split of short launches
+            const int ia = i + dx;
+            const bool ca = ia < W, cb = ia >= 1;
+            const i32x4 zero = {0, 0, 0, 0};
+            Vec16<T> v[4];
+            v[0].raw = ra && ca ? *(const i32x4*)(rowa + (int64_t)ia * ips) : zero;
+            v[1].raw = ra && cb ? *(const i32x4*)(rowa + (int64_t)(ia - 1) * ips) : zero;
+            v[2].raw = rb && ca ? *(const i32x4*)(rowb + (int64_t)ia * ips) : zero;
+            v[3].raw = rb && cb ? *(const i32x4*)(rowb + (int64_t)(ia - 1) * ips) : zero;
+            const int64_t opix = obase + F * i;
+            Vec16<T> a;
+            if (add) a.raw = *(const i32x4*)(add + opix * aps + c);
+            float s[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] = fmaf(v[t].get(e), wt[t][e], s[e]);
+            if (add) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] = ElemTraits<T>::to_f(ElemTraits<T>::from_f(s[e])) + a.get(e);
+            }
+            Vec16<T> o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o.set2(e, s[2 * e], s[2 * e + 1]);
+            *(i32x4*)(out + opix * ops + c) = o.raw;
+        }
+    }
+}
+
 // NCHW fp32 image -> zero-bordered NHWC with `cpad` channels (3 real + zeros), general borders
 template <typename T, int CPAD>
 __global__ void pack_image_c_kernel(const float* __restrict__ in, T* __restrict__ out, int B, int H, int W, int pad_y, int pad_l, int Hp, int Wp) {
@@ -466,6 +527,25 @@ extern "C" int vd3d_dwconv_transpose(const void* in, const float* weight, const 
     const int K = 2 * f, pad = f / 2;
     const int Ho = (H - 1) * f - 2 * pad + K, Wo = (W - 1) * f - 2 * pad + K;
     const int64_t total = (int64_t)B * Ho * Wo * (C / (dtype == VD3D_F32 ? 4 : 8));
+    // IDA-Up shapes: the phase kernel (weights in registers, no per-element div / mod); a skipped out-of-range term adds exactly zero
+    // there, so a non-finite weight is the one input on which the two kernels could differ -- the weights are parameters, finite.
+    if (dtype != VD3D_F32 && (f == 2 || f == 4) && C >= 8 && C <= 512 && (C & (C - 1)) == 0 && (int64_t)B * Ho * Wo < (1 << 30) &&
+        (int64_t)B * H * W * ips < (1ll << 31) && !vd3d_switch(VD3D_SW_DWCONVT_GENERIC)) {
+        int lcv = 0;
+        while ((8 << lcv) < C) ++lcv;
+        const int rows = B * H, cus = vd3d_device_cu_count();
+        if (cus <= 0) return VD3D_ELAUNCH;
+        const int grid = rows < 8 * cus ? rows : 8 * cus;
+        const int steps = (W + (64 >> lcv) - 1) / (64 >> lcv);                 // wave steps along a row
+        int nsplit = 4 * cus / grid;                                           // few rows (deep levels): split the columns as well
+        nsplit = nsplit < 1 ? 1 : (nsplit > steps ? steps : nsplit);
+#define VD3D_DWT(TT, FF) hipLaunchKernelGGL((dwconvT_phase_kernel<TT, FF>), dim3(grid, nsplit), dim3(64 * FF * FF), 0, (hipStream_t)stream, (const TT*)in, weight, \
+                                             (const TT*)add, (TT*)out, B, H, W, C, lcv, ips, aps, ops)
+        if (dtype == VD3D_F16) { if (f == 2) VD3D_DWT(hf16, 2); else VD3D_DWT(hf16, 4); }
+        else { if (f == 2) VD3D_DWT(short, 2); else VD3D_DWT(short, 4); }
+#undef VD3D_DWT
+        return vd3d_check_launch("dwconv_transpose(phase)");
+    }
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(dwconvT_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, weight, (const T*)add, (T*)out, B, H, W, C, f, K, pad, Ho, Wo, ips, aps, ops));
     return vd3d_check_launch("dwconv_transpose");

@@ -106,8 +106,9 @@ def pack_conv(weight, bias=None, bn=None, dtype=torch.bfloat16, stride=1, pad=0,
     packed[:O, :K] = w.reshape(O, K).to(dtype)
     scale, shift = fold_bn(bias, bn, O, dev)
     pc = PackedConv(packed, scale, shift, Cin, O, kh, kw, stride, pad, dil, Kpad, CoutPad, dtype)
-    if is16(dtype) and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and Cin in (64, 128, 256) and O % 32 == 0:
-        # register image for the resident-weight kernels (layout: include/vd3d.h, vd3d_conv_params.weight_frag):
+    if is16(dtype) and (kh, kw, stride, pad, dil) == (3, 3, 1, 1, 1) and O % 32 == 0 and (Cin in (64, 128, 256) or (Cin % 64 == 0 and O == 32)):
+        # register image for the resident-weight kernels and the narrow-output streaming kernel (O = 32, any Cin % 64 == 0)
+        # (layout: include/vd3d.h, vd3d_conv_params.weight_frag):
         # [O/32][Cin/64][tap*4 + ks][half*32 + lr][8]  <-  w[32*nb + lr][tap][64*kc + (2*ks + half)*8 + e]
         w7 = w.reshape(O // 32, 32, 9, Cin // 64, 4, 2, 8)                 # nb, lr, tap, kc, ks, half, e
         pc.w_frag = w7.permute(0, 3, 2, 4, 5, 1, 6).contiguous().to(dtype)
