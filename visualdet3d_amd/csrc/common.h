@@ -136,7 +136,7 @@ int vd3d_check_launch(const char* what);
 // per process (no getenv on the launch path, no race with setenv); tests flip them through vd3d_test_set_switch (test_hooks.h).
 enum Vd3dSwitch {
     VD3D_SW_CONV_DEBUG, VD3D_SW_FORCE_GROUP_M, VD3D_SW_NO_GROUP_M, VD3D_SW_NO_LINE_STORE, VD3D_SW_DCN_GENERIC,
-    VD3D_SW_DCN_COLUMNS_GENERIC, VD3D_SW_CONV3D_VALU, VD3D_SW_DCN_WINDOW, VD3D_SW_PSM_VALU, VD3D_SW_DCN_KSPLIT, VD3D_SW_NO_NARROW, VD3D_SW_DWCONVT_GENERIC, VD3D_SW_COUNT
+    VD3D_SW_DCN_COLUMNS_GENERIC, VD3D_SW_CONV3D_VALU, VD3D_SW_DCN_WINDOW, VD3D_SW_PSM_VALU, VD3D_SW_DCN_KSPLIT, VD3D_SW_NO_NARROW, VD3D_SW_DWCONVT_GENERIC, VD3D_SW_HEAD_PARKED, VD3D_SW_COUNT
 };
 bool vd3d_switch(Vd3dSwitch s);
 
