@@ -206,8 +206,10 @@ def test_fused_head_matches_unfused():
     sd = syn.seeded_state_dict({'h.' + k: v for k, v in head.state_dict().items()}, seed=9, head_std=0.02)
     head.load_state_dict({k[2:]: v for k, v in sd.items()})
     g = torch.Generator().manual_seed(4)
-    # 3 x 24 x 80: ragged last 256-pixel tile; bf16 and fp16
-    for shape, dt in (((3, 24, 80), torch.bfloat16), ((2, 20, 96), torch.bfloat16), ((2, 20, 96), torch.float16)):
+    # 3 x 24 x 80: ragged last 256-pixel tile; bf16 and fp16.  4 x 64 x 130: 1 170 tiles -- every persistent workgroup walks 4 - 5
+    # tiles across branch boundaries (next tile's first slice and head constants requested under the previous tile's epilogue)
+    for shape, dt in (((3, 24, 80), torch.bfloat16), ((2, 20, 96), torch.bfloat16), ((2, 20, 96), torch.float16),
+                      ((4, 64, 130), torch.float16), ((4, 64, 130), torch.bfloat16)):
         x = torch.randn(shape[0], shape[1], shape[2], 64, generator=g).cuda().to(dt)
         with torch.no_grad():
             head.fuse_head = True
@@ -218,6 +220,25 @@ def test_fused_head_matches_unfused():
             a, b = fused_maps[k].float(), ref_maps[k].float()
             assert a.shape == b.shape
             assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 2e-3, (k, shape, dt)
+    # an even slice count (128 input features: 18 slices, the last one in stage 1) and the first version of the kernel (A/B switch)
+    from visualdet3d_amd import _lib
+    cfg.head.layer_cfg.input_features = 128
+    head2 = KM3DHead(**cfg.head).cuda().eval()
+    sd = syn.seeded_state_dict({'h.' + k: v for k, v in head2.state_dict().items()}, seed=10, head_std=0.02)
+    head2.load_state_dict({k[2:]: v for k, v in sd.items()})
+    for shape, dt in (((4, 64, 130), torch.float16), ((1, 24, 80), torch.bfloat16)):
+        x = torch.randn(shape[0], shape[1], shape[2], 128, generator=g).cuda().to(dt)
+        with torch.no_grad():
+            head2.fuse_head = True
+            fused_maps = head2.forward_nhwc(x)
+            with _lib.test_switch('VD3D_HEAD_PARKED'):
+                parked_maps = head2.forward_nhwc(x)
+            head2.fuse_head = False
+            ref_maps = head2.forward_nhwc(x)
+        for k in ref_maps:
+            for got in (fused_maps[k], parked_maps[k]):
+                a, b = got.float(), ref_maps[k].float()
+                assert ((a - b).abs().max() / b.abs().max().clamp_min(1e-6)).item() < 2e-3, (k, shape, dt)
 
 
 def _teacher_forced_dcn_blocks(m, taps, dtype):

@@ -37,6 +37,7 @@ struct ConvArgs {
     int Kpad, relu, out_f32;
     int M, tiles_m, tiles_n, ntaps, nk;
     FastDiv fd_howo, fd_wo;           // m / (Ho * Wo), rem / Wo of the tile kernels' pixel-row decode
+    FastDiv fd_tiles_m;               // tile / tiles_m (persistent fused-head kernel)
     int vec_epilogue, wide_store, chunk_major;
     int group_m = 0;                  // > 0: DMA tile kernels walk group_m pixel tiles x all N tiles per XCD run (huge 1x1 GEMMs)
     int strip_lines = 0;              // 16x16x32 strip tiles: 16-bit output re-laid through LDS (whole pixel runs per store instruction)
@@ -62,6 +63,8 @@ bool small_shape_ok(const ConvArgs& a);                                // 3x3, s
 int launch_small(ConvArgs& a, hipStream_t stream, int fmt);           // small-channel streaming kernel
 bool narrow_shape_ok(const ConvArgs& a);                               // 3x3 / s1 / p1, Cin % 64 == 0 (>= 128), Cout <= 32, weight_frag given
 int launch_narrow(ConvArgs& a, hipStream_t stream, int fmt);          // narrow-output streaming kernel (chunked small-channel kernel)
+bool km3d_head_shape_ok(const ConvArgs& a);                            // 3x3 / s1 / p1, Cin % 64 == 0, Cout = 256 x branches (h_* fields set)
+int launch_km3d_head(ConvArgs& a, hipStream_t stream, int fmt);       // persistent fused KM3D head (km3d_head_conv.hip)
 bool pw_shape_ok(const ConvArgs& a);                                   // 1x1 / stride 1, Cin 64 | 128 | 256, Cout % 256 == 0, weight_frag given
 int launch_pw(ConvArgs& a, hipStream_t stream, int fmt);              // point-wise expansion streaming kernel (no LDS)
 

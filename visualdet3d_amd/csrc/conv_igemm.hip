@@ -523,13 +523,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    // fused head (4 x 2 waves): PERSISTENT -- one workgroup per CU walks tiles bid', bid' + nwg, ... (a fresh workgroup per tile paid the
-    // launch / teardown turnover and the kernel-argument fetch 124 times per CU)
-    constexpr bool PERSIST = HEADF && WARPS_N == 2;
-    const int total_tiles = p.tiles_m * p.tiles_n;
-  for (int round = 0;; ++round) {
-    const int tile = round * nwg + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    if (PERSIST ? tile >= total_tiles : round > 0) break;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
     if (p.group_m > 0) {
         // pixel matrix far larger than L2 + Infinity Cache (the 1.8 GB DCN column matrix of BASELINE config 3): N-major order makes
@@ -585,16 +579,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
             for (int u = 0; u < HDV; ++u) {
                 const int v = tid + u * NW * 64, r = v >> 5, sl = v & 31;
-                if constexpr (WARPS_N == 2) {
-                    // second GEMM straight from the accumulators (below): its k order inside a 16-channel group is
-                    // [0-3, 8-11 | 4-7, 12-15] -- what a lane's accumulator quads g, g + 1 hold -- so W2 is stored in that order:
-                    // source slot (group, hh) = channels 8 hh + 0..7 of the group -> low half to slot (group, 0), high half to
-                    // slot (group, 1), each at byte 8 hh
-                    const int ksg = sl >> 1, hh = sl & 1;
-                    *(i32x2*)(smem + HD_W2 + r * 512 + (((2 * ksg) ^ (r & 15)) << 4) + hh * 8) = i32x2{hd_w2[u][0], hd_w2[u][1]};
-                    *(i32x2*)(smem + HD_W2 + r * 512 + (((2 * ksg + 1) ^ (r & 15)) << 4) + hh * 8) = i32x2{hd_w2[u][2], hd_w2[u][3]};
-                } else
-                    *(i32x4*)(smem + HD_W2 + r * 512 + ((sl ^ (r & 15)) << 4)) = hd_w2[u];
+                *(i32x4*)(smem + HD_W2 + r * 512 + ((sl ^ (r & 15)) << 4)) = hd_w2[u];
             }
             if (tid < 64) *(f32x4*)(smem + HD_B1 + tid * 16) = hd_b;
             else if (tid < 72) *(f32x4*)(smem + HD_B2 + (tid - 64) * 16) = hd_b;
@@ -845,74 +830,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         const int m = m0 + wm * WTM + j * MS + lr;
         mrow[j] = m < p.M ? m : -1;
     }
-    if constexpr (HEADF && WARPS_N == 2) {
-        // ---- fused KM3D head, second GEMM from the registers: wave (wm, wn) holds 64 pixels x 128 hidden channels of head h = tile_n.
-        // After bias + ReLU + rounding to the 16-bit format (the rounding point of the unfused path's `mid` tensor) a lane's accumulator
-        // quads g, g + 1 of channel block i ARE the B fragment of a 32x32x16 MFMA whose k run is the 16-channel group 2 i + g / 2 in the
-        // order the W2 image above is stored in: out_h[32][64 px] += W2_h[32][128] x hidden[128][64 px] without the tile ever going
-        // through LDS (the first version parked 128 KB per tile and read 256 KB back).  The two channel halves (wn = 0 | 1) meet in
-        // LDS: 8 KB per wave.  The 9 x 256-channel intermediate (4 GB at 16 x 128 x 440) never exists in HBM.
-        static_assert(BM == 256 && BN == 256 && MS == 32 && sizeof(T) == 2 && WARPS_M == 4, "fused head: 256 x 256 16-bit tiles, 4 x 2 waves");
-        const int h = tile_n;
-        f32x16 acc2[TM];
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[j][e] = 0.f;
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
-#pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                const int ks = wn * 8 + i * 2 + gp;                       // 16-channel group inside the head
-                const f32x4 sh0 = *(const f32x4*)(smem + HD_B1 + (16 * ks + 4 * half) * 4);
-                const f32x4 sh1 = *(const f32x4*)(smem + HD_B1 + (16 * ks + 8 + 4 * half) * 4);
-                const i32x4 fa2 = *(const i32x4*)(smem + HD_W2 + lr * 512 + (((2 * ks + half) ^ (lr & 15)) << 4));
-#pragma unroll
-                for (int j = 0; j < TM; ++j) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = fmaxf(acc[i][j][8 * gp + e] + sh0[e], 0.f);
-                        v[4 + e] = fmaxf(acc[i][j][8 * gp + 4 + e] + sh1[e], 0.f);
-                    }
-                    const i32x4 fb2 = {Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3]), Fmt16<T>::pack2(v[4], v[5]), Fmt16<T>::pack2(v[6], v[7])};
-                    Fmt16<T>::mfma32(fa2, fb2, acc2[j]);
-                }
-            }
-        __syncthreads();                                   // every wave is done with the operand stages: [0, 32 KiB) becomes the meeting area
-        if (wn == 1) {
-#pragma unroll
-            for (int j = 0; j < TM; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *(f32x4*)(smem + ((wm * TM + j) * 4 + g) * 1024 + lane * 16) = f32x4{acc2[j][4 * g], acc2[j][4 * g + 1], acc2[j][4 * g + 2], acc2[j][4 * g + 3]};
-        }
-        __syncthreads();
-        if (wn == 0) {
-        // The wave's 64 pixels x nh outputs are one contiguous run of the [M][nh] map: laid out as [pixel][nh] in LDS first, so that
-        // consecutive lanes store consecutive floats (whole lines) instead of nh scattered floats per lane.
-        const int nh = p.h_n[h];
-        float* stage = (float*)(smem + 32768 + wm * (64 * 32 * 4));
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 other = *(const f32x4*)(smem + ((wm * TM + j) * 4 + g) * 1024 + lane * 16);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = 8 * g + 4 * half + e;
-                    if (n < nh) stage[(j * 32 + lr) * nh + n] = acc2[j][4 * g + e] + other[e] + *(const float*)(smem + HD_B2 + n * 4);
-                }
-            }
-        const int mw = m0 + wm * 64;                     // first pixel of this wave's run
-        const int nrun = (p.M - mw < 64 ? (p.M - mw > 0 ? p.M - mw : 0) : 64) * nh;
-        float* dst = p.h_out[h] + (int64_t)mw * nh;
-        for (int i = lane; i < nrun; i += 64) dst[i] = stage[i];
-        }
-        __syncthreads();       // the meeting area and the head constants are free for the next tile
-        continue;
-    } else if constexpr (HEADF) {
-        // ---- fused KM3D head (first version, VD3D_HEAD_PARKED=1): this N tile is head h = tile_n.  bias + ReLU, round to bf16 (the rounding point of the unfused
+    if constexpr (HEADF) {
+        // ---- fused KM3D head, first version (VD3D_HEAD_PARKED=1; the product path is km3d_head_conv.hip): this N tile is head h = tile_n.  bias + ReLU, round to bf16 (the rounding point of the unfused
         // path's `mid` tensor), park the 256 x 256 tile in LDS, then out_h = tile x W2_h + b2_h on the matrix cores.  The
         // 9 x 256-channel intermediate (4 GB at 16 x 128 x 440) never exists in HBM.
         static_assert(BM == 256 && BN == 256 && MS == 32 && sizeof(T) == 2, "fused head: 256 x 256 bf16 tiles");
@@ -988,8 +907,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     }
     if constexpr (MS == 32) conv_epilogue<T, TM, TN, WTM, WTN>(p, acc, mrow, n0, wn, half, ltab, BN);
     else conv_epilogue16<T, TM, TN, WTN>(p, acc, mrow, n0, wn, half, ltab, BN);
-    return;
-  }
 }
 
 // =====================================================================================================
@@ -1205,13 +1122,8 @@ int launch(ConvArgs& a, hipStream_t stream) {
     if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL, HEADF>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_igemm)")) return rc;
-    int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
+    const int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
     if (grid <= 0 || grid > 0x7fffffff) return VD3D_EINVAL;
-    if constexpr (HEADF && WARPS_N == 2) {          // persistent: one workgroup per CU
-        const int cus = vd3d_device_cu_count();
-        if (cus <= 0) return VD3D_ELAUNCH;
-        if (grid > cus) grid = cus;
-    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NT), LDS, stream, a);
     return vd3d_check_launch("conv_igemm");
 }
@@ -1550,6 +1462,6 @@ extern "C" int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_pa
         if (p->dtype == VD3D_F16) return launch<hf16, 256, 256, 2, 4, true, true, 32, 0, 0, true>(a, (hipStream_t)stream);
         return launch<short, 256, 256, 2, 4, true, true, 32, 0, 0, true>(a, (hipStream_t)stream);
     }
-    if (p->dtype == VD3D_F16) return launch<hf16, 256, 256, 4, 2, true, true, 32, 0, 0, true>(a, (hipStream_t)stream);
-    return launch<short, 256, 256, 4, 2, true, true, 32, 0, 0, true>(a, (hipStream_t)stream);
+    if (!km3d_head_shape_ok(a)) { vd3d_set_error("km3d_head_fused: shape not supported by the persistent head kernel"); return VD3D_EINVAL; }
+    return launch_km3d_head(a, (hipStream_t)stream, p->dtype);
 }
