@@ -1216,7 +1216,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 10: return launch<T, 256, 288, 8, 1, true>(a, stream);
         case 17: return launch<T, 128, 192, 2, 2, true>(a, stream);
         case 51: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16>(a, stream));
-        case 70: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream));
+        case 47: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 2, 2, 2>(a, stream));
         case 77: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 256, 2, 2, 3>(a, stream));
         case 84: return launch<T, 256, 32, 4, 1, true, true>(a, stream);
         case 85: return launch<T, 128, 64, 4, 1, true, true, 32, 2>(a, stream);
