@@ -96,7 +96,8 @@ def test_image_conv7x7_base_layer_kernel(dtype, B, H, W, O):
     assert rel_err(got, old) < (1e-2 if dtype == torch.bfloat16 else 2e-3)
 
 
-@pytest.mark.parametrize('H,W,B,seed', [(24, 80, 2, 0), (48, 160, 3, 1)])
+# (128 x 440: thousands of peaks per heat-map channel -> the radix-select path of the top-K kernel and the multi-span peak lists)
+@pytest.mark.parametrize('H,W,B,seed', [(24, 80, 2, 0), (48, 160, 3, 1), (128, 440, 2, 2)])
 def test_decode_matches_oracle_on_identical_maps(H, W, B, seed):
     from visualdet3d_amd.networks.heads.km3d_head import KM3DHead
     cfg = syn.km3d_cfg()
@@ -113,7 +114,7 @@ def test_decode_matches_oracle_on_identical_maps(H, W, B, seed):
     want = orc.km3d_get_bboxes(maps, P2, (H * 4, W * 4), score_thr=0.3, nms_iou_thr=0.5)
     dev = {k: v.permute(0, 2, 3, 1).contiguous().cuda() for k, v in maps.items()}
     got = head.unpad(head.get_bboxes_batched(dev, P2.cuda(), (H * 4, W * 4)))
-    assert sum(len(w[0]) for w in want) > 20 and any(len(w[0]) < 100 for w in want)
+    assert sum(len(w[0]) for w in want) > 20 and (H > 100 or any(len(w[0]) < 100 for w in want))
     for b in range(B):
         s, bx, l = [t.cpu() for t in got[b]]
         assert_detections_close((s, bx, l), want[b], rtol=1e-3, what='sample %d' % b)

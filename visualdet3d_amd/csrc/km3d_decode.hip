@@ -51,10 +51,16 @@ __global__ void km3d_zero_kernel(int32_t* a, int n) {
 // the first version -- put ~900 atomics on each of the B x 12 counters: with many candidates, e.g. untrained weights, those
 // serialised into 0.7 ms per launch at 16 x 128 x 440.)  The order inside a list is irrelevant: the top-K kernel sorts it.
 constexpr int kPeakSpan = 1024;
+// The sigmoid of the span and of one image row (+ 1 pixel) on either side is evaluated ONCE into LDS; the 3x3 test then compares LDS
+// values.  (First version: every candidate re-evaluated the sigmoid of its eight neighbours from global memory -- with many candidates,
+// e.g. untrained weights, nine expf per pixel and channel: 127 us per launch at 16 x 128 x 440, VALU bound.)  Same function, same
+// comparisons: the peak lists are identical.
 __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char peaks_smem[];
     __shared__ float s_score[kPeakSpan];
     __shared__ int s_idx[kPeakSpan];
     __shared__ int s_n, s_base;
+    float* sg = (float*)peaks_smem;                    // sigmoid of pixels [first - W - 1, first + kPeakSpan + W + 1)
     const int nch = p.n_cls + p.J;
     const int slot = blockIdx.y;                       // b * nch + ch
     const int b = slot / nch, ch = slot - b * nch;
@@ -62,19 +68,25 @@ __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
     const float* m = (is_hm ? p.hm : p.hm_hp);
     const int C = is_hm ? p.n_cls : p.J, c = is_hm ? ch : ch - p.n_cls;
     const float thr = is_hm ? p.score_thr : 0.1f;
-    const int HW = p.H * p.W;
+    const int HW = p.H * p.W, W = p.W;
     const float* mb = m + (int64_t)b * HW * C + c;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
     const int first = blockIdx.x * kPeakSpan;
+    const int lo = first - W - 1, nsg = kPeakSpan + 2 * (W + 1);
+    for (int i = threadIdx.x; i < nsg; i += 256) {
+        const int pix = lo + i;
+        sg[i] = (pix >= 0 && pix < HW) ? sigm(mb[(int64_t)pix * C]) : 0.f;
+    }
+    __syncthreads();
     for (int it = 0; it < kPeakSpan / 256; ++it) {
         const int pix = first + it * 256 + threadIdx.x;
         bool peak = false;
         float v = 0.f;
         if (pix < HW) {
-            const int y = pix / p.W, x = pix - y * p.W;
-            v = sigm(mb[(int64_t)pix * C]);
+            const int y = pix / W, x = pix - y * W;
+            const float* ctr = sg + (pix - lo);
+            v = ctr[0];
             if (v > thr) {
                 peak = true;
                 for (int dy = -1; dy <= 1 && peak; ++dy) {
@@ -82,8 +94,8 @@ __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
                     if ((unsigned)yy >= (unsigned)p.H) continue;
                     for (int dx = -1; dx <= 1; ++dx) {
                         const int xx = x + dx;
-                        if ((unsigned)xx >= (unsigned)p.W || (dx == 0 && dy == 0)) continue;
-                        if (sigm(mb[((int64_t)yy * p.W + xx) * C]) > v) { peak = false; break; }
+                        if ((unsigned)xx >= (unsigned)W || (dx == 0 && dy == 0)) continue;
+                        if (ctr[dy * W + dx] > v) { peak = false; break; }
                     }
                 }
             }
@@ -116,9 +128,21 @@ __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
 }
 
 // ---- 2. per-channel top-K -------------------------------------------------------------------------------------------
+// Keys are unique 64-bit values (orderable score << 32 | pixel index), ascending key = descending score, ties by index -- the order
+// of torch.topk on the flattened map.  With thousands of peaks per channel (untrained weights: ~half the pixels of the keypoint map
+// pass 0.1) a full bitonic sort of the padded list is 91 passes over 8192 keys; only the K = 100 smallest are wanted.  So the list is
+// first cut by a byte-wise radix SELECT on the score word: per pass a 256-bin histogram of the next byte among the keys that still
+// share the prefix, the bin where the running count crosses K extends the prefix -- until at most kTopkSort keys are <= the prefix
+// bound; those are compacted and sorted.  Every one of the K smallest keys has its score prefix <= the bound by construction, so
+// the result equals the full sort's.  (Scores equal to the last bit in more than kTopkSort peaks: the full sort, as before.)
+constexpr int kTopkSort = 1024;
 __global__ void __launch_bounds__(kNmsThreads) km3d_topk_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = (uint64_t*)smem;
+    uint64_t* keys = (uint64_t*)smem;                               // [max_peaks]
+    uint64_t* cand = keys + p.max_peaks;                            // [kTopkSort]
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix, s_below;
+    __shared__ int s_ncand;
     const int nch = p.n_cls + p.J;
     const int slot = blockIdx.y * nch + blockIdx.x;   // (b, ch)
     int n = p.peak_count[slot];
@@ -126,22 +150,84 @@ __global__ void __launch_bounds__(kNmsThreads) km3d_topk_kernel(const KArgs p) {
         if (threadIdx.x == 0) p.overflow[blockIdx.y] = 1;
         n = p.max_peaks;
     }
-    int P = 1;
-    while (P < n) P <<= 1;
     const float* sc = p.peak_score + (int64_t)slot * p.max_peaks;
     const int32_t* ix = p.peak_idx + (int64_t)slot * p.max_peaks;
-    for (int i = threadIdx.x; i < P; i += blockDim.x)
-        keys[i] = i < n ? (((uint64_t)orderable_desc(sc[i]) << 32) | (uint32_t)ix[i]) : ~0ull;   // score desc, index asc
-    __syncthreads();
-    bitonic_sort(keys, P);
+    uint64_t* sorted = keys;
+    int P = 1;
+    if (n <= kTopkSort) {
+        while (P < n) P <<= 1;
+        for (int i = threadIdx.x; i < P; i += blockDim.x)
+            keys[i] = i < n ? (((uint64_t)orderable_desc(sc[i]) << 32) | (uint32_t)ix[i]) : ~0ull;   // score desc, index asc
+        __syncthreads();
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) keys[i] = ((uint64_t)orderable_desc(sc[i]) << 32) | (uint32_t)ix[i];
+        if (threadIdx.x == 0) { s_prefix = 0; s_below = 0; }
+        __syncthreads();
+        // after pass q the bound is: score word's top 8 (q + 1) bits <= prefix's;  below = keys strictly under the prefix bin
+        int shift = 24, nle = n;                      // nle: keys with score word <= bound (all of them before the first pass)
+        for (; shift >= 0 && nle > kTopkSort; shift -= 8) {
+            for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix, below = s_below;
+            const uint32_t himask = shift == 24 ? 0u : ~0u << (shift + 8);
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t w = (uint32_t)(keys[i] >> 32);
+                if ((w & himask) == prefix) atomicAdd(&hist[(w >> shift) & 255], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int run = (int)below, bin = 0;
+                for (; bin < 255; ++bin) {            // the bin in which the running count reaches K
+                    if (run + hist[bin] >= p.K) break;
+                    run += hist[bin];
+                }
+                s_prefix = prefix | ((uint32_t)bin << shift);
+                s_below = (uint32_t)run;
+                s_ncand = run + hist[bin];
+            }
+            __syncthreads();
+            nle = s_ncand;
+        }
+        if (nle > kTopkSort) {
+            // (more than kTopkSort peaks share the K-th score exactly) the full sort
+            while (P < n) P <<= 1;
+            for (int i = n + threadIdx.x; i < P; i += blockDim.x) keys[i] = ~0ull;
+            __syncthreads();
+        } else {
+            const int sh = shift + 8;                 // the bound covers the score word's bits [31 : sh]
+            const uint32_t bound = s_prefix >> sh;
+            if (threadIdx.x == 0) s_ncand = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < n; i0 += blockDim.x) {
+                const int i = i0 + threadIdx.x;
+                const uint64_t k = i < n ? keys[i] : ~0ull;
+                const bool take = i < n && ((uint32_t)(k >> 32) >> sh) <= bound;
+                const uint64_t mask = __ballot(take);
+                if (mask) {
+                    const int lane = threadIdx.x & 63;
+                    int pos0 = 0;
+                    if (lane == 0) pos0 = atomicAdd(&s_ncand, __popcll(mask));
+                    pos0 = __shfl(pos0, 0);
+                    if (take) cand[pos0 + __popcll(mask & ((1ull << lane) - 1ull))] = k;
+                }
+            }
+            __syncthreads();
+            n = s_ncand;                              // >= min(K, n): every key that can be among the K smallest
+            while (P < n) P <<= 1;
+            for (int i = n + threadIdx.x; i < P; i += blockDim.x) cand[i] = ~0ull;
+            __syncthreads();
+            sorted = cand;
+        }
+    }
+    bitonic_sort(sorted, P);
     for (int k = threadIdx.x; k < p.K; k += blockDim.x) {
         float s = 0.f;
         int id = 0;
         if (k < n) {
-            const uint32_t hi = ~(uint32_t)(keys[k] >> 32);
+            const uint32_t hi = ~(uint32_t)(sorted[k] >> 32);
             const uint32_t u = (hi & 0x80000000u) ? (hi ^ 0x80000000u) : ~hi;   // inverse of the orderable transform
             s = __builtin_bit_cast(float, u);
-            id = (int)(uint32_t)keys[k];
+            id = (int)(uint32_t)sorted[k];
         }
         p.top_score[(int64_t)slot * p.K + k] = s;
         p.top_idx[(int64_t)slot * p.K + k] = id;
@@ -372,10 +458,12 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     const int nz = (int)(((int64_t)q->B * nch * 4 + 255) / 256 * 256 + (int64_t)q->B * 4) / 4;
     hipLaunchKernelGGL(km3d_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, w.peak_count, nz);
     const int gx = (q->H * q->W + kPeakSpan - 1) / kPeakSpan;
-    hipLaunchKernelGGL(km3d_peaks_kernel, dim3((unsigned)gx, (unsigned)(q->B * nch)), dim3(256), 0, s, a);
+    const int peaks_lds = (kPeakSpan + 2 * (q->W + 1)) * 4;      // the span's sigmoid tile (+ one row and a pixel on either side)
+    if (peaks_lds > 48 * 1024) { vd3d_set_error("km3d_decode: heat-map wider than 5 631 pixels"); return VD3D_ERANGE; }
+    hipLaunchKernelGGL(km3d_peaks_kernel, dim3((unsigned)gx, (unsigned)(q->B * nch)), dim3(256), peaks_lds, s, a);
     int rc = vd3d_check_launch("km3d_peaks");
     if (rc) return rc;
-    const int lds = q->max_peaks * 8;
+    const int lds = (q->max_peaks + kTopkSort) * 8;      // the key list + the compacted candidates of the radix select
     static Vd3dLdsLimit lim;
     rc = vd3d_raise_lds_limit((const void*)km3d_topk_kernel, lds, lim, "hipFuncSetAttribute(km3d_topk)");
     if (rc) return rc;
