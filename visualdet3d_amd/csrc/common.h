@@ -132,6 +132,20 @@ template <> struct Vec16<float> {
 void vd3d_set_error(const char* msg);
 int vd3d_check_launch(const char* what);
 
+// Exact n / d for 0 <= n < 2^31 by one 32 x 32 -> 64-bit multiply (d fixed per launch): mul = ceil(2^(31 + s) / d), s = ceil(log2 d).
+// (A per-lane integer division is ~40 VALU instructions on gfx950; a tile prologue has two per staged pixel row.)
+struct FastDiv {
+    uint32_t mul = 0x80000000u, shift = 0;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    while ((1u << f.shift) < d) ++f.shift;
+    f.mul = (uint32_t)(((1ull << (31 + f.shift)) + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ int fastdiv(int n, FastDiv f) { return (int)((uint32_t)(((uint64_t)(uint32_t)n * f.mul) >> 31) >> f.shift); }
+
+
 // A/B switches between two CORRECT implementations.  Each is the environment variable of the same name, read ONCE
 // per process (no getenv on the launch path, no race with setenv); tests flip them through vd3d_test_set_switch (test_hooks.h).
 enum Vd3dSwitch {

@@ -6,19 +6,6 @@
 
 namespace vd3d_conv {
 
-// Exact n / d for 0 <= n < 2^31 by one 32 x 32 -> 64-bit multiply (d fixed per launch): mul = ceil(2^(31 + s) / d), s = ceil(log2 d).
-// (A per-lane integer division is ~40 VALU instructions on gfx950; a tile prologue has two per staged pixel row.)
-struct FastDiv {
-    uint32_t mul = 0x80000000u, shift = 0;
-};
-inline FastDiv make_fastdiv(uint32_t d) {
-    FastDiv f;
-    while ((1u << f.shift) < d) ++f.shift;
-    f.mul = (uint32_t)(((1ull << (31 + f.shift)) + d - 1) / d);
-    return f;
-}
-__device__ __forceinline__ int fastdiv(int n, FastDiv f) { return (int)((uint32_t)(((uint64_t)(uint32_t)n * f.mul) >> 31) >> f.shift); }
-
 struct ConvArgs {
     const char* in;
     const char* weight;

@@ -50,79 +50,105 @@ __global__ void km3d_zero_kernel(int32_t* a, int n) {
 // LDS append) and reserves room in the channel's global list with ONE atomicAdd.  (One global atomic per wave and iteration --
 // the first version -- put ~900 atomics on each of the B x 12 counters: with many candidates, e.g. untrained weights, those
 // serialised into 0.7 ms per launch at 16 x 128 x 440.)  The order inside a list is irrelevant: the top-K kernel sorts it.
-constexpr int kPeakSpan = 1024;
-// The sigmoid of the span and of one image row (+ 1 pixel) on either side is evaluated ONCE into LDS; the 3x3 test then compares LDS
-// values.  (First version: every candidate re-evaluated the sigmoid of its eight neighbours from global memory -- with many candidates,
-// e.g. untrained weights, nine expf per pixel and channel: 127 us per launch at 16 x 128 x 440, VALU bound.)  Same function, same
-// comparisons: the peak lists are identical.
-__global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p) {
+// One workgroup = one 8 x 64-pixel tile of ONE heat map (blockIdx.z: class map | keypoint map) with ALL its channels: the tile's logits
+// (+ a one-pixel ring) are read once, as contiguous [pixel][channel] row segments, their sigmoid goes to LDS in the same layout, and
+// the 3x3 test compares LDS values (ring positions outside the image hold 0, below every candidate).  Peaks are collected per channel
+// in LDS (wave-aggregated append) and each channel's run reserves room in the global list with ONE atomicAdd.
+// History: v1 one (sample, channel) per workgroup, sigmoid of the eight neighbours re-evaluated from global memory per candidate, one
+// global atomic per wave (0.7 ms at 16 x 128 x 440 with untrained weights); v2 workgroup-aggregated atomics (127 us); v3 the span's
+// sigmoid once into LDS (97 us: every workgroup still walked its channel with a 12 / 36-byte stride, 9 channels re-reading the same
+// lines).  Same function, same comparisons: the lists hold the same peaks (their order inside a list is irrelevant: the top-K kernel
+// sorts by (score, index)).
+constexpr int kPeakTH = 8, kPeakTW = 64, kPeakPix = kPeakTH * kPeakTW, kPeakRing = (kPeakTH + 2) * (kPeakTW + 2);
+constexpr int kPeakMaxC = 9;
+__global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p, int tiles_x, FastDiv fd_tiles_x, FastDiv fd_rowlen0, FastDiv fd_c0, FastDiv fd_rowlen1,
+                                                         FastDiv fd_c1) {
     extern __shared__ __attribute__((aligned(16))) char peaks_smem[];
-    __shared__ float s_score[kPeakSpan];
-    __shared__ int s_idx[kPeakSpan];
-    __shared__ int s_n, s_base;
-    float* sg = (float*)peaks_smem;                    // sigmoid of pixels [first - W - 1, first + kPeakSpan + W + 1)
-    const int nch = p.n_cls + p.J;
-    const int slot = blockIdx.y;                       // b * nch + ch
-    const int b = slot / nch, ch = slot - b * nch;
-    const bool is_hm = ch < p.n_cls;
-    const float* m = (is_hm ? p.hm : p.hm_hp);
-    const int C = is_hm ? p.n_cls : p.J, c = is_hm ? ch : ch - p.n_cls;
+    __shared__ int s_n[kPeakMaxC], s_base[kPeakMaxC];
+    __shared__ uint64_t s_mask[kPeakMaxC * kPeakTH];
+    const bool is_hm = blockIdx.z == 0;
+    const int C = is_hm ? p.n_cls : p.J;
+    if (C <= 0) return;
+    const FastDiv fd_rowlen = is_hm ? fd_rowlen0 : fd_rowlen1;
+    (void)fd_c0; (void)fd_c1;
+    const float* m = is_hm ? p.hm : p.hm_hp;
     const float thr = is_hm ? p.score_thr : 0.1f;
-    const int HW = p.H * p.W, W = p.W;
-    const float* mb = m + (int64_t)b * HW * C + c;
+    const int ch0 = is_hm ? 0 : p.n_cls, nch = p.n_cls + p.J;
+    const int b = blockIdx.y, H = p.H, W = p.W;
+    const int ty = fastdiv((int)blockIdx.x, fd_tiles_x), tx = (int)blockIdx.x - ty * tiles_x;
+    const int rowlen = (kPeakTW + 2) * C;                 // floats of one ring row
+    float* sg = (float*)peaks_smem;                       // [kPeakTH + 2][kPeakTW + 2][C] sigmoid
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) s_n = 0;
-    const int first = blockIdx.x * kPeakSpan;
-    const int lo = first - W - 1, nsg = kPeakSpan + 2 * (W + 1);
-    for (int i = threadIdx.x; i < nsg; i += 256) {
-        const int pix = lo + i;
-        sg[i] = (pix >= 0 && pix < HW) ? sigm(mb[(int64_t)pix * C]) : 0.f;
+    const float* mb = m + (int64_t)b * H * W * C;
+    const int x0c = (tx * kPeakTW - 1) * C, WC = W * C;
+    // (eight independent loads in flight per thread: one load per loop trip made the fill a chain of ~23 memory round trips)
+    for (int i0 = threadIdx.x; i0 < kPeakRing * C; i0 += 256 * 8) {
+        float raw[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int r = fastdiv(i, fd_rowlen), j = i - r * rowlen;
+            const int y = ty * kPeakTH - 1 + r, xc = x0c + j;
+            ok[u] = i < kPeakRing * C && (unsigned)y < (unsigned)H && (unsigned)xc < (unsigned)WC;
+            raw[u] = ok[u] ? mb[(int64_t)y * WC + xc] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            if (i < kPeakRing * C) sg[i] = ok[u] ? sigm(raw[u]) : 0.f;
+        }
     }
     __syncthreads();
-    for (int it = 0; it < kPeakSpan / 256; ++it) {
-        const int pix = first + it * 256 + threadIdx.x;
-        bool peak = false;
-        float v = 0.f;
-        if (pix < HW) {
-            const int y = pix / W, x = pix - y * W;
-            const float* ctr = sg + (pix - lo);
-            v = ctr[0];
-            if (v > thr) {
-                peak = true;
-                for (int dy = -1; dy <= 1 && peak; ++dy) {
-                    const int yy = y + dy;
-                    if ((unsigned)yy >= (unsigned)p.H) continue;
-                    for (int dx = -1; dx <= 1; ++dx) {
-                        const int xx = x + dx;
-                        if ((unsigned)xx >= (unsigned)W || (dx == 0 && dy == 0)) continue;
-                        if (ctr[dy * W + dx] > v) { peak = false; break; }
-                    }
-                }
-            }
-        }
-        const uint64_t mask = __ballot(peak);
-        if (mask) {
-            int pos0 = 0;
-            if (lane == 0) pos0 = atomicAdd(&s_n, __popcll(mask));
-            pos0 = __shfl(pos0, 0);
+    // thread <-> pixel (two per thread), channels one after the other: every lane of a wave tests the same channel, so a step's result
+    // is ONE ballot -- kept as a 64-bit word per (channel, 64-pixel row) in LDS.  (Peak LISTS in LDS, sized for the worst case -- a
+    // plateau makes every pixel a peak -- cost 37 KB and left two workgroups per CU; the bit masks leave six.)
+    const int wave = threadIdx.x >> 6;
+    for (int pl = threadIdx.x; pl < kPeakPix; pl += 256) {
+        const int yl = pl / kPeakTW, xl = pl - yl * kPeakTW;             // (a wave = one 64-pixel tile row)
+        const int y = ty * kPeakTH + yl, x = tx * kPeakTW + xl;
+        const bool inside = y < H && x < W;
+        const float* ctr0 = sg + (yl + 1) * rowlen + (xl + 1) * C;
+        for (int c = 0; c < C; ++c) {
+            const float* ctr = ctr0 + c;
+            const float v = ctr[0];
+            bool peak = inside && v > thr;
             if (peak) {
-                const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
-                s_score[pos] = v;
-                s_idx[pos] = pix;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx)
+                        if ((dx != 0 || dy != 0) && ctr[dy * rowlen + dx * C] > v) peak = false;
             }
+            const uint64_t mask = __ballot(peak);
+            if (lane == 0) s_mask[c * kPeakTH + yl] = mask;
         }
     }
+    (void)wave;
     __syncthreads();
-    const int n = s_n;
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(p.peak_count + slot, n);
+    // per channel: count, reserve the run in the global list with one atomicAdd, then every peak writes itself at base + its rank
+    if (threadIdx.x < C) {
+        int n = 0;
+        for (int r = 0; r < kPeakTH; ++r) n += __popcll(s_mask[threadIdx.x * kPeakTH + r]);
+        s_n[threadIdx.x] = n;
+        s_base[threadIdx.x] = n > 0 ? atomicAdd(p.peak_count + b * nch + ch0 + threadIdx.x, n) : 0;
+    }
     __syncthreads();
-    const int base = s_base;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int pos = base + i;
-        if (pos < p.max_peaks) {
-            p.peak_score[(int64_t)slot * p.max_peaks + pos] = s_score[i];
-            p.peak_idx[(int64_t)slot * p.max_peaks + pos] = s_idx[i];
+    for (int pl = threadIdx.x; pl < kPeakPix; pl += 256) {
+        const int yl = pl / kPeakTW, xl = pl - yl * kPeakTW;
+        const int pix = (ty * kPeakTH + yl) * W + tx * kPeakTW + xl;
+        for (int c = 0; c < C; ++c) {
+            if (s_n[c] == 0) continue;
+            const uint64_t mask = s_mask[c * kPeakTH + yl];
+            if (!((mask >> xl) & 1ull)) continue;
+            int rank = __popcll(mask & ((1ull << xl) - 1ull));
+            for (int r = 0; r < yl; ++r) rank += __popcll(s_mask[c * kPeakTH + r]);
+            const int pos = s_base[c] + rank;
+            if (pos < p.max_peaks) {
+                const int64_t slot = (int64_t)(b * nch + ch0 + c) * p.max_peaks;
+                p.peak_score[slot + pos] = sg[(yl + 1) * rowlen + (xl + 1) * C + c];
+                p.peak_idx[slot + pos] = pix;
+            }
         }
     }
 }
@@ -457,10 +483,16 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_cls = q->out_cls; a.out_count = q->out_count;
     const int nz = (int)(((int64_t)q->B * nch * 4 + 255) / 256 * 256 + (int64_t)q->B * 4) / 4;
     hipLaunchKernelGGL(km3d_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, w.peak_count, nz);
-    const int gx = (q->H * q->W + kPeakSpan - 1) / kPeakSpan;
-    const int peaks_lds = (kPeakSpan + 2 * (q->W + 1)) * 4;      // the span's sigmoid tile (+ one row and a pixel on either side)
-    if (peaks_lds > 48 * 1024) { vd3d_set_error("km3d_decode: heat-map wider than 5 631 pixels"); return VD3D_ERANGE; }
-    hipLaunchKernelGGL(km3d_peaks_kernel, dim3((unsigned)gx, (unsigned)(q->B * nch)), dim3(256), peaks_lds, s, a);
+    if (q->n_cls > kPeakMaxC || q->n_joints > kPeakMaxC) { vd3d_set_error("km3d_decode: more than 9 heat-map channels per map"); return VD3D_ERANGE; }
+    {
+        const int tiles_x = (q->W + kPeakTW - 1) / kPeakTW, tiles_y = (q->H + kPeakTH - 1) / kPeakTH;
+        const int cmax = q->n_cls > q->n_joints ? q->n_cls : q->n_joints;
+        const int peaks_lds = kPeakRing * cmax * 4;                       // the tile's sigmoid ring
+        const int c0 = q->n_cls > 0 ? q->n_cls : 1, c1 = q->n_joints > 0 ? q->n_joints : 1;
+        hipLaunchKernelGGL(km3d_peaks_kernel, dim3((unsigned)(tiles_x * tiles_y), (unsigned)q->B, 2), dim3(256), peaks_lds, s, a, tiles_x,
+                           make_fastdiv((uint32_t)tiles_x), make_fastdiv((uint32_t)((kPeakTW + 2) * c0)), make_fastdiv((uint32_t)c0),
+                           make_fastdiv((uint32_t)((kPeakTW + 2) * c1)), make_fastdiv((uint32_t)c1));
+    }
     int rc = vd3d_check_launch("km3d_peaks");
     if (rc) return rc;
     const int lds = (q->max_peaks + kTopkSort) * 8;      // the key list + the compacted candidates of the radix select
