@@ -315,6 +315,14 @@ int vd3d_kitti_postpath(const float* boxes, const int32_t* counts, const float* 
                         int B, int cap, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Two chained 3x3 convolutions in one launch: `a` (stride 1, pad 1, 16 -> 16 channels) + folded BN + ReLU, then `b` (stride 2, pad 1,
+ * 16 -> <= 32 channels) + folded BN + ReLU -- DLA level0 -> level1 (backbones/dla.py:118-121, :142-148 `_make_conv_level`; called
+ * from DLA.forward :150-158).  Both are the vd3d_conv2d_igemm parameter blocks of the two convolutions (16-bit formats, packed
+ * weights, scale / shift, relu flags); `a->out` and `b->in` are ignored: the intermediate tensor (the rounding point of the unfused
+ * path) lives in LDS only.  b's geometry must continue a's (b->B/H/W == a->B/Ho/Wo).  Results are bit-identical to the two calls. */
+int vd3d_conv2d_pair(const vd3d_conv_params* a, const vd3d_conv_params* b, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * KM3D head, fused (heads/km3d_head.py:132-153,353-357: nine branches conv3x3(64 -> 256) + ReLU + conv1x1(256 -> n_h)).  The nine
  * 3x3 convs run as ONE implicit GEMM with Cout = 256 x heads (`p`: the vd3d_conv2d_igemm parameters of that conv, bf16,
  * shift = the concatenated first-conv biases, relu implied, `p->out` ignored); each 256-pixel x 256-channel tile applies bias +

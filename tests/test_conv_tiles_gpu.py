@@ -285,3 +285,30 @@ def test_grouped_tile_order_of_huge_1x1_gemms(cfg):
         assert torch.equal(a, b), (cfg, B, H, W, Cin, Cout)
     ulp, rel = run_case(2, 18, 40, 192, 544, k=1, pad=0, residual=True, dtype=torch.bfloat16, seed=77, cfg=cfg)
     assert ulp <= 1.0
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,W,Cb', [(1, 16, 64, 32), (2, 37, 91, 32), (1, 9, 130, 16), (3, 64, 250, 32), (4, 512, 1760, 32)])
+def test_level_pair_kernel_is_bit_identical_to_two_launches(dtype, B, H, W, Cb):
+    """vd3d_conv2d_pair (DLA level0 -> level1, backbones/dla.py:118-121: conv 3x3 / s1 16 -> 16 + BN + ReLU, conv 3x3 / s2 16 -> 32 + BN +
+    ReLU) against the two small-channel launches it replaces (each of which tests above pin to the oracle): same MFMA shapes, tap
+    order and rounding points -> identical bits.  Odd sizes (ragged tiles on both levels, odd H / W under the stride), more tiles
+    than workgroups (the last case is BASELINE config 5's own shape: 14 080 tiles)."""
+    from visualdet3d_amd import hip_ops as ops
+    g = torch.Generator().manual_seed(B * 100 + H)
+    x = torch.randn(B, H, W, 16, generator=g).cuda().to(dtype)
+
+    def mk(cin, cout, stride, seed):
+        gg = torch.Generator().manual_seed(seed)
+        w = torch.randn(cout, cin, 3, 3, generator=gg) * (2.0 / (9 * cin)) ** 0.5
+        bn = (torch.rand(cout, generator=gg) + 0.5, torch.randn(cout, generator=gg) * 0.1, torch.randn(cout, generator=gg) * 0.1,
+              torch.rand(cout, generator=gg) + 0.5, 1e-5)
+        return ops.pack_conv(w.cuda(), None, tuple(t.cuda() if torch.is_tensor(t) else t for t in bn), dtype, stride, 1, 1)
+
+    pa, pb = mk(16, 16, 1, 1), mk(16, Cb, 2, 2)
+    assert ops.conv2d_pair_supported(pa, pb)
+    want = ops.conv2d(ops.conv2d(x, pa, relu=True), pb, relu=True)
+    got = ops.conv2d_pair(x, pa, pb)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))

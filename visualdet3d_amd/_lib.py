@@ -124,6 +124,7 @@ SIGNATURES = {
     'vd3d_kitti_postpath': (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     'vd3d_preprocess_image': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vd3d_rotate_iou_eval': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'vd3d_conv2d_pair': (c_int, [C.POINTER(ConvParams), C.POINTER(ConvParams), c_void_p]),
     'vd3d_km3d_head_fused': (c_int, [C.POINTER(ConvParams), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'vd3d_post_opt': (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_float] * 3 + [c_int, c_void_p]),
 }

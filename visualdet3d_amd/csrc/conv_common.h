@@ -50,6 +50,8 @@ bool small_shape_ok(const ConvArgs& a);                                // 3x3, s
 int launch_small(ConvArgs& a, hipStream_t stream, int fmt);           // small-channel streaming kernel
 bool narrow_shape_ok(const ConvArgs& a);                               // 3x3 / s1 / p1, Cin % 64 == 0 (>= 128), Cout <= 32, weight_frag given
 int launch_narrow(ConvArgs& a, hipStream_t stream, int fmt);          // narrow-output streaming kernel (chunked small-channel kernel)
+bool pair_shape_ok(const ConvArgs& a, const ConvArgs& b);               // conv A 3x3 / s1 16 -> 16, conv B 3x3 / s2 16 -> <= 32, 16-bit
+int launch_pair(ConvArgs& a, ConvArgs& b, hipStream_t stream, int fmt);   // DLA level0 + level1 in one launch
 bool km3d_head_shape_ok(const ConvArgs& a);                            // 3x3 / s1 / p1, Cin % 64 == 0, Cout = 256 x branches (h_* fields set)
 int launch_km3d_head(ConvArgs& a, hipStream_t stream, int fmt);       // persistent fused KM3D head (km3d_head_conv.hip)
 bool pw_shape_ok(const ConvArgs& a);                                   // 1x1 / stride 1, Cin 64 | 128 | 256, Cout % 256 == 0, weight_frag given

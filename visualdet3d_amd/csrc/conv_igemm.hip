@@ -1437,6 +1437,27 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
     return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : (p->dtype == VD3D_F16 ? dispatch<hf16>(a, s) : dispatch<float>(a, s));
 }
 
+extern "C" int vd3d_conv2d_pair(const vd3d_conv_params* pa, const vd3d_conv_params* pb, void* stream) {
+    if (!pa || !pb) { vd3d_set_error("conv2d_pair: null pointer"); return VD3D_EINVAL; }
+    if ((pa->dtype != VD3D_BF16 && pa->dtype != VD3D_F16) || pb->dtype != pa->dtype) { vd3d_set_error("conv2d_pair: both convs in the same 16-bit format"); return VD3D_EINVAL; }
+    vd3d_conv_params qa = *pa, qb = *pb;
+    qa.out = pb->out;                              // (unused: keeps the generic checks of the parameter block happy)
+    qa.out_pix_stride = pa->Cout;
+    qb.in = pa->in;
+    qb.in_pix_stride = pb->Cin; qb.in_row_stride = pb->W * pb->Cin; qb.in_batch_stride = (int64_t)pb->H * pb->W * pb->Cin;
+    qb.in_bytes = pa->in_bytes;
+    ConvArgs a, b;
+    int rc = fill_conv_args(&qa, a);
+    if (rc) return rc;
+    rc = fill_conv_args(&qb, b);
+    if (rc) return rc;
+    if (!pair_shape_ok(a, b)) {
+        vd3d_set_error("conv2d_pair: needs conv A 3x3/s1/p1 16 -> 16 and conv B 3x3/s2/p1 16 -> 16 | 32 continuing A's geometry, 16-bit, no residual");
+        return VD3D_EINVAL;
+    }
+    return launch_pair(a, b, (hipStream_t)stream, pa->dtype);
+}
+
 extern "C" int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_packed, const float* b2, void* const* outs,
                                     const int32_t* n_out, int n_heads, void* stream) {
     if (!p || !w2_packed || !b2 || !outs || !n_out) { vd3d_set_error("km3d_head_fused: null pointer"); return VD3D_EINVAL; }

@@ -1257,6 +1257,222 @@ __global__ void __launch_bounds__(512) conv_narrow_kernel(const ConvArgs p, int 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMA must not land in a successor workgroup's LDS
 }
 
+// =====================================================================================================
+// "level pair" kernel: conv A (3x3 / s1 / p1, 16 -> 16) + BN + ReLU followed by conv B (3x3 / s2 / p1, 16 -> <= 32) + BN + ReLU in ONE
+// launch -- DLA level0 -> level1 (backbones/dla.py:118-121, :142-148) at full / half resolution: 16 x 512 x 1760 x 16 channels are
+// 461 MB that the two small-channel launches wrote and read back (197 + 132 us, both HBM bound).  A workgroup owns 8 x 32 outputs of
+// conv B = 17 x 65 outputs of conv A (1.08x the pixels a non-overlapping split would compute) = a 19 x 67-pixel halo of the input,
+// staged by LDS-DMA two tiles ahead (three 40 KiB stages: with one tile ahead the 40 KB in flight per CU could not cover the memory
+// latency -- 288 us against 411 for the two launches; ...).  Phase 1: conv A on the matrix cores from the halo (32-pixel blocks dealt to
+// the waves, weights in registers), BN + ReLU, rounded to the 16-bit format (the rounding point of the unfused tensor), positions
+// outside the image zeroed (conv B's zero padding), into a [17 x 65][16] LDS image.  Phase 2: the small-channel kernel's stride-2
+// step from that image.  Same MFMA shapes and tap order as the two launches: results are bit-identical.
+constexpr int kPrTH = 8, kPrTW = 32;
+constexpr int kPrYH = 2 * kPrTH + 1, kPrYW = 2 * kPrTW + 1, kPrYN = kPrYH * kPrYW;            // 17 x 65 conv-A outputs
+constexpr int kPrXH = kPrYH + 2, kPrXW = kPrYW + 2, kPrXN = kPrXH * kPrXW;                    // 19 x 67 input halo
+constexpr int kPrXP = (kPrXN + 31) / 32, kPrXStage = kPrXP * 1024;                           // 40 pieces of 32 pixels x 32 B
+constexpr int kPrNst = 3;                                                                    // halo stages: two tiles ahead
+constexpr int kPrYB = (kPrYN + 31) / 32, kPrYOff = kPrNst * kPrXStage, kPrYBytes = kPrYB * 1024; // 35 blocks
+constexpr int kPrSS = kPrYOff + kPrYBytes, kPrLds = kPrSS + 512;
+
+template <typename T>
+__global__ void __launch_bounds__(512) conv_pair_kernel(const ConvArgs pa, const ConvArgs pb, int ntiles) {
+    constexpr int P = (kPrXP + 7) / 8;                // DMA pieces per wave and tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, half = lane >> 5;
+    const int H = pa.H, W = pa.W;                      // conv A: H x W -> H x W;  conv B: -> Ho x Wo
+    const int tiles_x = (pb.Wo + kPrTW - 1) / kPrTW, tiles_y = (pb.Ho + kPrTH - 1) / kPrTH, tiles_img = tiles_x * tiles_y;
+    // ---- weights -> registers (A operand: row = output channel, zero rows beyond Cout; one 16-channel k-step per tap) ----------------
+    i32x4 wa[9], wb[9];
+    {
+        const char* ra = pa.weight + (size_t)lr * pa.Kpad * 2;
+        const char* rb = pb.weight + (size_t)lr * pb.Kpad * 2;
+        static_for<9>([&](auto tc) {
+            constexpr int tap = decltype(tc)::value;
+            wa[tap] = *(const i32x4*)(ra + (tap * 16 + half * 8) * 2);
+            wb[tap] = *(const i32x4*)(rb + (tap * 16 + half * 8) * 2);
+        });
+    }
+    float* ss = (float*)(smem + kPrSS);                // A: scale[32] shift[32] | B: scale[32] shift[32]
+    if (tid < 32) {
+        ss[tid] = (pa.scale && tid < pa.Cout) ? pa.scale[tid] : 1.f;
+        ss[32 + tid] = (pa.shift && tid < pa.Cout) ? pa.shift[tid] : 0.f;
+        ss[64 + tid] = (pb.scale && tid < pb.Cout) ? pb.scale[tid] : 1.f;
+        ss[96 + tid] = (pb.shift && tid < pb.Cout) ? pb.shift[tid] : 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pa.in, 0, pa.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pb.out, 0, 0x80000000u, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int in_bs = (int)pa.in_batch_stride;
+    // a lane's halo pixels are the same in every tile (piece q = wave + 8 it, pixel 32 q + lane / 2): position and source offset
+    // relative to the tile origin are computed once (per tile they were five constant divisions and 150 VALU instructions per lane)
+    int h_yx[P], h_off[P];
+#pragma unroll
+    for (int it = 0; it < P; ++it) {
+        const int hr = (wave + it * 8) * 32 + (lane >> 1);
+        const int hy = hr / kPrXW, hx = hr - hy * kPrXW;
+        h_yx[it] = hr < kPrXN ? (hy << 16) | hx : -1;
+        h_off[it] = hy * pa.in_row_stride + hx * pa.in_pix_stride + (lane & 1) * 8;
+    }
+    auto issue_halo = [&](int t, int stage) {
+        const bool tv = t < ntiles;
+        const int tt = tv ? t : 0;
+        const int b = tt / tiles_img, trem = tt - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        char* base = smem + stage * kPrXStage;
+        const int y0 = 2 * ty * kPrTH - 2, x0 = 2 * tx * kPrTW - 2;
+        const int org = b * in_bs + y0 * pa.in_row_stride + x0 * pa.in_pix_stride;
+#pragma unroll
+        for (int it = 0; it < P; ++it) {
+            const int q = wave + it * 8;               // (kPrXP = 40 = 5 x 8: no partial round)
+            const int iy = y0 + (h_yx[it] >> 16), ix = x0 + (h_yx[it] & 0xffff);
+            const bool v = tv && h_yx[it] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const uint32_t off = ((uint32_t)(org + h_off[it]) * 2u) | (v ? 0u : kOOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + q * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    static_assert(kPrXP % 8 == 0, "halo pieces must split evenly over the waves");
+    // phase-2 fragment addresses (as the small-channel kernel with S = 2): wave = output row, lane = output pixel
+    int b_tap[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) b_tap[tap] = ((wave * 2 + tap / 3) * kPrYW + lr * 2 + tap % 3) * 32 + half * 16;
+    const float relu_a = pa.relu ? 0.f : -3.0e38f, relu_b = pb.relu ? 0.f : -3.0e38f;
+    const int nwg = gridDim.x;
+    int t = blockIdx.x, stage = 0, k = 0;
+    issue_halo(t, 0);
+    issue_halo(t + nwg, 1);
+    // VMEM queue of a wave: D(k) [P pieces, top of tile k - 2] S(k - 2) [2 stores] D(k + 1) S(k - 1): at the top of tile k the halo D(k)
+    // must have landed, with 2 P + 4 younger operations allowed in flight (the first two tiles: only the halos are in the queue)
+    for (; t < ntiles; t += nwg, ++k) {
+        const int b = t / tiles_img, trem = t - b * tiles_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        if (k < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P + 4) : "memory");
+        __builtin_amdgcn_s_barrier();                                     // ... for everybody; the conv-A image is free again
+        asm volatile("" ::: "memory");
+        const int nstage = stage + 2 >= kPrNst ? stage + 2 - kPrNst : stage + 2;
+        issue_halo(t + 2 * nwg, nstage);                                  // (the stage tile k - 1 read: everybody is past it)
+        // ---- phase 1: conv A on 32-pixel blocks of the 17 x 65 region -------------------------------------------------------------
+        const char* X = smem + stage * kPrXStage;
+        // (two blocks per step: their MFMA chains -- nine dependent accumulations each -- interleave)
+        for (int blk0 = wave; blk0 < kPrYB; blk0 += 16) {
+            const char* xq[2];
+            int qq[2];
+            bool inside[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int blk = blk0 + 8 * u < kPrYB ? blk0 + 8 * u : blk0;      // (a wave's odd last block is done twice: same values)
+                const int q = blk * 32 + lr;
+                const int qc = q < kPrYN ? q : kPrYN - 1;
+                const int ry = qc / kPrYW, rx = qc - ry * kPrYW;
+                xq[u] = X + (ry * kPrXW + rx) * 32 + half * 16;
+                qq[u] = q;
+                const int ay = 2 * ty * kPrTH - 1 + ry, ax = 2 * tx * kPrTW - 1 + rx;
+                inside[u] = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+            }
+            f32x16 acc[2];
+            static_for<9>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const i32x4 fb = *(const i32x4*)(xq[u] + ((tap / 3) * kPrXW + tap % 3) * 32);
+                    if constexpr (tap == 0) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        Fmt16<T>::mfma32z(wa[0], fb, zero, acc[u]);
+                    } else
+                        Fmt16<T>::mfma32(wa[tap], fb, acc[u]);
+                }
+            });
+            // lane (pixel, half) holds channels 8 g + 4 half + e (g = 0, 1 real): BN + ReLU, 16-bit, zero outside the image
+            const f32x4 s0 = *(const f32x4*)(ss + 4 * half), h0 = *(const f32x4*)(ss + 32 + 4 * half);
+            const f32x4 s1 = *(const f32x4*)(ss + 8 + 4 * half), h1 = *(const f32x4*)(ss + 40 + 4 * half);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float va[4], vb[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    va[e] = inside[u] ? fmaxf(acc[u][e] * s0[e] + h0[e], relu_a) : 0.f;
+                    vb[e] = inside[u] ? fmaxf(acc[u][4 + e] * s1[e] + h1[e], relu_a) : 0.f;
+                }
+                const int x0 = Fmt16<T>::pack2(va[0], va[1]), x1 = Fmt16<T>::pack2(va[2], va[3]);
+                const int y0 = Fmt16<T>::pack2(vb[0], vb[1]), y1 = Fmt16<T>::pack2(vb[2], vb[3]);
+                auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                *(i32x4*)(smem + kPrYOff + qq[u] * 32 + half * 16) = i32x4{(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};   // channels 8 half .. + 7
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- phase 2: conv B (stride 2) from the conv-A image ------------------------------------------------------------------------
+        {
+            const char* Y = smem + kPrYOff;
+            f32x16 acc;
+            static_for<9>([&](auto tc) {
+                constexpr int tap = decltype(tc)::value;
+                const i32x4 fb = *(const i32x4*)(Y + b_tap[tap]);
+                if constexpr (tap == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    Fmt16<T>::mfma32z(wb[0], fb, zero, acc);
+                } else
+                    Fmt16<T>::mfma32(wb[tap], fb, acc);
+            });
+            const int y = ty * kPrTH + wave, x = tx * kPrTW + lr;
+            const bool pin = y < pb.Ho && x < pb.Wo;
+            const uint32_t obase = (uint32_t)(((b * pb.Ho + y) * pb.Wo + x) * pb.out_pix_stride);
+            auto chan4 = [&](int g, float (&v)[4]) {
+                const f32x4 sc = *(const f32x4*)(ss + 64 + 8 * g + 4 * half), sh = *(const f32x4*)(ss + 96 + 8 * g + 4 * half);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(acc[4 * g + e] * sc[e] + sh[e], relu_b);
+            };
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                float va[4], vb[4];
+                chan4(g, va);
+                chan4(g + 1, vb);
+                const int x0 = Fmt16<T>::pack2(va[0], va[1]), x1 = Fmt16<T>::pack2(va[2], va[3]);
+                const int y0 = Fmt16<T>::pack2(vb[0], vb[1]), y1 = Fmt16<T>::pack2(vb[2], vb[3]);
+                auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                i32x4 o = {(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};
+                const int n = 8 * (g + half);
+                const uint32_t off = ((obase + n) * 2u) | (pin && n < pb.Cout ? 0u : kOOB);
+                __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
+            }
+        }
+        stage = stage + 1 == kPrNst ? 0 : stage + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMA must not land in a successor workgroup's LDS
+}
+
+bool pair_shape_ok(const ConvArgs& a, const ConvArgs& b) {
+    return a.Cin == 16 && a.Cout == 16 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && !a.residual && !a.out_f32 &&
+           b.Cin == 16 && b.Cout <= 32 && b.Cout % 16 == 0 && b.kh == 3 && b.kw == 3 && b.stride == 2 && b.pad == 1 && b.dil == 1 && !b.residual &&
+           !b.out_f32 && b.B == a.B && b.H == a.Ho && b.W == a.Wo && a.Ho == a.H && a.Wo == a.W && a.in_pix_stride % 8 == 0 &&
+           b.out_pix_stride % 8 == 0 && ((uintptr_t)b.out & 15) == 0 && (int64_t)b.M * b.out_pix_stride * 2 < 0x7ffffff0ll &&
+           (!a.scale || ((uintptr_t)a.scale & 15) == 0) && (!a.shift || ((uintptr_t)a.shift & 15) == 0) &&
+           (!b.scale || ((uintptr_t)b.scale & 15) == 0) && (!b.shift || ((uintptr_t)b.shift & 15) == 0);
+}
+
+int launch_pair(ConvArgs& a, ConvArgs& b, hipStream_t stream, int fmt) {
+    const int num_cu = vd3d_device_cu_count();
+    if (num_cu <= 0) return VD3D_ELAUNCH;
+    const int ntiles = b.B * ((b.Ho + kPrTH - 1) / kPrTH) * ((b.Wo + kPrTW - 1) / kPrTW);
+    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    static Vd3dLdsLimit limh, limb;
+    if (fmt == VD3D_F16) {
+        if (const int rc = vd3d_raise_lds_limit((const void*)conv_pair_kernel<hf16>, kPrLds, limh, "hipFuncSetAttribute(conv_pair)")) return rc;
+        hipLaunchKernelGGL(conv_pair_kernel<hf16>, dim3(grid), dim3(512), kPrLds, stream, a, b, ntiles);
+    } else {
+        if (const int rc = vd3d_raise_lds_limit((const void*)conv_pair_kernel<short>, kPrLds, limb, "hipFuncSetAttribute(conv_pair)")) return rc;
+        hipLaunchKernelGGL(conv_pair_kernel<short>, dim3(grid), dim3(512), kPrLds, stream, a, b, ntiles);
+    }
+    return vd3d_check_launch("conv_pair");
+}
+
+
 bool narrow_shape_ok(const ConvArgs& a) {
     const bool out16 = !a.out_f32;
     return a.Cin % 64 == 0 && a.Cin >= 128 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Cout <= 32 &&

@@ -187,6 +187,45 @@ def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
     return out
 
 
+def conv2d_pair(x, pc_a, pc_b, relu_a=True, relu_b=True):
+    """Two chained 3x3 convs in ONE launch (vd3d_conv2d_pair): ``pc_a`` stride 1, 16 -> 16, then ``pc_b`` stride 2, 16 -> <= 32, each
+    + folded BN (+ ReLU) -- DLA level0 -> level1.  The intermediate tensor is never written.  Bit-identical to two ``conv2d`` calls."""
+    _require_cuda(x, pc_a.w, pc_b.w)
+    B, H, W, Cx = x.shape
+    assert x.dtype == pc_a.dtype == pc_b.dtype and is16(x.dtype) and Cx == pc_a.Cin
+    ips, irs, ibs = _nhwc_strides(x)
+    span1 = ((H - 1) * irs + (W - 1) * ips + Cx) * x.element_size()
+    assert (B - 1) * ibs * x.element_size() + span1 <= _MAX_IN_BYTES, 'conv2d_pair: input view beyond 2 GiB'
+    Ho = (H + 2 * pc_b.pad - pc_b.dil * (pc_b.kh - 1) - 1) // pc_b.stride + 1
+    Wo = (W + 2 * pc_b.pad - pc_b.dil * (pc_b.kw - 1) - 1) // pc_b.stride + 1
+    out = torch.empty((B, Ho, Wo, pc_b.Cout), dtype=x.dtype, device=x.device)
+
+    def params(pc, Hi, Wi, Hout, Wout, relu):
+        p = ConvParams()
+        p.in_, p.weight, p.out = x.data_ptr(), pc.w.data_ptr(), out.data_ptr()
+        p.scale = pc.scale.data_ptr() if pc.scale is not None else None
+        p.shift = pc.shift.data_ptr() if pc.shift is not None else None
+        p.B, p.H, p.W, p.Cin = B, Hi, Wi, pc.Cin
+        p.in_pix_stride, p.in_row_stride, p.in_batch_stride = ips, irs, ibs
+        p.in_bytes = min(_bytes_from(x), (B - 1) * ibs * x.element_size() + span1)
+        p.Ho, p.Wo, p.Cout = Hout, Wout, pc.Cout
+        p.out_pix_stride = out.stride(2)
+        p.kh, p.kw, p.stride, p.pad, p.dil = pc.kh, pc.kw, pc.stride, pc.pad, pc.dil
+        p.Kpad, p.CoutPad, p.relu = pc.Kpad, pc.CoutPad, int(relu)
+        p.dtype, p.out_f32 = dtype_code(x.dtype), 0
+        return p
+
+    pa, pb = params(pc_a, H, W, H, W, relu_a), params(pc_b, H, W, Ho, Wo, relu_b)
+    check(_lib.lib().vd3d_conv2d_pair(C.byref(pa), C.byref(pb), _stream()), 'vd3d_conv2d_pair')
+    return out
+
+
+def conv2d_pair_supported(pc_a, pc_b):
+    k = lambda pc: (pc.kh, pc.kw, pc.pad, pc.dil)
+    return (is16(pc_a.dtype) and pc_a.dtype == pc_b.dtype and k(pc_a) == k(pc_b) == (3, 3, 1, 1) and pc_a.stride == 1 and pc_b.stride == 2 and
+            pc_a.Cin == 16 and pc_a.Cout == 16 and pc_b.Cin == 16 and pc_b.Cout in (16, 32))
+
+
 def _pack_stem_images(img_nchw, dtype):
     """NCHW fp32 image(s) -> bordered NHWC4 [B, H+6, W+8, 4].  A list / tuple of images is packed into consecutive batch
     slices (stereo: left then right -- no torch.cat copy)."""

@@ -12,6 +12,9 @@ from ..lib import fused
 from ..utils.registry import BACKBONE_DICT
 from .resnet import _conv_bn
 
+import os
+_PAIR = not os.environ.get('VD3D_NO_LEVEL_PAIR')     # A/B: level0 and level1 as two launches
+
 BatchNorm = nn.BatchNorm2d
 
 
@@ -152,7 +155,9 @@ class DLA(nn.Module):
             x = ops.conv2d(x, _conv_bn(self._cache, (name, i), seq[i], seq[i + 1], x.dtype), relu=True)
         return x
 
-    def forward_nhwc(self, img_nchw, dtype=None):
+    def forward_nhwc(self, img_nchw, dtype=None, first_needed=0):
+        """``first_needed``: the first level whose output the caller reads (DLA-Up starts at level 2): earlier entries of the result
+        may be None -- level0 -> level1 (one conv each) then run as ONE launch and level0's tensor is never written."""
         dtype = dtype or fused.default_compute_dtype()
         conv, bn = self.base_layer[0], self.base_layer[1]
         pc = self._cache.get(('base', dtype), [conv.weight] + fused.bn_sources(bn),
@@ -161,7 +166,18 @@ class DLA(nn.Module):
         x = ops.image_conv(img_nchw.float().contiguous(), pc, relu=True)
         if -1 in self.out_indices:
             y.append(x)
-        for i in range(6):
+        start = 0
+        if first_needed >= 1 and len(self.level0) == 3 and len(self.level1) == 3 and _PAIR:
+            pa = _conv_bn(self._cache, (0, 0), self.level0[0], self.level0[1], x.dtype)
+            pb = _conv_bn(self._cache, (1, 0), self.level1[0], self.level1[1], x.dtype)
+            if ops.conv2d_pair_supported(pa, pb):
+                x = ops.conv2d_pair(x, pa, pb)
+                if 0 in self.out_indices:
+                    y.append(None)
+                if 1 in self.out_indices:
+                    y.append(x)
+                start = 2
+        for i in range(start, 6):
             lvl = getattr(self, 'level{}'.format(i))
             x = self._conv_level_nhwc(lvl, i, x) if i < 2 else lvl.forward_nhwc(x)
             if i in self.out_indices:

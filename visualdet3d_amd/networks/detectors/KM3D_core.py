@@ -76,9 +76,10 @@ class KM3DCore(nn.Module):
         return y.view(B, H, W, 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, C)
 
     def forward_nhwc(self, image, dtype=None):
-        feats = self.backbone.forward_nhwc(image, dtype)
         if isinstance(self.backbone, DLA):
-            return self.deconv_layers.forward_nhwc(feats)
+            # DLA-Up reads levels first_level .. 5 only: level0's output never has to exist (level0 + level1 run as one launch)
+            return self.deconv_layers.forward_nhwc(self.backbone.forward_nhwc(image, dtype, first_needed=self.deconv_layers.first_level))
+        feats = self.backbone.forward_nhwc(image, dtype)
         x = feats[-1]
         for i in range(3):
             x = self._deconv_bn_relu(x, i)
