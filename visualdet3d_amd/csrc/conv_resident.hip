@@ -1356,52 +1356,61 @@ __global__ void __launch_bounds__(512) conv_pair_kernel(const ConvArgs pa, const
         issue_halo(t + 2 * nwg, nstage);                                  // (the stage tile k - 1 read: everybody is past it)
         // ---- phase 1: conv A on 32-pixel blocks of the 17 x 65 region -------------------------------------------------------------
         const char* X = smem + stage * kPrXStage;
-        // (two blocks per step: their MFMA chains -- nine dependent accumulations each -- interleave)
-        for (int blk0 = wave; blk0 < kPrYB; blk0 += 16) {
-            const char* xq[2];
-            int qq[2];
-            bool inside[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int blk = blk0 + 8 * u < kPrYB ? blk0 + 8 * u : blk0;      // (a wave's odd last block is done twice: same values)
-                const int q = blk * 32 + lr;
-                const int qc = q < kPrYN ? q : kPrYN - 1;
-                const int ry = qc / kPrYW, rx = qc - ry * kPrYW;
-                xq[u] = X + (ry * kPrXW + rx) * 32 + half * 16;
-                qq[u] = q;
-                const int ay = 2 * ty * kPrTH - 1 + ry, ax = 2 * tx * kPrTW - 1 + rx;
-                inside[u] = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
-            }
-            f32x16 acc[2];
+        // Software pipeline over the wave's blocks (wave, wave + 8, ...): the nine MFMAs of block j + 1 are ISSUED before the VALU epilogue
+        // of block j, so the matrix pipe works through them while the wave (and its SIMD partner, which the barriers keep in lock
+        // step) converts and stores -- in plain order both waves of a SIMD did their MFMAs, then both their epilogues.
+        const f32x4 s0 = *(const f32x4*)(ss + 4 * half), h0 = *(const f32x4*)(ss + 32 + 4 * half);
+        const f32x4 s1 = *(const f32x4*)(ss + 8 + 4 * half), h1 = *(const f32x4*)(ss + 40 + 4 * half);
+        auto chain = [&](int blk, f32x16& acc) {
+            const int q = blk * 32 + lr;
+            const int qc = q < kPrYN ? q : kPrYN - 1;
+            const int ry = qc / kPrYW, rx = qc - ry * kPrYW;
+            const char* xq = X + (ry * kPrXW + rx) * 32 + half * 16;
             static_for<9>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const i32x4 fb = *(const i32x4*)(xq[u] + ((tap / 3) * kPrXW + tap % 3) * 32);
-                    if constexpr (tap == 0) {
-                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        Fmt16<T>::mfma32z(wa[0], fb, zero, acc[u]);
-                    } else
-                        Fmt16<T>::mfma32(wa[tap], fb, acc[u]);
-                }
+                const i32x4 fb = *(const i32x4*)(xq + ((tap / 3) * kPrXW + tap % 3) * 32);
+                if constexpr (tap == 0) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    Fmt16<T>::mfma32z(wa[0], fb, zero, acc);
+                } else
+                    Fmt16<T>::mfma32(wa[tap], fb, acc);
             });
+        };
+        auto finish = [&](int blk, const f32x16& acc) {
             // lane (pixel, half) holds channels 8 g + 4 half + e (g = 0, 1 real): BN + ReLU, 16-bit, zero outside the image
-            const f32x4 s0 = *(const f32x4*)(ss + 4 * half), h0 = *(const f32x4*)(ss + 32 + 4 * half);
-            const f32x4 s1 = *(const f32x4*)(ss + 8 + 4 * half), h1 = *(const f32x4*)(ss + 40 + 4 * half);
+            const int q = blk * 32 + lr;
+            const int qc = q < kPrYN ? q : kPrYN - 1;
+            const int ry = qc / kPrYW, rx = qc - ry * kPrYW;
+            const int ay = 2 * ty * kPrTH - 1 + ry, ax = 2 * tx * kPrTW - 1 + rx;
+            const bool inside = (unsigned)ay < (unsigned)H && (unsigned)ax < (unsigned)W;
+            float va[4], vb[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float va[4], vb[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    va[e] = inside[u] ? fmaxf(acc[u][e] * s0[e] + h0[e], relu_a) : 0.f;
-                    vb[e] = inside[u] ? fmaxf(acc[u][4 + e] * s1[e] + h1[e], relu_a) : 0.f;
-                }
-                const int x0 = Fmt16<T>::pack2(va[0], va[1]), x1 = Fmt16<T>::pack2(va[2], va[3]);
-                const int y0 = Fmt16<T>::pack2(vb[0], vb[1]), y1 = Fmt16<T>::pack2(vb[2], vb[3]);
-                auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-                *(i32x4*)(smem + kPrYOff + qq[u] * 32 + half * 16) = i32x4{(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};   // channels 8 half .. + 7
+            for (int e = 0; e < 4; ++e) {
+                va[e] = inside ? fmaxf(acc[e] * s0[e] + h0[e], relu_a) : 0.f;
+                vb[e] = inside ? fmaxf(acc[4 + e] * s1[e] + h1[e], relu_a) : 0.f;
             }
+            const int x0 = Fmt16<T>::pack2(va[0], va[1]), x1 = Fmt16<T>::pack2(va[2], va[3]);
+            const int y0 = Fmt16<T>::pack2(vb[0], vb[1]), y1 = Fmt16<T>::pack2(vb[2], vb[3]);
+            auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            *(i32x4*)(smem + kPrYOff + q * 32 + half * 16) = i32x4{(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};   // channels 8 half .. + 7
+        };
+        static_assert(kPrYB > 24 + 7 && kPrYB <= 40, "a wave owns four or five blocks");
+        {
+            f32x16 c0, c1;
+            chain(wave, c0);
+            chain(wave + 8, c1);
+            finish(wave, c0);
+            chain(wave + 16, c0);
+            finish(wave + 8, c1);
+            chain(wave + 24, c1);
+            finish(wave + 16, c0);
+            if (wave + 32 < kPrYB) {                    // (wave-uniform)
+                chain(wave + 32, c0);
+                finish(wave + 24, c1);
+                finish(wave + 32, c0);
+            } else
+                finish(wave + 24, c1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
