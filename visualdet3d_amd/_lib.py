@@ -25,7 +25,7 @@ if _NAME != 'libvd3d_hip.so':
 VD3D_BF16 = 0
 VD3D_F32 = 1
 VD3D_F16 = 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

@@ -75,5 +75,5 @@ int vd3d_raise_lds_limit(const void* kern, int bytes, Vd3dLdsLimit& state, const
     return VD3D_OK;
 }
 
-extern "C" int vd3d_abi_version(void) { return 3; }
+extern "C" int vd3d_abi_version(void) { return 4; }
 extern "C" const char* vd3d_last_error(void) { return g_err; }
