@@ -1270,14 +1270,25 @@ __global__ void __launch_bounds__(512) conv_narrow_kernel(const ConvArgs p, int 
 constexpr int kPrTH = 8, kPrTW = 32;
 constexpr int kPrYH = 2 * kPrTH + 1, kPrYW = 2 * kPrTW + 1, kPrYN = kPrYH * kPrYW;            // 17 x 65 conv-A outputs
 constexpr int kPrXH = kPrYH + 2, kPrXW = kPrYW + 2, kPrXN = kPrXH * kPrXW;                    // 19 x 67 input halo
-constexpr int kPrXP = (kPrXN + 31) / 32, kPrXStage = kPrXP * 1024;                           // 40 pieces of 32 pixels x 32 B
-constexpr int kPrNst = 3;                                                                    // halo stages: two tiles ahead
-constexpr int kPrYB = (kPrYN + 31) / 32, kPrYOff = kPrNst * kPrXStage, kPrYBytes = kPrYB * 1024; // 35 blocks
-constexpr int kPrSS = kPrYOff + kPrYBytes, kPrLds = kPrSS + 512;
+constexpr int kPrXP = 2 * ((kPrXN + 63) / 64), kPrXStage = kPrXP * 1024;                     // 2 x 20 pieces of 64 pixels x 16 B
+constexpr int kPrNW = 4;                                                                     // waves per workgroup; TWO workgroups per CU
+// LDS images are PLANAR in the 8-channel half (the MFMA k-group of a lane): lanes 0-31 of a fragment read then walk consecutive 16-byte
+// slots -- the pixel-major [pixel][32 B] image of the first version put the lanes 32 bytes apart, a 2-way bank conflict on every
+// ds_read_b128 (4-way for the stride-2 reads of conv B): 57 % of the LDS cycles were conflict cycles (SQ_LDS_BANK_CONFLICT), LDS 64 % busy.
+// The conv-A image is additionally split by column parity, so that conv B's stride-2 fragment reads are contiguous as well.
+constexpr int kPrXPlane = kPrXStage / 2;                                                     // 20 pieces of 64 pixels x 16 B per half
+constexpr int kPrYC = kPrTW + 1;                                                             // 33 columns per parity
+constexpr int kPrYQ = ((kPrYH * kPrYC * 16 + 255) / 256) * 256 + 128;                        // parity plane (odd multiple of 128 B)
+constexpr int kPrYP = 2 * kPrYQ;                                                             // half plane
+constexpr int kPrYB = (kPrYN + 31) / 32, kPrYOff = kPrXStage, kPrYBytes = 2 * kPrYP;         // 35 blocks
+constexpr int kPrSS = kPrYOff + kPrYBytes, kPrLds = kPrSS + 512;                              // 76.5 KiB
 
 template <typename T>
-__global__ void __launch_bounds__(512) conv_pair_kernel(const ConvArgs pa, const ConvArgs pb, int ntiles) {
-    constexpr int P = (kPrXP + 7) / 8;                // DMA pieces per wave and tile
+__global__ void __launch_bounds__(kPrNW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_pair_kernel(const ConvArgs pa, const ConvArgs pb, int ntiles) {
+    constexpr int P = kPrXP / kPrNW;                  // DMA pieces per wave and tile
+    constexpr int NB = (kPrYB + kPrNW - 1) / kPrNW;   // conv-A blocks per wave (the last one only for the first waves)
+    constexpr int RW = kPrTH / kPrNW;                 // conv-B output rows per wave
+    static_assert(kPrXP % kPrNW == 0 && kPrTH % kPrNW == 0, "halo pieces / output rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1306,69 +1317,64 @@ __global__ void __launch_bounds__(512) conv_pair_kernel(const ConvArgs pa, const
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pb.out, 0, 0x80000000u, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int in_bs = (int)pa.in_batch_stride;
-    // a lane's halo pixels are the same in every tile (piece q = wave + 8 it, pixel 32 q + lane / 2): position and source offset
-    // relative to the tile origin are computed once (per tile they were five constant divisions and 150 VALU instructions per lane)
+    // a lane's halo pixels are the same in every tile (piece q = wave + NW it = (half plane, 64-pixel run), pixel = run * 64 + lane): position and source offset
+    // relative to the tile origin are computed once (per tile they were constant divisions and ~30 VALU instructions per piece)
     int h_yx[P], h_off[P];
 #pragma unroll
     for (int it = 0; it < P; ++it) {
-        const int hr = (wave + it * 8) * 32 + (lane >> 1);
+        const int q2 = wave + it * kPrNW, plane = q2 / (kPrXP / 2);
+        const int hr = (q2 - plane * (kPrXP / 2)) * 64 + lane;
         const int hy = hr / kPrXW, hx = hr - hy * kPrXW;
         h_yx[it] = hr < kPrXN ? (hy << 16) | hx : -1;
-        h_off[it] = hy * pa.in_row_stride + hx * pa.in_pix_stride + (lane & 1) * 8;
+        h_off[it] = hy * pa.in_row_stride + hx * pa.in_pix_stride + plane * 8;
     }
-    auto issue_halo = [&](int t, int stage) {
+    auto issue_halo = [&](int t) {
         const bool tv = t < ntiles;
         const int tt = tv ? t : 0;
         const int b = tt / tiles_img, trem = tt - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        char* base = smem + stage * kPrXStage;
         const int y0 = 2 * ty * kPrTH - 2, x0 = 2 * tx * kPrTW - 2;
         const int org = b * in_bs + y0 * pa.in_row_stride + x0 * pa.in_pix_stride;
 #pragma unroll
         for (int it = 0; it < P; ++it) {
-            const int q = wave + it * 8;               // (kPrXP = 40 = 5 x 8: no partial round)
+            const int q = wave + it * kPrNW;
             const int iy = y0 + (h_yx[it] >> 16), ix = x0 + (h_yx[it] & 0xffff);
             const bool v = tv && h_yx[it] >= 0 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             const uint32_t off = ((uint32_t)(org + h_off[it]) * 2u) | (v ? 0u : kOOB);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + q * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(smem + q * 1024), 16, off, 0, 0, 0);
         }
     };
-    static_assert(kPrXP % 8 == 0, "halo pieces must split evenly over the waves");
-    // phase-2 fragment addresses (as the small-channel kernel with S = 2): wave = output row, lane = output pixel
+    // phase-2 fragment addresses (as the small-channel kernel with S = 2): wave = RW output rows, lane = output pixel
     int b_tap[9];
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) b_tap[tap] = ((wave * 2 + tap / 3) * kPrYW + lr * 2 + tap % 3) * 32 + half * 16;
+    for (int tap = 0; tap < 9; ++tap)
+        b_tap[tap] = half * kPrYP + ((tap % 3) & 1) * kPrYQ + ((wave * RW * 2 + tap / 3) * kPrYC + lr + ((tap % 3) >> 1)) * 16;
     const float relu_a = pa.relu ? 0.f : -3.0e38f, relu_b = pb.relu ? 0.f : -3.0e38f;
     const int nwg = gridDim.x;
-    int t = blockIdx.x, stage = 0, k = 0;
-    issue_halo(t, 0);
-    issue_halo(t + nwg, 1);
-    // VMEM queue of a wave: D(k) [P pieces, top of tile k - 2] S(k - 2) [2 stores] D(k + 1) S(k - 1): at the top of tile k the halo D(k)
-    // must have landed, with 2 P + 4 younger operations allowed in flight (the first two tiles: only the halos are in the queue)
-    for (; t < ntiles; t += nwg, ++k) {
+    int t = blockIdx.x;
+    issue_halo(t);
+    // VMEM queue of a wave per tile: D(k + 1) [P pieces, after phase 1 of tile k] S(k) [2 RW stores].  At the top of tile k the halo D(k)
+    // must have landed: younger are only the stores of tile k - 1.
+    for (; t < ntiles; t += nwg) {
         const int b = t / tiles_img, trem = t - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-        if (k < 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P + 4) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * RW) : "memory");
         __builtin_amdgcn_s_barrier();                                     // ... for everybody; the conv-A image is free again
         asm volatile("" ::: "memory");
-        const int nstage = stage + 2 >= kPrNst ? stage + 2 - kPrNst : stage + 2;
-        issue_halo(t + 2 * nwg, nstage);                                  // (the stage tile k - 1 read: everybody is past it)
         // ---- phase 1: conv A on 32-pixel blocks of the 17 x 65 region -------------------------------------------------------------
-        const char* X = smem + stage * kPrXStage;
-        // Software pipeline over the wave's blocks (wave, wave + 8, ...): the nine MFMAs of block j + 1 are ISSUED before the VALU epilogue
-        // of block j, so the matrix pipe works through them while the wave (and its SIMD partner, which the barriers keep in lock
-        // step) converts and stores -- in plain order both waves of a SIMD did their MFMAs, then both their epilogues.
+        // Software pipeline over the wave's blocks (wave, wave + NW, ...): the nine MFMAs of block j + 1 are ISSUED before the VALU
+        // epilogue of block j, so the matrix pipe works through them while the wave converts and stores.
+        const char* X = smem;
         const f32x4 s0 = *(const f32x4*)(ss + 4 * half), h0 = *(const f32x4*)(ss + 32 + 4 * half);
         const f32x4 s1 = *(const f32x4*)(ss + 8 + 4 * half), h1 = *(const f32x4*)(ss + 40 + 4 * half);
         auto chain = [&](int blk, f32x16& acc) {
             const int q = blk * 32 + lr;
             const int qc = q < kPrYN ? q : kPrYN - 1;
             const int ry = qc / kPrYW, rx = qc - ry * kPrYW;
-            const char* xq = X + (ry * kPrXW + rx) * 32 + half * 16;
+            const char* xq = X + half * kPrXPlane + (ry * kPrXW + rx) * 16;
             static_for<9>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
-                const i32x4 fb = *(const i32x4*)(xq + ((tap / 3) * kPrXW + tap % 3) * 32);
+                const i32x4 fb = *(const i32x4*)(xq + ((tap / 3) * kPrXW + tap % 3) * 16);
                 if constexpr (tap == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     Fmt16<T>::mfma32z(wa[0], fb, zero, acc);
@@ -1393,42 +1399,38 @@ __global__ void __launch_bounds__(512) conv_pair_kernel(const ConvArgs pa, const
             const int y0 = Fmt16<T>::pack2(vb[0], vb[1]), y1 = Fmt16<T>::pack2(vb[2], vb[3]);
             auto r0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
             auto r1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
-            *(i32x4*)(smem + kPrYOff + q * 32 + half * 16) = i32x4{(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};   // channels 8 half .. + 7
+            *(i32x4*)(smem + kPrYOff + half * kPrYP + (rx & 1) * kPrYQ + (ry * kPrYC + (rx >> 1)) * 16) =
+                i32x4{(int)r0[0], (int)r1[0], (int)r0[1], (int)r1[1]};                                                   // channels 8 half .. + 7
         };
-        static_assert(kPrYB > 24 + 7 && kPrYB <= 40, "a wave owns four or five blocks");
         {
-            f32x16 c0, c1;
-            chain(wave, c0);
-            chain(wave + 8, c1);
-            finish(wave, c0);
-            chain(wave + 16, c0);
-            finish(wave + 8, c1);
-            chain(wave + 24, c1);
-            finish(wave + 16, c0);
-            if (wave + 32 < kPrYB) {                    // (wave-uniform)
-                chain(wave + 32, c0);
-                finish(wave + 24, c1);
-                finish(wave + 32, c0);
-            } else
-                finish(wave + 24, c1);
+            f32x16 c[2];
+            chain(wave, c[0]);
+            static_for<NB - 1>([&](auto jc) {
+                constexpr int j = decltype(jc)::value + 1;               // block j's MFMAs, then block j - 1's epilogue
+                if (j < NB - 1 || wave + j * kPrNW < kPrYB) chain(wave + j * kPrNW, c[j & 1]);      // (wave-uniform)
+                finish(wave + (j - 1) * kPrNW, c[(j - 1) & 1]);
+            });
+            if (wave + (NB - 1) * kPrNW < kPrYB) finish(wave + (NB - 1) * kPrNW, c[(NB - 1) & 1]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();                                     // the conv-A image is complete, the halo stage is free
         asm volatile("" ::: "memory");
+        issue_halo(t + nwg);                                              // lands under phase 2 and the partner workgroup's phases
         // ---- phase 2: conv B (stride 2) from the conv-A image ------------------------------------------------------------------------
-        {
-            const char* Y = smem + kPrYOff;
+        const char* Y = smem + kPrYOff;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
             f32x16 acc;
             static_for<9>([&](auto tc) {
                 constexpr int tap = decltype(tc)::value;
-                const i32x4 fb = *(const i32x4*)(Y + b_tap[tap]);
+                const i32x4 fb = *(const i32x4*)(Y + b_tap[tap] + r * 2 * kPrYC * 16);
                 if constexpr (tap == 0) {
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     Fmt16<T>::mfma32z(wb[0], fb, zero, acc);
                 } else
                     Fmt16<T>::mfma32(wb[tap], fb, acc);
             });
-            const int y = ty * kPrTH + wave, x = tx * kPrTW + lr;
+            const int y = ty * kPrTH + wave * RW + r, x = tx * kPrTW + lr;
             const bool pin = y < pb.Ho && x < pb.Wo;
             const uint32_t obase = (uint32_t)(((b * pb.Ho + y) * pb.Wo + x) * pb.out_pix_stride);
             auto chan4 = [&](int g, float (&v)[4]) {
@@ -1451,7 +1453,6 @@ __global__ void __launch_bounds__(512) conv_pair_kernel(const ConvArgs pa, const
                 __builtin_amdgcn_raw_buffer_store_b128(o, out_rsrc, off, 0, 0);
             }
         }
-        stage = stage + 1 == kPrNst ? 0 : stage + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMA must not land in a successor workgroup's LDS
 }
@@ -1469,14 +1470,14 @@ int launch_pair(ConvArgs& a, ConvArgs& b, hipStream_t stream, int fmt) {
     const int num_cu = vd3d_device_cu_count();
     if (num_cu <= 0) return VD3D_ELAUNCH;
     const int ntiles = b.B * ((b.Ho + kPrTH - 1) / kPrTH) * ((b.Wo + kPrTW - 1) / kPrTW);
-    const int grid = ntiles < num_cu ? ntiles : num_cu;
+    const int grid = ntiles < 2 * num_cu ? ntiles : 2 * num_cu;          // two persistent workgroups per CU (76.5 KiB of LDS each)
     static Vd3dLdsLimit limh, limb;
     if (fmt == VD3D_F16) {
         if (const int rc = vd3d_raise_lds_limit((const void*)conv_pair_kernel<hf16>, kPrLds, limh, "hipFuncSetAttribute(conv_pair)")) return rc;
-        hipLaunchKernelGGL(conv_pair_kernel<hf16>, dim3(grid), dim3(512), kPrLds, stream, a, b, ntiles);
+        hipLaunchKernelGGL(conv_pair_kernel<hf16>, dim3(grid), dim3(kPrNW * 64), kPrLds, stream, a, b, ntiles);
     } else {
         if (const int rc = vd3d_raise_lds_limit((const void*)conv_pair_kernel<short>, kPrLds, limb, "hipFuncSetAttribute(conv_pair)")) return rc;
-        hipLaunchKernelGGL(conv_pair_kernel<short>, dim3(grid), dim3(512), kPrLds, stream, a, b, ntiles);
+        hipLaunchKernelGGL(conv_pair_kernel<short>, dim3(grid), dim3(kPrNW * 64), kPrLds, stream, a, b, ntiles);
     }
     return vd3d_check_launch("conv_pair");
 }
