@@ -75,7 +75,7 @@ def build_model(args, device):
 def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
     """Per-launch HIP-event timing of the MFMA kernel families on the launch stream, side streams off (durations must not
     overlap): every launch through hip_ops.conv2d (the implicit-GEMM family), deform_conv_general (fused DCN), deform_columns
-    (DCN sampling half) and km3d_head_fused.  Returns a dict: conv family (flops, seconds, launches, algorithmic bytes, dominant
+    (DCN sampling half), km3d_head_fused and conv2d_pair (DLA level0 + level1, counted in the conv family).  Returns a dict: conv family (flops, seconds, launches, algorithmic bytes, dominant
     layer shape) + per-family totals of the other entries."""
     from visualdet3d_amd import hip_ops as ops
     records = []     # (family, flops, start, end, bytes, label)
@@ -83,7 +83,7 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
-    orig = dict(conv2d=ops.conv2d, dcn=ops.deform_conv_general, cols=ops.deform_columns, head=ops.km3d_head_fused)
+    orig = dict(conv2d=ops.conv2d, dcn=ops.deform_conv_general, cols=ops.deform_columns, head=ops.km3d_head_fused, pair=ops.conv2d_pair)
 
     def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
         s, e = ev(), ev()
@@ -128,7 +128,19 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
         records.append(('km3d_head_fused', fl, s, e, 0, 'fused head %d->%d x %d @ %dx%dx%d' % (pc_first.Cin, 256, len(n_out), B, H, W)))
         return o
 
-    ops.conv2d, ops.deform_conv_general, ops.deform_columns, ops.km3d_head_fused = conv2d, dcn, cols, head
+    def pair(x, pc_a, pc_b, relu_a=True, relu_b=True):
+        s, e = ev(), ev()
+        s.record()
+        o = orig['pair'](x, pc_a, pc_b, relu_a=relu_a, relu_b=relu_b)
+        e.record()
+        B, H, W, _ = x.shape
+        _, Ho, Wo, Co = o.shape
+        fl = 2.0 * B * 9 * (H * W * pc_a.Cout * pc_a.Cin + Ho * Wo * Co * pc_b.Cin)
+        nbytes = x.numel() * x.element_size() + o.numel() * o.element_size()
+        records.append(('conv', fl, s, e, nbytes, '3x3 s1 %d->%d + 3x3 s2 %d->%d (one launch) @ %dx%dx%d' % (pc_a.Cin, pc_a.Cout, pc_b.Cin, Co, B, H, W)))
+        return o
+
+    ops.conv2d, ops.deform_conv_general, ops.deform_columns, ops.km3d_head_fused, ops.conv2d_pair = conv2d, dcn, cols, head, pair
     switches = []
     for mod, attr in ((getattr(model, 'bbox_head', None), 'overlap_towers'), (getattr(model, 'core', None), 'overlap_neck')):
         if mod is not None and hasattr(mod, attr):
@@ -141,6 +153,7 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
         torch.cuda.synchronize()
     finally:
         ops.conv2d, ops.deform_conv_general, ops.deform_columns, ops.km3d_head_fused = orig['conv2d'], orig['dcn'], orig['cols'], orig['head']
+        ops.conv2d_pair = orig['pair']
         for mod, attr, v in switches:
             setattr(mod, attr, v)
     # No event-overhead correction: per-launch HIP events were compared with the kernel durations of a rocprofv3 --kernel-trace

@@ -18,6 +18,7 @@ if hasattr(m.core, 'overlap_neck'):
     m.core.overlap_neck = False
 rec = []
 orig = ops.conv2d
+orig_pair = ops.conv2d_pair
 
 
 def timed(x, pc, out=None, residual=None, relu=False, out_f32=False):
@@ -32,14 +33,28 @@ def timed(x, pc, out=None, residual=None, relu=False, out_f32=False):
     return o
 
 
+def timed_pair(x, pa, pb, relu_a=True, relu_b=True):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    o = orig_pair(x, pa, pb, relu_a=relu_a, relu_b=relu_b)
+    e.record()
+    B, H, W, _ = x.shape
+    _, Ho, Wo, Co = o.shape
+    fl = 2.0 * B * 9 * (H * W * pa.Cout * pa.Cin + Ho * Wo * Co * pb.Cin)
+    rec.append(('3x3 s1 %d->%d + 3x3 s2 %d->%d @ %dx%dx%d' % (pa.Cin, pa.Cout, pb.Cin, Co, B, H, W), fl, x.numel() * x.element_size() + o.numel() * o.element_size(), s, e))
+    return o
+
+
 with torch.no_grad():
     m.forward_device(*inputs)
     torch.cuda.synchronize()
     ops.conv2d = timed
+    ops.conv2d_pair = timed_pair
     rec.clear()
     m.forward_device(*inputs)
     torch.cuda.synchronize()
 ops.conv2d = orig
+ops.conv2d_pair = orig_pair
 tot = 0.0
 for d, fl, by, s, e in rec:
     t = s.elapsed_time(e) * 1e-3

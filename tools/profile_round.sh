@@ -43,10 +43,10 @@ grep '^{' $OUT/trace_serial.log | tail -1 > $OUT/${TAG}_serial_bench.json
 grep '^{' $OUT/trace_overlap.log | tail -1 > $OUT/${TAG}_overlap_bench_under_rocprof.json
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json
 python tools/rocpd_pmc_table.py $OUT/pmc_sq conv_ > $OUT/${TAG}_sq_pmc.txt
-{ echo "# BASELINE config 5 (KM3D DLA-34, fp16, 16 x 512 x 1760), eager launches: DCN and fused-head kernels"; echo "## SQ pass"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq "true, 32, 0, 0, true" | tail -n +2;
-  echo "## instruction mix"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu "true, 32, 0, 0, true" | tail -n +2;
-  echo "## FETCH_SIZE (x2 for bytes on gfx950: 32-byte units reported as 64)"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch "true, 32, 0, 0, true" | tail -n +2;
-  echo "## WRITE_SIZE"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write "true, 32, 0, 0, true" | tail -n +2; } > $OUT/${TAG}_c5_pmc.txt 2>&1
+{ echo "# BASELINE config 5 (KM3D DLA-34, fp16, 16 x 512 x 1760), eager launches: DCN, fused-head (km3d_head_kernel) and level-pair kernels"; echo "## SQ pass"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq conv_pair_kernel | tail -n +2;
+  echo "## instruction mix"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu conv_pair_kernel | tail -n +2;
+  echo "## FETCH_SIZE (x2 for bytes on gfx950: 32-byte units reported as 64)"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch conv_pair_kernel | tail -n +2;
+  echo "## WRITE_SIZE"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write conv_pair_kernel | tail -n +2; } > $OUT/${TAG}_c5_pmc.txt 2>&1
 python tools/serial_roofline_check.py $OUT/${TAG}_serial_kernel_stats.csv $OUT/${TAG}_serial_bench.json > $OUT/${TAG}_serial_roofline_check.txt
 cat $OUT/${TAG}_serial_roofline_check.txt
 python tools/rocpd_stats.py $(db trace_c3) > $OUT/${TAG}_c3_kernel_stats.csv
