@@ -356,3 +356,46 @@ def test_fp16_mode_config5_vs_fp16_oracle_and_reference_golden():
         frac = matched_fraction((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=3e-2)
         print('[KM3D fp16] frame %d: %d detections (reference %d), %.0f %% matched one-to-one within 3e-2' % (f, len(s), len(g['f%d_scores' % f]), 100 * frac))
         assert abs(len(s) - len(g['f%d_scores' % f])) <= 5 and frac >= 0.9
+
+
+def test_persistent_kernels_are_run_to_run_identical_at_size():
+    """The round-3 kernels hand LDS regions from one phase / tile to the next with as few barriers as their reasoning allows (fused head:
+    no barrier between the main loop and the second GEMM, next tile's DMA under the epilogue; level pair: halo stage released after
+    conv A; peaks: bit masks + ranks).  A missing dependency shows as run-to-run differences under load: ten runs each at BASELINE
+    config 5's size, every output bit-identical to the first run's."""
+    from visualdet3d_amd import hip_ops as ops
+    from visualdet3d_amd.networks.heads.km3d_head import KM3DHead
+    cfg = syn.km3d_cfg(output_w=440)
+    head = KM3DHead(**cfg.head).cuda().eval()
+    sd = syn.seeded_state_dict({'h.' + k: v for k, v in head.state_dict().items()}, seed=3, head_std=0.02)
+    head.load_state_dict({k[2:]: v for k, v in sd.items()})
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(16, 128, 440, 64, generator=g).cuda().half()
+    P2, _ = syn.kitti_calib(1760, batch=16)
+    with torch.no_grad():
+        first = None
+        for _ in range(10):
+            maps = head.forward_nhwc(x)
+            dets = head.get_bboxes_batched(maps, P2.cuda(), (512, 1760))
+            torch.cuda.synchronize()
+            scores, boxes, cls, count = dets
+            valid = torch.arange(scores.shape[1], device=scores.device)[None, :] < count.clamp_min(0)[:, None]     # rows >= count are padding
+            cur = [v.clone() for _, v in sorted(maps.items())] + [count.clone(), torch.where(valid, scores, 0), torch.where(valid[..., None], boxes, 0),
+                                                                  torch.where(valid, cls, 0)]
+            if first is None:
+                first = cur
+                continue
+            for a, b in zip(first, cur):
+                assert torch.equal(a, b)
+    # level pair at full resolution
+    xin = torch.randn(8, 512, 1760, 16, generator=g).cuda().half()
+
+    def mk(cin, cout, stride, seed):
+        gg = torch.Generator().manual_seed(seed)
+        w = torch.randn(cout, cin, 3, 3, generator=gg) * (2.0 / (9 * cin)) ** 0.5
+        return ops.pack_conv(w.cuda(), torch.randn(cout, generator=gg).cuda() * 0.1, None, torch.float16, stride, 1, 1)
+
+    pa, pb = mk(16, 16, 1, 1), mk(16, 32, 2, 2)
+    ref = ops.conv2d_pair(xin, pa, pb)
+    for _ in range(9):
+        assert torch.equal(ops.conv2d_pair(xin, pa, pb).view(torch.int16), ref.view(torch.int16))
