@@ -74,7 +74,9 @@ typedef struct vd3d_conv_params {
      * 32*nb + (l & 31), k = tap*Cin + 64*kc + (2*ks + (l >> 5))*8 .. +7 -- so the once-per-launch weight load of a wave is 36
      * (or 72) fully coalesced 1 KiB reads instead of 64 scattered 16-byte reads per instruction.
      * 1x1 / stride 1 / pad 0 convolutions with Cin = 64 | 128 | 256 and Cout % 256 == 0 (point-wise streaming kernel) take the same
-     * image with ONE tap: [Cout/32][Cin/64][4][64 lanes][8 elements]. */
+     * image with ONE tap: [Cout/32][Cin/64][4][64 lanes][8 elements].
+     * ABI >= 4: the narrow-output streaming kernel (3x3 / stride 1 / pad 1, Cout = 32 rows incl. zero filters, ANY Cin % 64 == 0 >= 128:
+     * the DCN offset convs) streams the same image through LDS one 64-channel block [36][64 lanes][8] at a time. */
     const void* weight_frag;
 } vd3d_conv_params;
 
