@@ -41,6 +41,9 @@ VD3D_DEV hf16 f2h(float f) {
 template <typename T> struct Fmt16;
 template <> struct Fmt16<short> {
     static VD3D_DEV int pack2(float lo, float hi) { return (int)((uint32_t)(uint16_t)f2bf(lo) | ((uint32_t)(uint16_t)f2bf(hi) << 16)); }
+    // the same conversion as pack2 pinned to ONE instruction (the compiler turns pack2 followed by integer ops on the pair into two
+    // conversions + v_perm_b32)
+    static VD3D_DEV int pack2_1(float lo, float hi) { int r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
     static VD3D_DEV float lo(uint32_t u) { return i2f((int)(u << 16)); }
     static VD3D_DEV float hi(uint32_t u) { return i2f((int)(u & 0xffff0000u)); }
     static VD3D_DEV short one(float f) { return f2bf(f); }
@@ -60,6 +63,7 @@ template <> struct Fmt16<hf16> {
         f16x2 p = {(_Float16)lo, (_Float16)hi};          // v_cvt_pk_f16_f32 (RNE)
         return __builtin_bit_cast(int, p);
     }
+    static VD3D_DEV int pack2_1(float lo, float hi) { int r; asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi)); return r; }
     static VD3D_DEV float lo(uint32_t u) { return h2f((hf16)(u & 0xffffu)); }
     static VD3D_DEV float hi(uint32_t u) { return h2f((hf16)(u >> 16)); }
     static VD3D_DEV hf16 one(float f) { return f2h(f); }
@@ -74,6 +78,15 @@ template <> struct Fmt16<hf16> {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 };
+
+// ReLU on a packed pair of 16-bit floats (bf16 or fp16 alike): a negative value has its sign bit set, i.e. is a negative int16 --
+// v_pk_max_i16 with 0 clears it (-0 -> +0 as fmaxf does); relu(round(x)) == round(relu(x)) since rounding keeps the sign.  One
+// instruction per TWO values where fmaxf on an MFMA result costs two per value (canonicalise + max).  (NaN: a positive NaN stays NaN.)
+typedef __attribute__((ext_vector_type(2))) short vd3d_s16x2;
+VD3D_DEV int relu_pk16(int p) {
+    const vd3d_s16x2 z = {0, 0};
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(vd3d_s16x2, p), z));
+}
 
 template <> struct Fmt16<float> {      // never used for arithmetic: lets 16-bit-only epilogue code compile in fp32 instantiations
     static VD3D_DEV int pack2(float lo, float hi) { return Fmt16<short>::pack2(lo, hi); }

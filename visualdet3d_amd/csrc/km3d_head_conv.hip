@@ -221,10 +221,9 @@ __global__ void __launch_bounds__(kNW * 64) km3d_head_kernel(const ConvArgs p) {
                 const i32x4 fa2 = *(const i32x4*)(smem + kW2 + elr * 512 + (((2 * ks + ehalf) ^ (elr & 15)) << 4));
 #pragma unroll
                 for (int j = 0; j < TM; ++j) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc[i][j][8 * gp + e], 0.f);
-                    const i32x4 fb2 = {Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3]), Fmt16<T>::pack2(v[4], v[5]), Fmt16<T>::pack2(v[6], v[7])};
+                    const f32x16& a = acc[i][j];             // round, then ReLU on the packed pairs (one v_pk_max_i16 per two values)
+                    const i32x4 fb2 = {relu_pk16(Fmt16<T>::pack2_1(a[8 * gp], a[8 * gp + 1])), relu_pk16(Fmt16<T>::pack2_1(a[8 * gp + 2], a[8 * gp + 3])),
+                                       relu_pk16(Fmt16<T>::pack2_1(a[8 * gp + 4], a[8 * gp + 5])), relu_pk16(Fmt16<T>::pack2_1(a[8 * gp + 6], a[8 * gp + 7]))};
                     Fmt16<T>::mfma32(fa2, fb2, acc2[j]);
                 }
             }
