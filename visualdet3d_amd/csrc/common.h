@@ -83,6 +83,10 @@ template <> struct Fmt16<hf16> {
 // v_pk_max_i16 with 0 clears it (-0 -> +0 as fmaxf does); relu(round(x)) == round(relu(x)) since rounding keeps the sign.  One
 // instruction per TWO values where fmaxf on an MFMA result costs two per value (canonicalise + max).  (NaN: a positive NaN stays NaN.)
 typedef __attribute__((ext_vector_type(2))) short vd3d_s16x2;
+// (floor = 0x00000000: ReLU;  0x80008000 = two INT16_MIN: identity -- a wave-uniform "relu or not" without a branch)
+VD3D_DEV int max_pk16(int p, int floor) {
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(vd3d_s16x2, p), __builtin_bit_cast(vd3d_s16x2, floor)));
+}
 VD3D_DEV int relu_pk16(int p) {
     const vd3d_s16x2 z = {0, 0};
     return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(vd3d_s16x2, p), z));
