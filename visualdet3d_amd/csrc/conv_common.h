@@ -54,8 +54,6 @@ bool pair_shape_ok(const ConvArgs& a, const ConvArgs& b);               // conv 
 int launch_pair(ConvArgs& a, ConvArgs& b, hipStream_t stream, int fmt);   // DLA level0 + level1 in one launch
 bool km3d_head_shape_ok(const ConvArgs& a);                            // 3x3 / s1 / p1, Cin % 64 == 0, Cout = 256 x branches (h_* fields set)
 int launch_km3d_head(ConvArgs& a, hipStream_t stream, int fmt);       // persistent fused KM3D head (km3d_head_conv.hip)
-bool strip1w_shape_ok(const ConvArgs& a);                              // EXPERIMENT (conv_strip1w.hip): chunk-aligned channel counts
-int launch_strip1w(ConvArgs& a, hipStream_t stream, int fmt, int bn);  // one-wave-per-SIMD strips, bn = 352 | 288 (test hook tiles 52 / 53)
 bool pw_shape_ok(const ConvArgs& a);                                   // 1x1 / stride 1, Cin 64 | 128 | 256, Cout % 256 == 0, weight_frag given
 int launch_pw(ConvArgs& a, hipStream_t stream, int fmt);              // point-wise expansion streaming kernel (no LDS)
 

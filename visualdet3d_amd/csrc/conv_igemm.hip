@@ -1186,11 +1186,6 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
                 if (!narrow_shape_ok(a)) return forced_tile_error("needs a 16-bit 3x3 / stride 1 / pad 1 conv with Cin a multiple of 64 (>= 128), Cout <= 32, weight_frag, no residual");
                 return launch_narrow(a, stream, std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16);
             } else return forced_tile_error("is a 16-bit-only tile");
-        case 52: case 53:       // EXPERIMENT: one-wave-per-SIMD strips (not in the production list: only reachable through the test hook)
-            if constexpr (kBf16) {
-                if (!strip1w_shape_ok(a)) return forced_tile_error("needs chunk-aligned channel counts (Cin % 64 == 0)");
-                return launch_strip1w(a, stream, std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16, g_force_cfg == 52 ? 352 : 288);
-            } else return forced_tile_error("is a 16-bit-only tile");
         case 58:
             if constexpr (kBf16) {
                 if (!pw_shape_ok(a)) return forced_tile_error("needs a 16-bit 1x1 / stride 1 conv over a dense NHWC input with Cin 64 | 128, Cout a multiple of 256");
