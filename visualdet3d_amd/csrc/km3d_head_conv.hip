@@ -145,16 +145,23 @@ __global__ void __launch_bounds__(kNW * 64) km3d_head_kernel(const ConvArgs p) {
         issue_group(1, 0, p.nk > 1);
         issue_group(1, 1, p.nk > 1);
         f32x16 acc[TN][TM];
+        {
+            // one LDS read per accumulator quad, as volatile asm (the two pixel blocks read the same four biases separately, which the
+            // compiler would merge into one read + 64 copies): the reads land in the accumulator registers
+            const uint32_t bb = (uint32_t)(uintptr_t)(lds_ptr_t)(smem + kB1) + (uint32_t)((wn * WTN + 4 * half) * 4);
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b1 = *(const f32x4*)(smem + kB1 + (wn * WTN + i * 32 + 8 * g + 4 * half) * 4);   // bias of the first conv
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int j = 0; j < TM; ++j)
+                    for (int j = 0; j < TM; ++j) {
+                        f32x4 b1;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b1) : "v"(bb), "n"((i * 32 + 8 * g) * 4));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b1[e];
-            }
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b1[e];
+                    }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         // ---- main loop: the software-pipelined slice walk of conv_igemm_dma_kernel<.., PIPE, 32> (ring of TN weight fragments,
         // double-buffered pixel fragments, barrier before the last sub-step of a slice) --------------------------------------------
         {
