@@ -78,9 +78,19 @@ typedef struct vd3d_conv_params {
      * ABI >= 4: the narrow-output streaming kernel (3x3 / stride 1 / pad 1, Cout = 32 rows incl. zero filters, ANY Cin % 64 == 0 >= 128:
      * the DCN offset convs) streams the same image through LDS one 64-channel block [36][64 lanes][8] at a time. */
     const void* weight_frag;
+    /* ABI >= 5.  Optional scratch for the split-K path of low-parallelism shapes (a batch-1 call: M = B*Ho*Wo gives fewer 128-row
+     * tiles than the device has CUs while K = kh*kw*Cin is thousands deep): tiles x splits workgroups park fp32 partial tiles here and
+     * a second launch adds them in split order and runs the epilogue -- deterministic, no atomics.  NULL (or fewer bytes than
+     * vd3d_conv2d_workspace_bytes asks for): the convolution runs unsplit.  16-byte aligned device memory, contents undefined on
+     * entry and exit; the library never allocates. */
+    void* splitk_ws;
+    int64_t splitk_ws_bytes;
 } vd3d_conv_params;
 
 int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream);
+/* Bytes of `splitk_ws` with which vd3d_conv2d_igemm(p) would split K (0: this shape does not split; -1: invalid parameters).
+ * Depends on the shape fields, dtype and weight_frag only. */
+int64_t vd3d_conv2d_workspace_bytes(const vd3d_conv_params* p);
 /* ids of the tiles the dispatch heuristic can select -> ids[0..cap); returns how many there are (every one of them is forced
  * against the oracle by tests/test_conv_tiles_gpu.py through the test hook of csrc/test_hooks.h, which is not part of this ABI). */
 int vd3d_conv2d_production_tiles(int32_t* ids, int cap);
@@ -340,7 +350,10 @@ int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_packed, const
  * All maps are fp32 NHWC logits / regressions [B][H][W][n] (n: hm n_cls, wh 2, hps 18, rot 8, dim 3, prob 1, reg 2,
  * hm_hp 9, hp_offset 2); P2 [B][3][4]; kconst = the head's `const` buffer, 32 floats ([16][2]).
  * Outputs padded to K per sample in decreasing-score order: scores [B][K], boxes [B][K][11]
- * (x1,y1,x2,y2,cx,cy,z,w,h,l,alpha), cls [B][K] int32, count [B] int32 (-1: more peaks than max_peaks). */
+ * (x1,y1,x2,y2,cx,cy,z,w,h,l,alpha), cls [B][K] int32, count [B] int32 (-1: more peaks than max_peaks).
+ * Limits (checked before anything is enqueued): n_joints == 9, K <= 128, n_cls * K <= 512, max_peaks a power of two in [K, 8192]
+ * (VD3D_EINVAL); n_cls <= 9 heat-map channels per map -- the tiled peaks kernel keeps all channels of a map per workgroup
+ * (VD3D_ERANGE). */
 typedef struct vd3d_km3d_params {
     const float *hm, *wh, *hps, *rot, *dim, *prob, *reg, *hm_hp, *hp_offset, *P2, *kconst;
     int32_t B, H, W, n_cls, n_joints, K, max_peaks, img_h, img_w;

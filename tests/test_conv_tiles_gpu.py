@@ -19,11 +19,11 @@ pytestmark = pytest.mark.gpu
 
 BF16_TILES = {50, 54, 76, 79, 73, 61, 68, 69, 58, 70}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
-NARROW = {87: 32, 30: 64}                # tiles whose N extent bounds Cout in production
+NARROW = {87: 32, 30: 64, 130: 64}       # tiles whose N extent bounds Cout in production (130: the split-K form of the 128 x 64 tile)
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70]
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130]   # 144 / 130: split-K (two launches)
 
 
 class forced_tile:
@@ -150,6 +150,16 @@ def _shapes_for(cfg):
             (16, 24, 80, 256, 256, dict(residual=True)),                # layer3 at the bench shape: 4 slices, 3.75 rounds
             (2, 48, 160, 128, 128, dict(residual=False)),               # many tiles per workgroup (steady-state vmcnt path)
         ]
+    if cfg == 144:      # split-K over 128 x 128 tiles (phase 1: tiles x splits workgroups park fp32 partials, phase 2: add + epilogue)
+        return [
+            (1, 13, 27, 64, 400, dict(residual=True)),                      # 9 slices -> 2 splits of 5 + 4; ragged M, partial last N tile
+            (2, 7, 45, 200, 360, dict(residual=False, relu=False, in_extra=56, out_extra=40)),   # tap-major K walk entered mid-tap
+            (1, 9, 33, 128, 300, dict(k=1, pad=0, residual=True)),          # 1x1: two slices, one per split
+            (1, 15, 21, 64, 290, dict(stride=2, residual=False)),           # stride 2, scalar epilogue
+            (1, 6, 50, 256, 288, dict(out_f32=True, bn=False, relu=False)), # fp32 output
+            (1, 24, 80, 1408, 256, dict(bn=False)),                         # the batch-1 cls conv: 30 tiles x 17 splits, chunk-major walk
+            (1, 12, 40, 1152, 1152, dict(residual=True)),                   # whole-line epilogue in phase 2, splits of unequal length
+        ]
     if cfg in HALO_TILES:
         return [
             (1, 11, 37, 64, 136, dict(residual=True)),                 # ragged patch grid, partial N tile
@@ -236,6 +246,69 @@ def test_bench_shapes_natural_dispatch_bf16_vs_oracle(case):
     torch.set_num_threads(min(64, torch.get_num_threads()))
     ulp, rel = run_case(B, H, W, Cin, Cout, dtype=torch.bfloat16, seed=7, cfg=0, **kw)
     assert ulp <= 1.0, '%s: %.2f bf16 ulp (rel %.2e)' % (name, ulp, rel)
+
+
+# ---- the shapes of a batch-1 call (the reference's contract: one frame per test_forward): natural dispatch picks the split-K path ----
+B1_SHAPES = [
+    ('b1 head 1408->1408 + res', 1, 24, 80, 1408, 1408, dict(residual=True)),       # 165 tiles x 3 splits
+    ('b1 neck 1152->1152 + res', 1, 24, 80, 1152, 1152, dict(residual=True)),
+    ('b1 reg out 1408->576 f32', 1, 24, 80, 1408, 576, dict(out_f32=True, bn=False, relu=False)),
+    ('b1 cls 1408->256', 1, 24, 80, 1408, 256, dict(bn=False)),
+    ('b1 neck 288->288 + res', 1, 24, 80, 288, 288, dict(residual=True)),
+    ('b1 mono cls 512->512', 1, 24, 80, 512, 512, dict(bn=False)),
+    ('b1 mono cls out 512->64 f32', 1, 24, 80, 512, 64, dict(out_f32=True, bn=False, relu=False)),    # 128 x 64 split tiles
+    ('b1 look-ground 256->1', 1, 24, 80, 256, 1, dict(bn=False, relu=False)),
+    ('b1 mono reg out 256->384 f32', 1, 24, 80, 256, 384, dict(out_f32=True, bn=False, relu=False)),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize('case', B1_SHAPES, ids=[c[0] for c in B1_SHAPES])
+def test_batch1_shapes_natural_dispatch_vs_oracle(case, dtype):
+    from visualdet3d_amd import _lib
+    name, B, H, W, Cin, Cout, kw = case
+    ulp, rel = run_case(B, H, W, Cin, Cout, dtype=dtype, seed=11, cfg=0, **kw)
+    if dtype == torch.float32:
+        assert rel <= 2e-5, '%s: rel %.2e' % (name, rel)
+    else:
+        assert ulp <= 1.0, '%s: %.2f ulp (rel %.2e)' % (name, ulp, rel)
+
+
+def test_splitk_is_what_batch1_dispatch_picks_and_is_deterministic():
+    """vd3d_conv2d_workspace_bytes > 0 exactly for the low-parallelism deep-K shapes (and 0 for the batched bench shapes: nothing
+    changes for them); without a workspace the same call runs unsplit and agrees to fp32 summation noise; two split runs are
+    bit-identical (partials are added in split order, no atomics)."""
+    import ctypes as C
+    from visualdet3d_amd import _lib, hip_ops as ops
+    g = torch.Generator().manual_seed(5)
+
+    def params(B, H, W, Cin, Cout):
+        x = torch.randn(B, H, W, Cin, generator=g).cuda().to(torch.bfloat16)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+        return x, ops.pack_conv(w, None, None, torch.bfloat16, 1, 1, 1)
+
+    x, pc = params(1, 24, 80, 1408, 1408)
+    a = ops.conv2d(x, pc, relu=True)
+    b = ops.conv2d(x, pc, relu=True)
+    assert torch.equal(a, b)
+    orig = _lib.lib().vd3d_conv2d_workspace_bytes
+    seen = []
+    try:
+        _lib.lib().vd3d_conv2d_workspace_bytes = lambda p: (seen.append(orig(p)), 0)[1]     # hip_ops then passes no workspace: unsplit
+        c = ops.conv2d(x, pc, relu=True)
+    finally:
+        _lib.lib().vd3d_conv2d_workspace_bytes = orig
+    assert seen and seen[0] == 3 * 165 * 128 * 128 * 4, seen
+    d = (a.float() - c.float()).abs().max().item() / c.float().abs().max().item()
+    assert 0 < d < 2.0 ** -7, d            # a different summation order (so it really was another path), within one bf16 ulp
+    x8, pc8 = params(8, 24, 80, 1408, 1408)
+    seen.clear()
+    try:
+        _lib.lib().vd3d_conv2d_workspace_bytes = lambda p: (seen.append(orig(p)), 0)[1]
+        ops.conv2d(x8, pc8, relu=True)
+    finally:
+        _lib.lib().vd3d_conv2d_workspace_bytes = orig
+    assert seen == [0]
 
 
 @pytest.mark.parametrize('cfg', [44, 42, 30])

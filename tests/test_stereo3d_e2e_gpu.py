@@ -42,6 +42,9 @@ def test_fp32_mode_matches_reference_golden(name):
     s1, b1, l1 = m([L[:1].cuda(), R[:1].cuda(), P2[:1].cuda(), P3[:1].cuda()])
     assert torch.equal(s1, outs[0][0]) and torch.equal(b1, outs[0][1]) and torch.equal(l1, outs[0][2])
     assert l1.dtype == torch.int64 and b1.shape[1] == 11
+    # both calls went through the hipGraph cache (lib/graphed.py): one capture per batch shape, every result from a replay
+    st = m.graph_stats
+    assert st['eager'] == 0 and st['replays'] == 2 and st['captures'] == (1 if L.shape[0] == 1 else 2), st
 
 
 def test_bf16_mode_matches_bf16_oracle():

@@ -25,7 +25,7 @@ if _NAME != 'libvd3d_hip.so':
 VD3D_BF16 = 0
 VD3D_F32 = 1
 VD3D_F16 = 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -42,6 +42,7 @@ class ConvParams(C.Structure):
         ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32), ('dil', C.c_int32),
         ('Kpad', C.c_int32), ('CoutPad', C.c_int32), ('relu', C.c_int32), ('dtype', C.c_int32), ('out_f32', C.c_int32),
         ('weight_frag', c_void_p),
+        ('splitk_ws', c_void_p), ('splitk_ws_bytes', C.c_int64),
     ]
 
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     'vd3d_last_error': (C.c_char_p, []),
     'vd3d_conv2d_igemm': (c_int, [C.POINTER(ConvParams), c_void_p]),
     'vd3d_conv2d_production_tiles': (c_int, [c_void_p, c_int]),
+    'vd3d_conv2d_workspace_bytes': (c_int64, [C.POINTER(ConvParams)]),
     'vd3d_pack_image_nhwc4': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_maxpool3x3s2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
     'vd3d_avgpool2x2': (c_int, [c_void_p, c_void_p] + [c_int] * 7 + [c_void_p]),
@@ -132,6 +134,7 @@ SIGNATURES = {
 TEST_HOOKS = {
     'vd3d_test_force_conv_tile': (c_int, [c_int]),
     'vd3d_test_set_switch': (c_int, [C.c_char_p, c_int]),
+    'vd3d_test_get_switch': (c_int, [C.c_char_p]),
 }
 # declared in include/vd3d.h, implemented later this round (moved into SIGNATURES as they land)
 PENDING = {
@@ -163,8 +166,28 @@ def lib():
         v = h.vd3d_abi_version()
         if v != ABI_VERSION:
             raise Vd3dError('libvd3d_hip.so ABI %d != expected %d; rebuild' % (v, ABI_VERSION))
+        # the test hooks change which kernels the following launches run: every call bumps an epoch that the detectors' hipGraph
+        # cache (networks/lib/graphed.py) keys on, so a captured graph never outlives the setting it was captured under
+        for name in TEST_HOOKS:
+            if name.startswith('vd3d_test_set') or name.startswith('vd3d_test_force'):
+                setattr(h, name, _bumping(getattr(h, name)))
         _lib = h
     return _lib
+
+
+_HOOK_EPOCH = 0
+
+
+def hook_epoch():
+    return _HOOK_EPOCH
+
+
+def _bumping(fn):
+    def call(*a):
+        global _HOOK_EPOCH
+        _HOOK_EPOCH += 1
+        return fn(*a)
+    return call
 
 
 def check(rc, what):
@@ -181,7 +204,10 @@ class test_switch:
         self.name, self.on = name.encode(), int(bool(on))
 
     def __enter__(self):
+        self.prev = lib().vd3d_test_get_switch(self.name)
+        if self.prev < 0:
+            raise Vd3dError('unknown switch %r' % self.name)
         check(lib().vd3d_test_set_switch(self.name, self.on), 'vd3d_test_set_switch')
 
     def __exit__(self, *exc):
-        check(lib().vd3d_test_set_switch(self.name, 1 - self.on), 'vd3d_test_set_switch')
+        check(lib().vd3d_test_set_switch(self.name, self.prev), 'vd3d_test_set_switch')   # restore what was found, not 1 - on

@@ -44,6 +44,14 @@ extern "C" int vd3d_test_set_switch(const char* name, int on) {
     return VD3D_EINVAL;
 }
 
+extern "C" int vd3d_test_get_switch(const char* name) {
+    std::call_once(g_switch_once, switches_from_env);
+    for (int i = 0; i < VD3D_SW_COUNT; ++i)
+        if (name && !strcmp(name, kSwitchNames[i])) return g_switch[i].load(std::memory_order_relaxed) != 0;
+    vd3d_set_error("vd3d_test_get_switch: unknown switch");
+    return -1;
+}
+
 int vd3d_current_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kVd3dMaxDevices) {
@@ -75,5 +83,5 @@ int vd3d_raise_lds_limit(const void* kern, int bytes, Vd3dLdsLimit& state, const
     return VD3D_OK;
 }
 
-extern "C" int vd3d_abi_version(void) { return 4; }
+extern "C" int vd3d_abi_version(void) { return 5; }
 extern "C" const char* vd3d_last_error(void) { return g_err; }

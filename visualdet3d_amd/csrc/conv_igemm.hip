@@ -501,7 +501,11 @@ VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const
 // logical slot (L%8) ^ ((row/2)%8) of its row -- the same 128 contiguous bytes per row, permuted among 8 lanes, so
 // global coalescing is unchanged and the fragment reads keep the conflict-free swizzled addressing.
 // Zero padding still comes from the SRD bounds check (out-of-range lanes write zeros into LDS).
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false>
+// KS = 1: split-K instantiation (ConvArgs::ks_*): the low-parallelism shapes of a batch-1 call -- M = 1920 pixels at stride 16 is 15 x 11
+// tiles of 128 x 128 for 256 CUs -- run as tiles x splits workgroups over disjoint K ranges + one reduction pass (two launches, no
+// atomics: the partials are added in split order, results do not depend on scheduling).  KS = 0 instantiations compile to the code
+// they were before the parameter existed.
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int KS = 0>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int ES = (int)sizeof(T);
@@ -523,9 +527,15 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    int split = 0;
+    if constexpr (KS) {
+        const int nt = p.tiles_m * p.tiles_n;       // phase 1: grid = tiles x splits (split-major); phase 2: grid = tiles
+        split = tile / nt;
+        tile -= split * nt;
+    }
     int tile_n = tile / p.tiles_m, tile_m = tile - tile_n * p.tiles_m;
-    if (p.group_m > 0) {
+    if (!KS && p.group_m > 0) {
         // pixel matrix far larger than L2 + Infinity Cache (the 1.8 GB DCN column matrix of BASELINE config 3): N-major order makes
         // every N tile re-stream it from HBM (8 x 1.8 GB).  Grouped order: group_m pixel tiles x ALL N tiles run back to back on
         // one XCD, so a pixel slice is fetched once per group and a weight slice once per group_m pixel tiles.
@@ -626,6 +636,28 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     }
     const uint32_t w_row = (uint32_t)(((n0 + 8 * wave + prow) * p.Kpad + slot * VE) * ES);
     uint32_t w_off = w_row;
+    int nk_l = p.nk;                             // K slices this workgroup walks
+    if constexpr (KS) {
+        const int kt0 = split * p.ks_per;        // first slice of this split: put the walk's state there
+        nk_l = p.nk - kt0 < p.ks_per ? p.nk - kt0 : p.ks_per;
+        if (kt0 > 0) {
+            if (p.chunk_major) {
+                const int chunk = kt0 / p.ntaps;
+                tap = kt0 - chunk * p.ntaps;
+                dy = tap / p.kw;
+                dx = tap - dy * p.kw;
+                kc = chunk * BKE + slot * VE;
+                w_off = w_row + (uint32_t)((tap * p.Cin + chunk * BKE) * ES);
+            } else {
+                const int klin = kt0 * BKE + slot * VE;
+                tap = klin / p.Cin;
+                kc = klin - tap * p.Cin;
+                dy = tap / p.kw;
+                dx = tap - dy * p.kw;
+                w_off = w_row + (uint32_t)(kt0 * BKE * ES);
+            }
+        }
+    }
 
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.weight, 0, p.w_bytes, 0x00020000);
@@ -720,6 +752,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
       }
     };
 
+    bool run_main = true;
+    if constexpr (KS) run_main = p.ks_phase != 2;   // (phase 2 only adds the partials and runs the epilogue)
+    if (!run_main) {
+        write_ltab();
+        __syncthreads();
+    } else
     if constexpr (!PIPE) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) issue_group(0, g);
@@ -727,8 +765,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         write_ltab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        for (int kt = 0; kt < p.nk; ++kt) {
-            compute(kt & 1, kt + 1 < p.nk);     // DMA of slice k+1 is spread over the MFMAs of slice k
+        for (int kt = 0; kt < nk_l; ++kt) {
+            compute(kt & 1, kt + 1 < nk_l);     // DMA of slice k+1 is spread over the MFMAs of slice k
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -751,8 +789,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
         for (int g = 0; g < 4; ++g) issue_group(0, g);
         advance_k();
-        issue_group(1, 0, p.nk > 1);
-        issue_group(1, 1, p.nk > 1);
+        issue_group(1, 0, nk_l > 1);
+        issue_group(1, 1, nk_l > 1);
         write_ltab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -768,9 +806,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         for (int j = 0; j < TM; ++j) fb[0][j] = ld_a(0, 0, j);
         constexpr int NMFMA = sizeof(T) == 2 ? TM : 4 * TM;               // MFMA instructions per weight fragment
         auto group_size = [](int g) { return (NPIECE - g + 3) / 4; };
-        for (int kt = 0; kt < p.nk; ++kt) {
+        for (int kt = 0; kt < nk_l; ++kt) {
             const int st = kt & 1;
-            const bool more1 = kt + 1 < p.nk, more2 = kt + 2 < p.nk;
+            const bool more1 = kt + 1 < nk_l, more2 = kt + 2 < nk_l;
 #pragma unroll
             for (int f = 0; f < NSUB * TN; ++f) {
                 const int ks = f / TN, i = f - ks * TN;
@@ -829,6 +867,36 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     for (int j = 0; j < TM; ++j) {
         const int m = m0 + wm * WTM + j * MS + lr;
         mrow[j] = m < p.M ? m : -1;
+    }
+    if constexpr (KS) {
+        // partials in REGISTER order: vector v of wave w of workgroup (split, tile) is one fully coalesced 1 KiB row of the workspace
+        constexpr int AV = MS * MS / 64 / 4, NV = TN * TM * AV;           // f32x4 vectors per accumulator tile / per lane
+        f32x4* wsb = (f32x4*)p.ks_ws;
+        const int nt = p.tiles_m * p.tiles_n, tl = tile_n * p.tiles_m + tile_m;
+        if (p.ks_phase == 1) {
+            f32x4* dst = wsb + (((size_t)(split * nt + tl) * NW + wave) * NV) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int v = 0; v < AV; ++v)
+                        dst[((i * TM + j) * AV + v) * 64] = f32x4{acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+            return;
+        }
+        for (int sp = 0; sp < p.ks_n; ++sp) {
+            const f32x4* src = wsb + (((size_t)(sp * nt + tl) * NW + wave) * NV) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int v = 0; v < AV; ++v) {
+                        const f32x4 x = src[((i * TM + j) * AV + v) * 64];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * v + e] += x[e];
+                    }
+        }
     }
     if constexpr (HEADF) {
         // ---- fused KM3D head, first version (VD3D_HEAD_PARKED=1; the product path is km3d_head_conv.hip): this N tile is head h = tile_n.  bias + ReLU, round to bf16 (the rounding point of the unfused
@@ -1128,6 +1196,58 @@ int launch(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_igemm");
 }
 
+// ---- split-K (KS = 1 instantiations): two launches of the same kernel, phase 1 over tiles x splits, phase 2 over tiles -------------
+struct SplitPlan { int bn = 0; int splits = 1; int64_t ws_bytes = 0; };     // bn: 128 (128 x 128 tiles) | 64 (128 x 64), 0 = do not split
+
+// Low-parallelism shapes only: fewer 128-row tiles than ~1.2 x CUs (a batch-1 / batch-2 call at stride 16 or 32) AND a K deep enough
+// (>= 24 slices) that the extra reduction launch (~6 us) pays.  Splits fill two workgroup slots per CU, keep >= 4 slices per split.
+// Nothing the batch-8 ... batch-32 configurations launch gets here (their tile counts are in the thousands).
+static SplitPlan plan_splitk(const ConvArgs& a, bool forced) {
+    SplitPlan pl;
+    const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
+    const int bn = a.Cout <= 64 ? 64 : 128;
+    const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((a.Cout + bn - 1) / bn);
+    if (!forced && (a.nk < 24 || tiles * 10 > (int64_t)cus * 12)) return pl;
+    if (a.nk < 2) return pl;
+    int s = (int)((2 * (int64_t)cus) / tiles);
+    if (s > a.nk / 4) s = a.nk / 4;
+    if (s > 32) s = 32;
+    if (s < 2) { if (!forced) return pl; s = 2; }
+    const int per = (a.nk + s - 1) / s;
+    pl.splits = (a.nk + per - 1) / per;          // every split is non-empty
+    if (pl.splits < 2) return pl;
+    pl.bn = bn;
+    pl.ws_bytes = (int64_t)pl.splits * tiles * 128 * bn * 4;
+    return pl;
+}
+
+template <typename T, int BN, int WARPS_M, int WARPS_N, bool PIPE>
+int launch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
+    constexpr int BM = 128, NT = WARPS_M * WARPS_N * 64;
+    constexpr int LDS = 2 * (BM + BN) * 128 + 2 * BN * 4;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.Cout + BN - 1) / BN;
+    a.group_m = 0;
+    a.ks_n = pl.splits;
+    a.ks_per = (a.nk + pl.splits - 1) / pl.splits;
+    static Vd3dLdsLimit lim;
+    auto kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, 32, 0, 0, false, 1>;
+    if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_igemm split-K)")) return rc;
+    const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
+    if (tiles <= 0 || tiles * pl.splits > 0x7fffffff) return VD3D_EINVAL;
+    a.ks_phase = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * pl.splits)), dim3(NT), LDS, stream, a);
+    a.ks_phase = 2;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(NT), LDS, stream, a);
+    return vd3d_check_launch("conv_igemm split-K");
+}
+
+template <typename T>
+int dispatch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
+    if (pl.bn == 64) return launch_splitk<T, 64, 4, 1, false>(a, stream, pl);
+    return launch_splitk<T, 128, 2, 2, true>(a, stream, pl);
+}
+
 // Tile override: 0 = heuristic, otherwise a config id (vd3d_test_force_conv_tile, csrc/test_hooks.h: a TEST hook, thread-local,
 // not declared in include/vd3d.h).  The PRODUCT build only knows the ids of the
 // tiles the heuristic below can pick (tests/test_conv_tiles_gpu.py forces each of them on awkward shapes and compares with
@@ -1171,6 +1291,12 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 23: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 256, 2, 4, 3>(a, stream));
         case 27: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 2, 2, 4>(a, stream));
         case 60: break;      // heuristic, but without the resident-weight kernels (A/B of those kernels)
+        case 144: case 130: {  // split-K over 128 x 128 / 128 x 64 tiles (the plan's split count, at least 2)
+            const SplitPlan pl = plan_splitk(a, true);
+            if (pl.splits < 2 || pl.bn != (g_force_cfg == 144 ? 128 : 64)) return forced_tile_error("split-K: needs >= 2 K slices and Cout <= 64 for the 128 x 64 tile / > 64 for 128 x 128");
+            if (!a.ks_ws || a.ks_ws_bytes < pl.ws_bytes) return forced_tile_error("split-K: workspace missing or too small (vd3d_conv2d_workspace_bytes)");
+            return dispatch_splitk<T>(a, stream, pl);
+        }
         case 68:
             if constexpr (kBf16) {
                 if (!ksplit_shape_ok(a)) return forced_tile_error("needs a 16-bit 3x3 / stride 1 / pad 1 conv with Cin 256, Cout a multiple of 64");
@@ -1254,6 +1380,11 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
             a.wide_store && !a.out_f32)
             return launch_resident64(a, stream, fmt);
+    }
+    // low-parallelism shapes with a deep K (batch-1 calls: 1408 -> 1408 at 24 x 80 is 165 tiles for 512 workgroup slots): split-K
+    if (g_force_cfg == 0 && a.ks_ws) {
+        const SplitPlan pl = plan_splitk(a, false);
+        if (pl.splits >= 2 && a.ks_ws_bytes >= pl.ws_bytes) return dispatch_splitk<T>(a, stream, pl);
     }
     // Cout <= 32: 8 waves of 32 pixels x 32 channels, pipelined loop (+8 % on the ghost 24 -> 24 conv, +27 % on KM3D's 64 -> 27
     // offset convs over the 4-wave barrier-per-slice version)
@@ -1363,7 +1494,7 @@ extern "C" int vd3d_test_force_conv_tile(int cfg) {
 
 extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
     // keep in step with the "production tiles" block of dispatch()
-    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70};
+    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130};
     const int n = (int)(sizeof(kIds) / sizeof(kIds[0]));
     for (int i = 0; i < n && i < cap; ++i) ids[i] = kIds[i];
     return n;
@@ -1395,6 +1526,8 @@ static int fill_conv_args(const vd3d_conv_params* p, ConvArgs& a) {
     a.wfrag = (const char*)p->weight_frag;
     if (p->weight_frag && ((uintptr_t)p->weight_frag & 15)) { vd3d_set_error("conv2d_igemm: weight_frag must be 16-byte aligned"); return VD3D_EINVAL; }
     a.residual = (const char*)p->residual; a.out = (char*)p->out;
+    a.ks_ws = (float*)p->splitk_ws; a.ks_ws_bytes = p->splitk_ws ? p->splitk_ws_bytes : 0;
+    if (p->splitk_ws && ((uintptr_t)p->splitk_ws & 15)) { vd3d_set_error("conv2d_igemm: splitk_ws must be 16-byte aligned"); return VD3D_EINVAL; }
     a.B = p->B; a.H = p->H; a.W = p->W; a.Cin = p->Cin;
     a.in_pix_stride = p->in_pix_stride; a.in_row_stride = p->in_row_stride; a.in_batch_stride = p->in_batch_stride;
     a.in_bytes = (uint32_t)p->in_bytes; a.w_bytes = (uint32_t)((int64_t)p->CoutPad * p->Kpad * es);
@@ -1435,6 +1568,22 @@ extern "C" int vd3d_conv2d_igemm(const vd3d_conv_params* p, void* stream) {
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     return p->dtype == VD3D_BF16 ? dispatch<short>(a, s) : (p->dtype == VD3D_F16 ? dispatch<hf16>(a, s) : dispatch<float>(a, s));
+}
+
+extern "C" int64_t vd3d_conv2d_workspace_bytes(const vd3d_conv_params* p) {
+    ConvArgs a;
+    vd3d_conv_params q = *p;
+    q.splitk_ws = nullptr;
+    if (fill_conv_args(&q, a)) return -1;
+    if (g_force_cfg == 144 || g_force_cfg == 130) return plan_splitk(a, true).ws_bytes;
+    if (g_force_cfg != 0) return 0;
+    // the split-K path sits behind the resident-weight / streaming kernels in dispatch(): a shape one of those takes never splits
+    if (p->dtype != VD3D_F32) {
+        if ((a.Cin == 128 && regw_shape_ok(a)) || ksplit_shape_ok(a) || small_shape_ok(a) || narrow_shape_ok(a) || pw_shape_ok(a) ||
+            (a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.wide_store && !a.out_f32))
+            return 0;
+    }
+    return plan_splitk(a, false).ws_bytes;
 }
 
 extern "C" int vd3d_conv2d_pair(const vd3d_conv_params* pa, const vd3d_conv_params* pb, void* stream) {

@@ -1262,8 +1262,8 @@ __global__ void __launch_bounds__(512) conv_narrow_kernel(const ConvArgs p, int 
 // launch -- DLA level0 -> level1 (backbones/dla.py:118-121, :142-148) at full / half resolution: 16 x 512 x 1760 x 16 channels are
 // 461 MB that the two small-channel launches wrote and read back (197 + 132 us, both HBM bound).  A workgroup owns 8 x 32 outputs of
 // conv B = 17 x 65 outputs of conv A (1.08x the pixels a non-overlapping split would compute) = a 19 x 67-pixel halo of the input,
-// staged by LDS-DMA two tiles ahead (three 40 KiB stages: with one tile ahead the 40 KB in flight per CU could not cover the memory
-// latency -- 288 us against 411 for the two launches; ...).  Phase 1: conv A on the matrix cores from the halo (32-pixel blocks dealt to
+// staged by LDS-DMA ONE tile ahead into a single 40 KiB halo stage (the next tile's halo is requested after phase 1 has consumed the
+// current one; two workgroups of 4 waves share a CU, so the partner's phases cover the latency).  Phase 1: conv A on the matrix cores from the halo (32-pixel blocks dealt to
 // the waves, weights in registers), BN + ReLU, rounded to the 16-bit format (the rounding point of the unfused tensor), positions
 // outside the image zeroed (conv B's zero padding), into a [17 x 65][16] LDS image.  Phase 2: the small-channel kernel's stride-2
 // step from that image.  Same MFMA shapes and tap order as the two launches: results are bit-identical.
@@ -1354,7 +1354,10 @@ __global__ void __launch_bounds__(kPrNW * 64) __attribute__((amdgpu_waves_per_eu
     int t = blockIdx.x;
     issue_halo(t);
     // VMEM queue of a wave per tile: D(k + 1) [P pieces, after phase 1 of tile k] S(k) [2 RW stores].  At the top of tile k the halo D(k)
-    // must have landed: younger are only the stores of tile k - 1.
+    // must have landed: younger are only the stores of tile k - 1.  The FIRST tile has no such stores behind its halo, so the counted
+    // wait below would let up to 2 RW of its P pieces still be in flight: drain the prologue's DMA explicitly (the compiler happened to
+    // put a vmcnt(0) in the loop preheader for the weight loads; nothing guaranteed it).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (; t < ntiles; t += nwg) {
         const int b = t / tiles_img, trem = t - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;

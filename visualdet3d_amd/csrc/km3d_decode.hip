@@ -470,6 +470,8 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
         vd3d_set_error("km3d_decode: need 9 joints, K <= 128, n_cls*K <= 512, max_peaks a power of two in [K, 8192]");
         return VD3D_EINVAL;
     }
+    // validated with the other parameters, BEFORE anything is enqueued (include/vd3d.h states the limit)
+    if (q->n_cls > kPeakMaxC || q->n_joints > kPeakMaxC) { vd3d_set_error("km3d_decode: more than 9 heat-map channels per map"); return VD3D_ERANGE; }
     hipStream_t s = (hipStream_t)stream;
     const int nch = q->n_cls + q->n_joints;
     Ws w = carve(q->workspace, q->B, nch, q->max_peaks, q->K);
@@ -483,7 +485,6 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_cls = q->out_cls; a.out_count = q->out_count;
     const int nz = (int)(((int64_t)q->B * nch * 4 + 255) / 256 * 256 + (int64_t)q->B * 4) / 4;
     hipLaunchKernelGGL(km3d_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, w.peak_count, nz);
-    if (q->n_cls > kPeakMaxC || q->n_joints > kPeakMaxC) { vd3d_set_error("km3d_decode: more than 9 heat-map channels per map"); return VD3D_ERANGE; }
     {
         const int tiles_x = (q->W + kPeakTW - 1) / kPeakTW, tiles_y = (q->H + kPeakTH - 1) / kPeakTH;
         const int cmax = q->n_cls > q->n_joints ? q->n_cls : q->n_joints;

@@ -11,6 +11,9 @@ int vd3d_test_force_conv_tile(int cfg);
 /* Override one of the A/B environment switches of DESIGN 3.4 ("VD3D_NO_LINE_STORE", ...), which the library otherwise reads
  * once per process.  Both settings of every switch are correct implementations. */
 int vd3d_test_set_switch(const char* name, int on);
+/* Current state of a switch (0 | 1), -1 for an unknown name: lets a test restore what it found (a switch may have been enabled
+ * through the environment for the whole run). */
+int vd3d_test_get_switch(const char* name);
 #ifdef __cplusplus
 }
 #endif

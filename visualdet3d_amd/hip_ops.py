@@ -183,6 +183,13 @@ def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
     p.Kpad, p.CoutPad, p.relu = pc.Kpad, pc.CoutPad, int(relu)
     p.dtype, p.out_f32 = dtype_code(x.dtype), int(out_f32)
     p.weight_frag = pc.w_frag.data_ptr() if pc.w_frag is not None else None
+    # split-K scratch for low-parallelism shapes (batch-1 calls): the library says how much it wants (0 for everything the batched
+    # configurations launch); a fresh stream-ordered allocation per call -- inside a hipGraph capture it lives in the graph's pool
+    need = _lib.lib().vd3d_conv2d_workspace_bytes(C.byref(p))
+    ws = None
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), need
     check(_lib.lib().vd3d_conv2d_igemm(C.byref(p), _stream()), 'vd3d_conv2d_igemm')
     return out
 

@@ -5,12 +5,13 @@ import torch.nn as nn
 
 from ..heads.km3d_head import KM3DHead
 from ..lib import fused
+from ..lib.graphed import GraphedForward, clone_results
 from ..utils.registry import DETECTOR_DICT
 from .KM3D_core import KM3DCore
 
 
 @DETECTOR_DICT.register_module
-class KM3D(nn.Module):
+class KM3D(GraphedForward, nn.Module):
     def __init__(self, network_cfg):
         super(KM3D, self).__init__()
         self.obj_types = network_cfg.obj_types
@@ -39,7 +40,10 @@ class KM3D(nn.Module):
 
     @torch.no_grad()
     def test_forward_batched(self, img_batch, P2):
-        return self.bbox_head.unpad(self.forward_device(img_batch, P2))
+        if not img_batch.is_cuda:
+            raise RuntimeError('KM3D runs on the MI355X HIP path only: move the model and inputs to cuda')
+        P2 = torch.as_tensor(P2).to(device=img_batch.device)
+        return clone_results(self.bbox_head.unpad(self._graphed(img_batch, P2)))      # hipGraph cache, lib/graphed.py
 
     @torch.no_grad()
     def test_forward(self, img_batch, P2):

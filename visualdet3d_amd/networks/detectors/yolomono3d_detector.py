@@ -10,6 +10,7 @@ from ... import hip_ops as ops
 from ..heads.detection_3d_head import AnchorBasedDetection3DHead, _conv_pack
 from ..lib import fused
 from ..lib.blocks import AnchorFlatten
+from ..lib.graphed import GraphedForward, clone_results
 from ..lib.look_ground import LookGround
 from ..utils.registry import DETECTOR_DICT
 from .yolomono3d_core import YoloMono3DCore
@@ -48,7 +49,7 @@ class GroundAwareHead(AnchorBasedDetection3DHead):
 
 
 @DETECTOR_DICT.register_module
-class Yolo3D(nn.Module):
+class Yolo3D(GraphedForward, nn.Module):
     def __init__(self, network_cfg):
         super(Yolo3D, self).__init__()
         self.obj_types = network_cfg.obj_types
@@ -77,7 +78,11 @@ class Yolo3D(nn.Module):
 
     @torch.no_grad()
     def test_forward_batched(self, img_batch, P2):
-        return self.bbox_head.unpad(self.forward_device(img_batch, P2))   # post_optimization runs inside get_bboxes_batched
+        if not img_batch.is_cuda:
+            raise RuntimeError('Yolo3D runs on the MI355X HIP path only: move the model and inputs to cuda')
+        P2 = torch.as_tensor(P2).to(device=img_batch.device)
+        # through the hipGraph cache (lib/graphed.py); post_optimization runs inside get_bboxes_batched, i.e. inside the graph
+        return clone_results(self.bbox_head.unpad(self._graphed(img_batch, P2)))
 
     @torch.no_grad()
     def test_forward(self, img_batch, P2):

@@ -9,12 +9,13 @@ import torch.nn as nn
 
 from ..heads.detection_3d_head import AnchorBasedDetection3DHead, StereoHead
 from ..lib import fused
+from ..lib.graphed import GraphedForward, clone_results
 from ..utils.registry import DETECTOR_DICT
 from .yolostereo3d_core import YoloStereo3DCore
 
 
 @DETECTOR_DICT.register_module
-class Stereo3D(nn.Module):
+class Stereo3D(GraphedForward, nn.Module):
     def __init__(self, network_cfg):
         super(Stereo3D, self).__init__()
         self.obj_types = network_cfg.obj_types
@@ -46,8 +47,12 @@ class Stereo3D(nn.Module):
 
     @torch.no_grad()
     def test_forward_batched(self, left_images, right_images, P2, P3=None):
-        """B >= 1.  Returns a list of per-sample ``(scores[N], bboxes[N,11], cls_indexes[N] int64)``."""
-        return self.bbox_head.unpad(self.forward_device(left_images, right_images, P2))
+        """B >= 1.  Returns a list of per-sample ``(scores[N], bboxes[N,11], cls_indexes[N] int64)``.  Runs through the hipGraph
+        cache (lib/graphed.py): the first call for a shape captures ``forward_device``, later calls replay it."""
+        if not left_images.is_cuda:
+            raise RuntimeError('Stereo3D runs on the MI355X HIP path only: move the model and inputs to cuda')
+        P2 = torch.as_tensor(P2).to(device=left_images.device)
+        return clone_results(self.bbox_head.unpad(self._graphed(left_images, right_images, P2)))
 
     @torch.no_grad()
     def test_forward(self, left_images, right_images, P2, P3):

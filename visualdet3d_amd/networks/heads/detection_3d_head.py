@@ -131,11 +131,18 @@ class AnchorBasedDetection3DHead(nn.Module):
         side = self._side_streams.get(feat.device)
         if side is None:
             side = self._side_streams[feat.device] = torch.cuda.Stream(device=feat.device)
-        side.wait_stream(main)
         self._preselected = None
+        early = self.overlap_select and not self.training and inputs.get('P2') is not None and inputs.get('image') is not None
+        if early:
+            # on the MAIN stream, before the fork: the calibration tensor in its device fp32 form and the candidate workspace -- a
+            # tensor allocated while the side stream is current would belong to that stream's pool, and a host / non-fp32 P2 would be
+            # converted (a synchronous H2D copy) inside the overlapped region and never match the key of the later NMS stage
+            self._device_p2(inputs['P2'], feat.device)
+            self._ensure_workspace(feat.shape[0], feat.device)
+        side.wait_stream(main)
         with torch.cuda.stream(side):
             cls_preds = self._cls_forward_nhwc(feat)
-            if self.overlap_select and not self.training and inputs.get('P2') is not None and inputs.get('image') is not None:
+            if early:
                 # stage 1 of get_bboxes (ground filter + sigmoid + threshold -> candidate lists) only reads the class logits: it runs
                 # here, behind the cls tower, while the reg tower still computes on the main stream (-20 us on the critical path)
                 self._preselected = self._select(cls_preds, inputs['P2'], inputs['image'].shape[2:], clip=True)
@@ -144,7 +151,7 @@ class AnchorBasedDetection3DHead(nn.Module):
         cls_preds.record_stream(main)
         feat.record_stream(side)
         if self._workspace is not None:
-            self._workspace.record_stream(side)
+            self._workspace.record_stream(side)      # allocated on the main stream (above), also used on the side stream
         return cls_preds, reg_preds
 
     def forward(self, inputs):
@@ -191,17 +198,33 @@ class AnchorBasedDetection3DHead(nn.Module):
         ops.head_select / ops.head_postprocess; (re)allocates the candidate workspace."""
         dev = cls_preds.device
         anchors, prior, A = self.anchors.device_tables(img_hw, dev)
-        B = cls_preds.shape[0]
-        need = ops._lib.lib().vd3d_head_workspace_bytes(B, self.max_candidates)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        self._ensure_workspace(cls_preds.shape[0], dev)
         lo, hi = self.anchors.filter_y_threshold_min_max
-        P2s = P2s.to(device=dev, dtype=torch.float32).contiguous()
+        P2s = self._device_p2(P2s, dev)
         args = (anchors, prior, P2s, A, self.num_classes, len(self.anchors.obj_types), tuple(int(v) for v in img_hw) if clip else (0, 0),
                 getattr(self.test_cfg, 'score_thr', 0.5), getattr(self.test_cfg, 'nms_iou_thr', 0.5))
         kw = dict(use_filter=bool(self._is_filtering() and self.anchors.readConfigFile), y_min_max=(lo, hi),
                   x_max=self.anchors.filter_x_threshold, max_cand=self.max_candidates, workspace=self._workspace)
         return args, kw
+
+    def _ensure_workspace(self, B, dev):
+        need = ops._lib.lib().vd3d_head_workspace_bytes(B, self.max_candidates)
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._workspace
+
+    def _device_p2(self, P2s, dev):
+        """The calibration matrices as a contiguous fp32 device tensor.  Already in that form: returned as is.  Otherwise converted ONCE
+        per source tensor (identity + version), so that the early selection and the NMS stage of one forward see the very same
+        tensor (the preselection key holds its data_ptr)."""
+        if P2s.device == dev and P2s.dtype == torch.float32 and P2s.is_contiguous():
+            return P2s
+        hit = getattr(self, '_p2_conv', None)
+        if hit is not None and hit[0] is P2s and hit[1] == P2s._version and hit[2].device == dev:
+            return hit[2]
+        conv = P2s.to(device=dev, dtype=torch.float32).contiguous()
+        self._p2_conv = (P2s, P2s._version, conv)
+        return conv
 
     @staticmethod
     def _select_key(cls_preds, args, kw):

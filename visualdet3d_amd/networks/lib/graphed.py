@@ -1,0 +1,133 @@
+"""hipGraph cache behind the detectors' ``test_forward`` / ``test_forward_batched``.
+
+The reference's contract is one frame per call (``networks/detectors/yolostereo3d_detector.py:77-103``, called once per frame by
+``networks/pipelines/testers.py:15-42``).  Launched eagerly, a batch-1 forward is ~60 kernel launches of a few microseconds each:
+the host's launch path, not the GPU, sets the frame time.  Here the first call for a given (input shapes, compute dtype, head
+settings, weights) runs ``forward_device`` eagerly (packs weights, builds the anchor tables, raises LDS limits, warms the allocator),
+captures it once into a hipGraph over STATIC input buffers, and every later call is: three device copies into the static inputs, one
+graph launch, one device->host read of the detection counts, and clones of the (tiny) result slices -- what ``bench.py`` measures is
+what a caller of ``module([left, right, P2, P3])`` gets.
+
+Invalidation (the same facts ``lib/fused.PackCache`` keys the packed weights on):
+  * every parameter's / buffer's ``_version`` (``load_state_dict`` and any in-place update bump it) -- checked on every call;
+  * ``Module._apply`` (``.to()``, ``.cuda()``, ``.half()`` ...: storages are replaced) drops all graphs;
+  * the library's test hooks (forced tiles, A/B switches) carry an epoch that is part of the key;
+  * head settings read at launch time (thresholds, post-optimisation, overlap switches) are part of the key.
+Swapping a parameter's storage by hand (``p.data = other``) is the one thing not seen; call ``drop_graphs()`` after doing that.
+
+``VD3D_NO_GRAPH=1`` in the environment or ``model.use_graph = False`` selects the eager path (same kernels, same results)."""
+import os
+import warnings
+from collections import OrderedDict
+from operator import attrgetter
+
+import torch
+
+from ... import _lib
+
+_VERSION = attrgetter('_version')
+_MAX_GRAPHS = 8          # per model; each holds the activations of its shape in a private pool (LRU beyond that)
+
+
+class _Entry:
+    __slots__ = ('graph', 'static_in', 'static_out', 'versions', 'eager')
+
+    def __init__(self):
+        self.graph, self.static_in, self.static_out, self.versions, self.eager = None, None, None, None, False
+
+
+class GraphedForward:
+    """Mixin for the detector classes: ``self._graphed(*device_tensors)`` == ``self.forward_device(*device_tensors)`` through the
+    graph cache.  The outputs are the graph's static result tensors: valid until the next call with the same key."""
+
+    use_graph = not os.environ.get('VD3D_NO_GRAPH')
+
+    def _graph_state(self):
+        st = self.__dict__.get('_vd3d_graphs')
+        if st is None:
+            st = self.__dict__['_vd3d_graphs'] = dict(entries=OrderedDict(), tensors=None, captures=0, replays=0, eager=0)
+        return st
+
+    @property
+    def graph_stats(self):
+        st = self._graph_state()
+        return dict(captures=st['captures'], replays=st['replays'], eager=st['eager'], cached=len(st['entries']))
+
+    def drop_graphs(self):
+        st = self._graph_state()
+        st['entries'].clear()
+        st['tensors'] = None
+
+    def _apply(self, fn, *a, **k):
+        self.drop_graphs()                       # storages are about to be replaced
+        return super()._apply(fn, *a, **k)
+
+    def _graph_knobs(self):
+        head = getattr(self, 'bbox_head', None)
+        core = getattr(self, 'core', None)
+        tc = getattr(head, 'test_cfg', None)
+        knobs = [self.compute_dtype, self.training, _lib.hook_epoch()]
+        for obj, names in ((head, ('overlap_towers', 'overlap_select', 'max_candidates', 'max_peaks', 'TOPK')), (core, ('overlap_neck',))):
+            knobs += [getattr(obj, n, None) for n in names]
+        if tc is not None:
+            knobs += [repr(sorted(tc.items())) if hasattr(tc, 'items') else repr(tc)]
+        return tuple(knobs)
+
+    def _graphed(self, *inputs):
+        if not self.use_graph or torch.cuda.is_current_stream_capturing():
+            self._graph_state()['eager'] += 1
+            return self.forward_device(*inputs)
+        st = self._graph_state()
+        if st['tensors'] is None:
+            st['tensors'] = list(self.parameters()) + list(self.buffers())
+        versions = tuple(map(_VERSION, st['tensors']))
+        key = (tuple((tuple(t.shape), t.dtype, t.device) for t in inputs), self._graph_knobs())
+        ent = st['entries'].get(key)
+        if ent is not None and ent.versions != versions:
+            ent = None                           # weights changed in place since the capture
+        if ent is None:
+            ent = self._capture(inputs, versions)
+            st['entries'][key] = ent
+            st['entries'].move_to_end(key)
+            while len(st['entries']) > _MAX_GRAPHS:
+                st['entries'].popitem(last=False)
+        if ent.eager:
+            st['eager'] += 1
+            return self.forward_device(*inputs)
+        for dst, src in zip(ent.static_in, inputs):
+            dst.copy_(src, non_blocking=True)
+        ent.graph.replay()
+        st['replays'] += 1
+        return ent.static_out
+
+    def _capture(self, inputs, versions):
+        st = self._graph_state()
+        ent = _Entry()
+        ent.versions = versions
+        ent.static_in = [t.detach().clone().contiguous() for t in inputs]
+        with torch.no_grad():
+            for _ in range(2):                   # packs weights, builds tables, raises LDS limits, warms the allocator
+                self.forward_device(*ent.static_in)
+            torch.cuda.synchronize()
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):    # one pass off the default stream before capturing (side streams of the model exist now)
+                    self.forward_device(*ent.static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    ent.static_out = self.forward_device(*ent.static_in)
+                ent.graph = g
+                st['captures'] += 1
+            except Exception as e:               # noqa: BLE001 -- the eager launches are the same kernels; say so once and carry on
+                warnings.warn('hipGraph capture of %s.forward_device failed (%s: %s); this shape runs eagerly' % (type(self).__name__, type(e).__name__, e))
+                torch.cuda.synchronize()
+                ent.eager, ent.graph, ent.static_out = True, None, None
+        return ent
+
+
+def clone_results(per_sample):
+    """The graph's result tensors are overwritten by the next replay: hand the caller its own copies (a few hundred bytes each).
+    ``unpad`` already made the int64 labels a fresh tensor."""
+    return [(s.clone(), b.clone(), l) for s, b, l in per_sample]
