@@ -31,6 +31,8 @@ STEREO_CASES = {
     'stereo3d_r34_384x1280_thr06': dict(depth=34, H=384, W=1280, frames=1, wseed=2, iseed=5, score_thr=0.6, head_std=0.009),
     # BASELINE config 3 as specified: ResNet-50 stereo core + the BASE (DCNv2) head, 288 x 1280 (Stereo3D with
     # build_head overridden to AnchorBasedDetection3DHead); the reference's CUDA-only DCN is served by oracle/dcn_ref.py
+    # config/Stereo3D_example:114-122 at its SHIPPED crop size (cropSize 288 x 1280, ResNet-34, StereoHead)
+    'stereo3d_r34_288x1280': dict(depth=34, H=288, W=1280, frames=1, wseed=1, iseed=16, score_thr=0.75, head_std=0.0005),
     'stereo3d_r50_dcn_288x1280': dict(depth=50, H=288, W=1280, frames=1, wseed=6, iseed=9, score_thr=0.5, head_std=0.006, dcn_head=True),
 }
 
@@ -97,6 +99,9 @@ MONO_CASES = {
     'groundaware_r34_96x320': dict(name='GroundAwareYolo3D', depth=34, H=96, W=320, frames=2, wseed=3, iseed=4, score_thr=0.5, head_std=0.02),
     'groundaware_r34_384x1280': dict(name='GroundAwareYolo3D', depth=34, H=384, W=1280, frames=1, wseed=3, iseed=6, score_thr=0.75, head_std=0.02),
     'yolo3d_dcn_r34_96x320': dict(name='Yolo3D', depth=34, H=96, W=320, frames=2, wseed=4, iseed=7, score_thr=0.5, head_std=0.02),
+    # config/Yolo3D_example:113-136 AS SHIPPED: GroundAwareYolo3D on ResNet-101, 288 x 1280 crop, score 0.75, nms 0.5, post_optimization on
+    'groundaware_r101_288x1280_postopt': dict(name='GroundAwareYolo3D', depth=101, H=288, W=1280, frames=1, wseed=8, iseed=15, score_thr=0.75,
+                                              head_std=0.03, post_optimization=True),
 }
 
 
@@ -108,7 +113,8 @@ def build_reference_mono(case, tmp):
         import visualDet3D.networks.lib.ops.dcn.deform_conv as ref_dcn
         from oracle import dcn_ref
         ref_dcn.modulated_deform_conv = lambda x, off, m, w, b, s, p, d, g, dg: dcn_ref.deform_conv_forward(x, off, m, w, b, s, p, d, g, dg)
-    cfg = syn.mono3d_cfg(tmp, depth=case['depth'], score_thr=case['score_thr'], name=case['name'])
+    cfg = syn.mono3d_cfg(tmp, depth=case['depth'], score_thr=case['score_thr'], name=case['name'],
+                         post_optimization=case.get('post_optimization', False))
     syn.write_synthetic_priors(tmp, cfg.obj_types, 2)
     model = DD[case['name']](cfg).eval()
     sd = syn.seeded_state_dict(model.state_dict(), seed=case['wseed'], head_std=case['head_std'])
@@ -139,6 +145,7 @@ def run_mono_case(name, case):
     out['meta'] = np.array([case['depth'], case['H'], case['W'], case['frames'], case['wseed'], case['iseed']])
     out['score_thr'] = np.float32(case['score_thr'])
     out['head_std'] = np.float64(case['head_std'])
+    out['post_optimization'] = np.int64(bool(case.get('post_optimization', False)))
     np.savez_compressed(os.path.join(GOLDEN_DIR, name + '.npz'), **out)
 
 

@@ -20,7 +20,8 @@ def _model(cfg, winit, dtype):
     return m, sd
 
 
-@pytest.mark.parametrize('name', ['groundaware_r34_96x320', 'groundaware_r34_384x1280', 'yolo3d_dcn_r34_96x320'])
+# (the last case is config/Yolo3D_example:113-136 AS SHIPPED: ResNet-101, 288 x 1280, nms 0.5, post_optimization on)
+@pytest.mark.parametrize('name', ['groundaware_r34_96x320', 'groundaware_r34_384x1280', 'yolo3d_dcn_r34_96x320', 'groundaware_r101_288x1280_postopt'])
 def test_fp32_mode_matches_reference_golden(name):
     g = load_golden(name)
     cfg, (img, P2), winit = mono_case_from_golden(g, name)
@@ -31,8 +32,10 @@ def test_fp32_mode_matches_reference_golden(name):
         assert rel_err(subsample(cls[f:f + 1].cpu()), g['f%d_cls_sub' % f]) < 1e-3
         assert rel_err(subsample(reg[f:f + 1].cpu()), g['f%d_reg_sub' % f]) < 1e-3
         s, b, l = [t.cpu() for t in outs[f]]
+        # post_optimization on (the shipped config): the yaw is the result of a discrete hill climb (steps >= 0.0125 rad, 3.14-vs-pi wrap)
+        loose = {10: (0.03, 2 * 3.141592653589793)} if cfg.head.test_cfg.post_optimization else None
         assert_detections_close((s, b, l), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=1e-3,
-                                what='%s frame %d' % (name, f))
+                                what='%s frame %d' % (name, f), loose_fields=loose)
     s1, b1, l1 = m([img[:1].cuda(), P2[:1].cuda()])      # the reference's batch-1 entry point
     assert torch.equal(s1, outs[0][0]) and torch.equal(b1, outs[0][1])
 

@@ -29,9 +29,9 @@ struct ConvArgs {
     int group_m = 0;                  // > 0: DMA tile kernels walk group_m pixel tiles x all N tiles per XCD run (huge 1x1 GEMMs)
     int strip_lines = 0;              // 16x16x32 strip tiles: 16-bit output re-laid through LDS (whole pixel runs per store instruction)
     int line_store = 0;               // 16-bit output re-laid through LDS so that store instructions cover whole 128-byte lines
-    // split-K (low-parallelism shapes, e.g. batch 1): ks_phase 1 = workgroup (tile, split) walks K slices [split * ks_per, + ks_per) and
-    // parks its raw fp32 accumulators in ks_ws in register order; ks_phase 2 = one workgroup per tile adds the ks_n partials in split
-    // order (deterministic) and runs the ordinary epilogue.  Only kernels instantiated with KS = 1 read these fields.
+    // split-K (low-parallelism shapes, e.g. batch 1): workgroup (tile, split) of a KS = 1 instantiation walks K slices
+    // [split * ks_per, + ks_per) and parks its raw fp32 accumulators in ks_ws in register order; splitk_reduce_kernel adds the ks_n
+    // partials in split order (deterministic) and runs the epilogue.  Only those two kernels read these fields.
     float* ks_ws = nullptr;
     int64_t ks_ws_bytes = 0;
     int ks_phase = 0, ks_per = 0, ks_n = 1;
