@@ -12,6 +12,7 @@ Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
 import sys
@@ -644,12 +645,20 @@ def main():
         fam, dominant_all, _ = profile_ops(model, inputs)
         conv, dominant = fam['conv'], dominant_all['conv']
         flops, secs, nl, alg_bytes = conv['flops'], conv['secs'], int(round(conv['launches'])), conv['bytes']
-        traffic, traffic_source = None, None
-        for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
-            pmc = os.path.join(REPO, 'profiles', name)
-            if args.dtype == 'bf16' and B == 8 and os.path.exists(pmc):
-                traffic = json.load(open(pmc))['conv_hbm_bytes_per_forward']
-                traffic_source = 'profiles/%s (STATIC: read from the committed rocprofv3 --pmc passes of this same command, NOT measured in this run)' % name
+        # roofline.traffic is STATIC (PMC counters need their own rocprofv3 passes): the newest committed record, stamped by
+        # tools/pmc_traffic.py with the hash of the convolution sources it measured -- `traffic_stale` says whether those sources moved since
+        from visualdet3d_amd import _lib as vlib, build as vbuild
+        traffic, traffic_source, traffic_stale = None, None, None
+        lib_hash = vlib.lib().vd3d_source_hash().decode()
+        library_current = lib_hash == vbuild.source_hash()          # the loaded .so was built from the sources in this tree
+        for pmc in sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+            if args.dtype == 'bf16' and B == 8:
+                rec = json.load(open(pmc))
+                traffic = rec['conv_hbm_bytes_per_forward']
+                stamp = rec.get('conv_sources_sha16')
+                traffic_stale = (stamp is None) or (stamp != vbuild.source_hash(vbuild.CONV_SOURCES)) or not library_current
+                traffic_source = ('profiles/%s (STATIC: read from the committed rocprofv3 --pmc passes of this same command, NOT measured in this run; '
+                                  'conv sources then %s, now %s)' % (os.path.basename(pmc), stamp or 'unstamped', vbuild.source_hash(vbuild.CONV_SOURCES)))
                 break
         peak = PEAK_BF16_TFLOPS if args.dtype == 'bf16' else PEAK_F32_TFLOPS
         ach = flops / secs / 1e12
@@ -666,7 +675,8 @@ def main():
                                % (feed.bytes_per_step, B, feed.HS, feed.WS)},
             'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw / conv_ksplit256 / conv_small / conv_pw (all %d launches per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                         'traffic': traffic, 'traffic_source': traffic_source,
+                         'traffic': traffic, 'traffic_source': traffic_source, 'traffic_stale': traffic_stale,
+                         'library_sources_sha16': lib_hash, 'library_matches_tree': library_current,
                          'traffic_unit': 'bytes per step over the conv launches (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes)',
                          'algorithmic_bytes': alg_bytes,
                          'dominant_layer': dict(dominant, unit='TFLOP/s', frac=round(dominant['achieved'] / peak, 4)),

@@ -36,6 +36,9 @@ extern "C" {
 int vd3d_abi_version(void);
 /* Human-readable text of the last HIP error seen by this thread (host pointer, never NULL). */
 const char* vd3d_last_error(void);
+/* sha256 (first 16 hex digits) of the sources this library was built from (visualdet3d_amd/build.py source_hash): lets a measurement
+ * record say which kernels it measured -- bench.py marks profiles/*_pmc_traffic.json stale when the convolution sources moved since. */
+const char* vd3d_source_hash(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused implicit-GEMM convolution:  out = act( conv(in, W) * scale + shift (+ residual) )
@@ -82,7 +85,8 @@ typedef struct vd3d_conv_params {
      * tiles than the device has CUs while K = kh*kw*Cin is thousands deep): tiles x splits workgroups park fp32 partial tiles here and
      * a second launch adds them in split order and runs the epilogue -- deterministic, no atomics.  NULL (or fewer bytes than
      * vd3d_conv2d_workspace_bytes asks for): the convolution runs unsplit.  16-byte aligned device memory, contents undefined on
-     * entry and exit; the library never allocates. */
+     * entry and exit; the library never allocates.  16-bit formats only: in VD3D_F32 (validation mode) the summation order must not
+     * depend on the batch size, the field is ignored and vd3d_conv2d_workspace_bytes returns 0. */
     void* splitk_ws;
     int64_t splitk_ws_bytes;
 } vd3d_conv_params;

@@ -401,6 +401,7 @@ def dcn_head(c, feats, num_cls_output, p='bbox_head'):
                                     1, 1, 1, 1, 1, rnd=(c.rnd if c.rnd is not identity else None))
     s, t = c.bn(p + '.reg_feature_extraction.1')
     r = c.rnd(F.relu(_affine(y, s, t)))
+    c.tap('dcn_head', q, bn=p + '.reg_feature_extraction.1', x=feats, y=r, logits=off_logits)
     r = conv_bn_act(c, r, p + '.reg_feature_extraction.3', p + '.reg_feature_extraction.4', True)
     reg = conv_bn_act(c, r, p + '.reg_feature_extraction.6', None, False, out_round=False)
     return anchor_flatten(cls, num_cls_output), anchor_flatten(reg, 12)
@@ -441,6 +442,8 @@ def dla_tree(c, p, x, levels, in_ch, out_ch, stride, level_root, residual=None, 
     """backbones/dla.py:177-230."""
     children = [] if children is None else children
     bottom = F.max_pool2d(x, stride, stride) if stride > 1 else x
+    if stride > 1:
+        c.tap('maxpool', p + '.downsample', x=x, y=bottom, k=stride)
     if in_ch != out_ch:
         residual = conv_bn_act(c, bottom, p + '.project.0', p + '.project.1', False, padding=0)
     else:
@@ -486,6 +489,7 @@ def dcn_bn_relu(c, p, x):
     taps = getattr(c, 'taps', None)
     if taps is not None:              # stage taps for teacher-forced per-layer parity (tests/test_km3d_gpu.py)
         taps[p] = (x, out)
+    c.tap('dcn', p, x=x, y=out, logits=logits)
     return out
 
 
@@ -495,8 +499,11 @@ def ida_up(c, p, layers, startp, endp, up_f):
         k = i - startp
         f = int(up_f[k])
         w = c.sd['%s.up_%d.weight' % (p, k)]
-        up = c.rnd(F.conv_transpose2d(dcn_bn_relu(c, '%s.proj_%d' % (p, k), layers[i]), w, None, stride=f, padding=f // 2, groups=w.shape[0]))
-        layers[i] = dcn_bn_relu(c, '%s.node_%d' % (p, k), c.rnd(up + layers[i - 1]))
+        proj = dcn_bn_relu(c, '%s.proj_%d' % (p, k), layers[i])
+        up = c.rnd(F.conv_transpose2d(proj, w, None, stride=f, padding=f // 2, groups=w.shape[0]))
+        summed = c.rnd(up + layers[i - 1])
+        c.tap('dwconvT', '%s.up_%d' % (p, k), x=proj, add=layers[i - 1], y=summed, f=f)
+        layers[i] = dcn_bn_relu(c, '%s.node_%d' % (p, k), summed)
 
 
 def dla_seg_upsample(c, p, tensors, first_level=2, last_level=5):
@@ -524,6 +531,7 @@ def km3d_heads(c, feat, heads, p='bbox_head.head_layers'):
     for h in heads:
         x = conv_bn_act(c, feat, '%s.%s.0' % (p, h), None, True)
         out[h] = conv_bn_act(c, x, '%s.%s.2' % (p, h), None, False, padding=0, out_round=False)
+    c.tap('km3d_head', p, x=feat, y=dict(out))
     return out
 
 
@@ -657,11 +665,12 @@ def km3d_resnet_neck(c, p, x):
     return x
 
 
-def km3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False, taps=None):
+def km3d_forward(sd, cfg, img, P2, rnd=identity, return_stages=False, taps=None, stage_taps=None):
     """KM3D.test_forward (detectors/KM3D.py:61-79), B >= 1, with either core of KM3D_core.py: DLA-34 + DLA-Up, or (when the
     state_dict holds ``core.deconv_layers.0.weight``) ResNet + three transposed convolutions.  ``taps``: optional dict that
-    receives (input, output) of every DCNv2 + BN + ReLU block of the up-path, keyed by its state_dict prefix."""
-    c = Ctx(sd, rnd)
+    receives (input, output) of every DCNv2 + BN + ReLU block of the up-path, keyed by its state_dict prefix.  ``stage_taps``: optional
+    list receiving one record per fused operation of the whole path (see ``Ctx``)."""
+    c = Ctx(sd, rnd, stage_taps)
     if taps is not None:
         c.taps = taps
     if c.has('core.deconv_layers.0.weight'):

@@ -7,6 +7,9 @@ import os
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from visualdet3d_amd import build as _build  # noqa: E402
+
 CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small', 'conv_pw')
 
 
@@ -36,6 +39,8 @@ wk = sum(v for k, (n, v) in write.items() if any(c in k for c in CONV))
 rows = {k[:110]: {'dispatches': n, 'fetch_kb': v, 'write_kb': write.get(k, (0, 0.0))[1]} for k, (n, v) in fetch.items() if any(c in k for c in CONV)}
 out = {
     'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline`',
+    # which kernels were measured: hash of the convolution family's sources (bench.py marks the record stale when it moves)
+    'conv_sources': list(_build.CONV_SOURCES), 'conv_sources_sha16': _build.source_hash(_build.CONV_SOURCES), 'library_sources_sha16': _build.source_hash(),
     'forwards': forwards, 'conv_fetch_kb_sum': fk, 'conv_write_kb_sum': wk, 'fetch_correction': 2.0,
     'note': 'gfx950: FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM section); '
             'WRITE_SIZE is 1:1. Counters are in KB (x1024).',

@@ -84,6 +84,7 @@ class HeadParams(C.Structure):
 SIGNATURES = {
     'vd3d_abi_version': (c_int, []),
     'vd3d_last_error': (C.c_char_p, []),
+    'vd3d_source_hash': (C.c_char_p, []),
     'vd3d_conv2d_igemm': (c_int, [C.POINTER(ConvParams), c_void_p]),
     'vd3d_conv2d_production_tiles': (c_int, [c_void_p, c_int]),
     'vd3d_conv2d_workspace_bytes': (c_int64, [C.POINTER(ConvParams)]),

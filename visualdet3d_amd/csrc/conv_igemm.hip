@@ -505,7 +505,7 @@ VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const
 // tiles of 128 x 128 for 256 CUs -- run as tiles x splits workgroups over disjoint K ranges + one reduction pass (two launches, no
 // atomics: the partials are added in split order, results do not depend on scheduling).  KS = 0 instantiations compile to the code
 // they were before the parameter existed.
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int KS = 0>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int KS = 0, int STG = 0>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
     constexpr int NW = WARPS_M * WARPS_N;
     constexpr int ES = (int)sizeof(T);
@@ -783,8 +783,15 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
 #pragma unroll
         for (int g = 0; g < 4; ++g) issue_group(0, g);
         advance_k();
-        issue_group(1, 0, nk_l > 1);
-        issue_group(1, 1, nk_l > 1);
+        // STG > 0 (experiment, round 4): the two waves of a SIMD (w and w + NW / 2) issue their DMA pieces at DIFFERENT points of the slice
+        // -- behind the barrier both waves of a SIMD are in lock step, so both sat in their DMA bursts (60 - 185 issue cycles per piece, ten
+        // pieces per slice and wave) at the same time and the MFMA pipe idled; the upper half issues all four groups of slice t + 1 at
+        // fragment STG of slice t instead (its stage was freed by the barrier of slice t - 1), the lower half keeps the schedule below
+        const bool hiw = STG > 0 && wave >= NW / 2;
+        if (!hiw) {
+            issue_group(1, 0, nk_l > 1);
+            issue_group(1, 1, nk_l > 1);
+        }
         write_ltab();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -818,7 +825,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     // DMA of slice t+2: half of it here, the rest at the top of the next slice -- everything is in flight
                     // within the first tenth of a slice, i.e. has ~0.9 slice times to land before its barrier (PMC: with
                     // the pieces spread evenly over the slice a third of the wave cycles were spent parked at that barrier)
-                    if constexpr (ABL < 4) { issue_group(st, 0, more2); issue_group(st, 1, more2); }
+                    if constexpr (ABL < 4) {
+                        if (!hiw) { issue_group(st, 0, more2); issue_group(st, 1, more2); }
+                    }
                 }
                 if ((i == 0 && ks < NSUB - 1) || f == F0) {
                     // pixel fragments of the next sub-step (past the last slice they read a dead stage; never consumed)
@@ -830,8 +839,17 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
                 }
                 if (i == 0 && ks == 0) {
-                    if constexpr (ABL < 4) { issue_group(st ^ 1, 2, more1); issue_group(st ^ 1, 3, more1); }
-                    advance_k();
+                    if (!hiw) {
+                        if constexpr (ABL < 4) { issue_group(st ^ 1, 2, more1); issue_group(st ^ 1, 3, more1); }
+                        advance_k();
+                    }
+                }
+                if constexpr (STG > 0) {
+                    if (f == STG && hiw) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) issue_group(st ^ 1, g4, more1);
+                        advance_k();
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < TM; ++j) MmaShape<T, MS>::run(fa[f % R], fb[ks & 1][j], acc[i][j]);
@@ -1158,7 +1176,7 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_halo");
 }
 
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int STG = 0>
 int launch(ConvArgs& a, hipStream_t stream) {
     constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int LDS = 2 * (BM + BN) * 128 + (HEADF ? 16384 + 1024 + 128 : (DMA ? 2 * BN * 4 : 0));    // + fused head: W2 fragments and biases; DMA tiles: scale | shift table
@@ -1166,7 +1184,7 @@ int launch(ConvArgs& a, hipStream_t stream) {
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static Vd3dLdsLimit lim;
     void (*kern)(const ConvArgs);
-    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL, HEADF>;
+    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL, HEADF, 0, STG>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_igemm)")) return rc;
     const int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
@@ -1404,6 +1422,10 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 95: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 5>(a, stream));
         case 96: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 6>(a, stream));
         case 97: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 7>(a, stream));
+        // staggered DMA issue of the two waves of a SIMD (STG = the fragment at which the upper half issues)
+        case 55: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 4>(a, stream));
+        case 56: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 8>(a, stream));
+        case 57: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 4>(a, stream));
         case 74: VD3D_BF16_ONLY(launch<T, 64, 144, 2, 1, true, true, 16>(a, stream));
         case 75: VD3D_BF16_ONLY(launch<T, 128, 288, 2, 2, true, true, 16>(a, stream));
         case 71: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream));
@@ -1429,8 +1451,10 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
             a.wide_store && !a.out_f32)
             return launch_resident64(a, stream, fmt);
     }
-    // low-parallelism shapes with a deep K (batch-1 calls: 1408 -> 1408 at 24 x 80 is 165 tiles for 512 workgroup slots): split-K
-    if (g_force_cfg == 0 && a.ks_ws) {
+    // low-parallelism shapes with a deep K (batch-1 calls: 1408 -> 1408 at 24 x 80 is 165 tiles for 512 workgroup slots): split-K.
+    // 16-bit formats only: the split changes the fp32 summation order with the tile count, i.e. with the batch size -- fp32 is the
+    // validation mode, whose results must not depend on how many frames share a call (tests: batch-1 == slice of the batched call)
+    if (g_force_cfg == 0 && a.ks_ws && sizeof(T) == 2) {
         const SplitPlan pl = plan_splitk(a, false);
         if (pl.splits >= 2 && a.ks_ws_bytes >= pl.ws_bytes) return dispatch_splitk<T>(a, stream, pl);
     }
@@ -1630,6 +1654,8 @@ extern "C" int64_t vd3d_conv2d_workspace_bytes(const vd3d_conv_params* p) {
         if ((a.Cin == 128 && regw_shape_ok(a)) || ksplit_shape_ok(a) || small_shape_ok(a) || narrow_shape_ok(a) || pw_shape_ok(a) ||
             (a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.wide_store && !a.out_f32))
             return 0;
+    } else {
+        return 0;                                   // fp32 never splits under natural dispatch (see dispatch())
     }
     return plan_splitk(a, false).ws_bytes;
 }

@@ -12,19 +12,25 @@
 
 namespace {
 
-constexpr int kTPY = 8, kTPX = 16;                 // pooled tile
-constexpr int kCY = 2 * kTPY + 1, kCX = 2 * kTPX + 1;   // conv outputs needed: 17 x 33
-constexpr int kNQ = kCY * kCX;                     // 561
-constexpr int kNBLK = (kNQ + 31) / 32;             // 18 blocks of 32 conv pixels
-constexpr int kIR = 2 * (kCY - 1) + 7;             // 39 packed rows
-constexpr int kCPR = (2 * (kCX - 1) + 8) / 2;      // 36 16-byte chunks (2 NHWC4 pixels) per packed row
-constexpr int kChunks = kIR * kCPR;                // 1404
-constexpr int kPieces = (kChunks + 63) / 64;       // 22 DMA pieces of 1 KiB
-constexpr int kInStage = kPieces * 1024;
-constexpr int kInStages = 3;
-constexpr int kStaging = kNBLK * 32 * 128;         // conv outputs: one 128-byte row (64 bf16) per conv pixel
-constexpr int kLds = kInStages * kInStage + kStaging + 512;
+constexpr int kTPX = 16;                           // pooled tile width
 constexpr uint32_t kOOB = 0x80000000u;
+// Tile geometry for a pooled tile of TPY x 16 pixels.  TPY = 8, 8 waves: the LDS-DMA (packed-image) variant, one workgroup per CU.
+// TPY = 4, 4 waves (round 4 experiment, opt-in VD3D_STEM_WG4=1): 51 KB of LDS, 180 VGPRs -> TWO independent workgroups per CU, so that one
+// workgroup's epilogue / pool phase could run under the other's MFMAs.  Measured slower (launch_stem below).
+template <int TPY>
+struct StemGeo {
+    static constexpr int kTPY = TPY;
+    static constexpr int kCY = 2 * TPY + 1, kCX = 2 * kTPX + 1;   // conv outputs needed: 17 x 33 (9 x 33)
+    static constexpr int kNQ = kCY * kCX;                         // 561 (297)
+    static constexpr int kNBLK = (kNQ + 31) / 32;                 // 18 (10) blocks of 32 conv pixels
+    static constexpr int kIR = 2 * (kCY - 1) + 7;                 // 39 (23) packed rows
+    static constexpr int kCPR = (2 * (kCX - 1) + 8) / 2;          // 36 16-byte chunks (2 NHWC4 pixels) per packed row
+    static constexpr int kChunks = kIR * kCPR;                    // 1404 (828)
+    static constexpr int kPieces = (kChunks + 63) / 64;           // 22 (13) pieces of 1 KiB
+    static constexpr int kInStage = kPieces * 1024;
+    static constexpr int kStaging = kNQ * 128;                    // conv outputs: one 128-byte row (64 bf16) per conv pixel
+};
+template <int TPY, bool F32IN> constexpr int stem_lds_bytes() { return (F32IN ? 1 : 3) * StemGeo<TPY>::kInStage + StemGeo<TPY>::kStaging + 512; }
 
 struct StemArgs {
     const float* img0; const float* img1; int B0;     // F32IN: the fp32 NCHW image(s): batch entries [0, B0) from img0, [B0, B) from img1
@@ -42,9 +48,14 @@ struct StemArgs {
 // F32IN: the patch comes straight from the fp32 NCHW image (the reference's network input) -- converted to the NHWC4 16-bit LDS image
 // in registers, one tile ahead -- instead of by LDS-DMA from a packed copy: the two pack_image launches (2 x 17 us, 94 MB read + 64 MB
 // written + 64 MB re-read per step) disappear.
-template <bool F32IN>
-__global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
-    constexpr int NW = 8, HP = 3;
+template <bool F32IN, int TPY = 8, int NW = 8>
+__global__ void __launch_bounds__(NW * 64) stem_pool_kernel(const StemArgs p) {
+    using G = StemGeo<TPY>;
+    constexpr int kTPY = G::kTPY, kCX = G::kCX, kNQ = G::kNQ, kNBLK = G::kNBLK, kCPR = G::kCPR, kChunks = G::kChunks, kPieces = G::kPieces;
+    constexpr int kInStage = G::kInStage, kStaging = G::kStaging;
+    constexpr int kInStages = F32IN ? 1 : 3;       // fp32 image: the next patch is written after this tile's conv phase -- one stage
+    constexpr int NT = NW * 64, WMI = NW / 2;      // waves = 2 channel halves x WMI block lanes
+    constexpr int HP = (kPieces * 64 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* stg = smem + kInStages * kInStage;
     float* ss = (float*)(stg + kStaging);
@@ -96,7 +107,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(base + d_piece[it] * 1024), 16, off, 0, 0, 0);
         }
     };
-    // F32IN: chunk c = tid + 512 it (two NHWC4 pixels) of the patch <- 6 floats of the three image planes, prefetched into registers
+    // F32IN: chunk c = tid + NT it (two NHWC4 pixels) of the patch <- 6 floats of the three image planes, prefetched into registers
     float pre[HP][6];
     typedef f32x2 __attribute__((aligned(4))) f32x2_u;       // a pixel pair starts at an odd x: 4-byte aligned 8-byte loads
     auto load_patch = [&](int t) {
@@ -111,7 +122,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
         for (int it = 0; it < HP; ++it) {
             // UNCONDITIONAL loads (a border pixel pair is fetched from the clamped position and shifted / zeroed afterwards): no
             // exec-masked branches in front of the MFMA phase, three 8-byte loads per chunk, lanes = consecutive pixel pairs
-            const int c = tid + 512 * it;
+            const int c = tid + NT * it;
             const int cc = c < kChunks ? c : kChunks - 1;
             const int r = cc / kCPR, j = cc - r * kCPR;
             const int y = y0 + r, x = x0 + 2 * j;
@@ -134,7 +145,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
         char* base = smem + stage * kInStage;
 #pragma unroll
         for (int it = 0; it < HP; ++it) {
-            const int c = tid + 512 * it;
+            const int c = tid + NT * it;
             if (c < kPieces * 64) {       // the tail of the last 1 KiB piece is written too (zeros), like the DMA did
                 i32x4 o;
                 o[0] = Fmt16<short>::pack2(pre[it][0], pre[it][2]);
@@ -146,17 +157,16 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
         }
     };
     // conv pixel q of block blk for this lane; fragment byte = ((2cy + ky)*36 + cx + 2ks + half)*16
-    constexpr int MAXB = (kNBLK + 3) / 4;
-    int q_of[MAXB], fbase[MAXB], cy_of[MAXB], cx_of[MAXB];
+    constexpr int MAXB = (kNBLK + WMI - 1) / WMI;
+    // (only the fragment base lives across tiles: the pixel's (cy, cx) is re-derived in the epilogue -- a constant division -- instead of
+    // three more arrays held through the MFMA phase: the 4-wave variant must fit 168 registers for three waves per SIMD)
+    int fbase[MAXB];
 #pragma unroll
     for (int i = 0; i < MAXB; ++i) {
-        const int blk = wmi + 4 * i;
-        const int q = blk * 32 + lr;
+        const int q = (wmi + WMI * i) * 32 + lr;
         const int qc = q < kNQ ? q : kNQ - 1;
-        cy_of[i] = qc / kCX;
-        cx_of[i] = qc - cy_of[i] * kCX;
-        q_of[i] = q;
-        fbase[i] = ((2 * cy_of[i]) * kCPR + cx_of[i] + half) * 16;
+        const int cy = qc / kCX, cx = qc - cy * kCX;
+        fbase[i] = ((2 * cy) * kCPR + cx + half) * 16;
     }
 
     const int nwg = gridDim.x;
@@ -192,7 +202,7 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
         // ---- conv phase --------------------------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < MAXB; ++i) {
-            if (wmi + 4 * i < kNBLK) {                 // wave-uniform
+            if (wmi + WMI * i < kNBLK) {               // wave-uniform
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -201,8 +211,9 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
                     const i32x4 frag = *(const i32x4*)(in_s + fbase[i] + ((f >> 1) * kCPR + 2 * (f & 1)) * 16);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[f]), __builtin_bit_cast(bf16x8, frag), acc, 0, 0, 0);
                 }
-                const int q = q_of[i];
-                const bool qv = q < kNQ && (unsigned)(cy0 + cy_of[i]) < (unsigned)p.Ho && (unsigned)(cx0 + cx_of[i]) < (unsigned)p.Wo;
+                const int q = (wmi + WMI * i) * 32 + lr;
+                const int qcy = q / kCX, qcx = q - qcy * kCX;
+                const bool qv = q < kNQ && (unsigned)(cy0 + qcy) < (unsigned)p.Ho && (unsigned)(cx0 + qcx) < (unsigned)p.Wo;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int nb = wn * 32 + 8 * g + 4 * half;
@@ -218,18 +229,19 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
                     i32x2 o;
                     o[0] = (int)((uint32_t)(uint16_t)f2bf(v[0]) | ((uint32_t)(uint16_t)f2bf(v[1]) << 16));
                     o[1] = (int)((uint32_t)(uint16_t)f2bf(v[2]) | ((uint32_t)(uint16_t)f2bf(v[3]) << 16));
-                    *(i32x2*)(stg + q * 128 + (((wn * 4 + g) ^ (q & 7)) << 4) + half * 8) = o;
+                    if (q < kNQ) *(i32x2*)(stg + q * 128 + (((wn * 4 + g) ^ (q & 7)) << 4) + half * 8) = o;     // (staging holds exactly kNQ rows)
                 }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // ---- pool phase: item = (pooled pixel, 8-channel slot); 1024 items / 512 threads -------------------------
+        // ---- pool phase: item = (pooled pixel, 8-channel slot); TPY * 16 * 8 items / NT threads -----------------------
         typedef __attribute__((ext_vector_type(8))) short s16x8;
+        static_assert((kTPY * kTPX * 8) % NT == 0, "pool items per thread");
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int item = pass * 512 + tid;
+        for (int pass = 0; pass < kTPY * kTPX * 8 / NT; ++pass) {
+            const int item = pass * NT + tid;
             const int pp = item >> 3, s = item & 7;
             const int ly = pp >> 4, lx = pp & 15;
             s16x8 m;
@@ -245,32 +257,42 @@ __global__ void __launch_bounds__(512) stem_pool_kernel(const StemArgs p) {
             *(s16x8*)(p.out + (pix * p.out_pix_stride + s * 8) * 2) = m;
         }
         stage = stage + 1 == kInStages ? 0 : stage + 1;
-        if constexpr (F32IN) store_patch(stage);     // stage (k+1) % 3 was last read by the conv phase of tile k-2: long done
+        if constexpr (F32IN) store_patch(stage);     // the (single) stage was last read by this tile's conv phase: every wave is past the barrier behind it
     }
 }
 
 }  // namespace
 
-static int launch_stem(StemArgs& a, int B, int H, int W, int Kpad, int out_pix_stride, bool f32in, hipStream_t stream) {
-    a.B = B; a.H = H; a.W = W; a.Hp = H + 6; a.Wp = W + 8; a.Ho = H / 2; a.Wo = W / 2; a.Hq = H / 4; a.Wq = W / 4; a.Kpad = Kpad;
-    a.out_pix_stride = out_pix_stride;
-    a.ntiles = B * (a.Hq / kTPY) * (a.Wq / kTPX);
+template <bool F32IN, int TPY, int NW>
+static int launch_stem_t(StemArgs& a, int wg_per_cu, hipStream_t stream) {
+    constexpr int LDS = stem_lds_bytes<TPY, F32IN>();
+    a.ntiles = a.B * (a.Hq / TPY) * (a.Wq / kTPX);
     const int num_cu = vd3d_device_cu_count();
     if (num_cu <= 0) return VD3D_ELAUNCH;
-    const int grid = a.ntiles < num_cu ? a.ntiles : num_cu;
-    static Vd3dLdsLimit lim0, lim1;
-    if (f32in) {
-        if (const int rc = vd3d_raise_lds_limit((const void*)stem_pool_kernel<true>, kLds, lim1, "hipFuncSetAttribute(stem_pool)")) return rc;
-        hipLaunchKernelGGL(stem_pool_kernel<true>, dim3(grid), dim3(512), kLds, stream, a);
-    } else {
-        if (const int rc = vd3d_raise_lds_limit((const void*)stem_pool_kernel<false>, kLds, lim0, "hipFuncSetAttribute(stem_pool)")) return rc;
-        hipLaunchKernelGGL(stem_pool_kernel<false>, dim3(grid), dim3(512), kLds, stream, a);
-    }
+    const int slots = num_cu * wg_per_cu;
+    const int grid = a.ntiles < slots ? a.ntiles : slots;
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)stem_pool_kernel<F32IN, TPY, NW>, LDS, lim, "hipFuncSetAttribute(stem_pool)")) return rc;
+    hipLaunchKernelGGL((stem_pool_kernel<F32IN, TPY, NW>), dim3(grid), dim3(NW * 64), LDS, stream, a);
     return vd3d_check_launch("stem_conv_pool");
 }
 
+static int launch_stem(StemArgs& a, int B, int H, int W, int Kpad, int out_pix_stride, bool f32in, hipStream_t stream) {
+    a.B = B; a.H = H; a.W = W; a.Hp = H + 6; a.Wp = W + 8; a.Ho = H / 2; a.Wo = W / 2; a.Hq = H / 4; a.Wq = W / 4; a.Kpad = Kpad;
+    a.out_pix_stride = out_pix_stride;
+    if (!f32in) return launch_stem_t<false, 8, 8>(a, 1, stream);
+    // VD3D_STEM_WG4=1 (round-4 experiment, same arithmetic, bit-identical): 4 x 16 pooled tiles, four waves, TWO independent workgroups per CU
+    // (180 VGPRs; a third needs <= 168 and spills 13).  MEASURED SLOWER: 105.7 - 121 us against 99.8 - 109 us for the 8 x 16 / eight-wave /
+    // one-per-CU kernel (16 x 3 x 384 x 1280, same box) -- the stem is not held back by its waves running in lock step: per 8 x 16 tile it
+    // issues ~4.0k cycles of MFMA per SIMD (K padded 21 -> 32 per kernel row), ~2.9k of epilogue VALU (BN, ReLU, round on 561 x 64 values)
+    // and ~3.7k of LDS traffic (504 KB of fragment reads, 72 KB parked, 147 KB of pool reads), and the smaller tile adds 6 % MFMA work and
+    // 18 % patch bytes for the same eight waves per CU.
+    if (vd3d_switch(VD3D_SW_STEM_WG4)) return launch_stem_t<true, 4, 4>(a, 2, stream);
+    return launch_stem_t<true, 8, 8>(a, 1, stream);
+}
+
 static bool stem_shape_ok(int B, int H, int W, int Kpad, int out_pix_stride) {
-    return B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && (H / 4) % kTPY == 0 && (W / 4) % kTPX == 0 && Kpad >= 224 && out_pix_stride >= 64 &&
+    return B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0 && (H / 4) % 8 == 0 && (W / 4) % kTPX == 0 && Kpad >= 224 && out_pix_stride >= 64 &&
            out_pix_stride % 8 == 0;
 }
 
