@@ -385,3 +385,31 @@ def test_level_pair_kernel_is_bit_identical_to_two_launches(dtype, B, H, W, Cb):
     torch.cuda.synchronize()
     assert got.shape == want.shape
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('shape', [(8, 24, 80, 1408, 1408), (8, 24, 80, 1152, 1152), (3, 17, 41, 1408, 1408), (2, 18, 80, 2176, 2176)],
+                         ids=['c2 head', 'c2 neck', 'ragged', 'c3 head'])
+def test_staggered_dma_schedule_of_the_strips_is_bit_identical(shape, dtype):
+    """The 352 / 288 column strips issue their LDS-DMA pieces on two schedules (waves 0-3 right behind the slice's barrier, waves 4-7 at a
+    later fragment: conv_igemm.hip launch_strip352 / launch_strip288); VD3D_CONV_NO_STAGGER=1 puts every wave on the first.  Where a piece
+    is issued changes nothing about what is computed: same operands, same k order -> the outputs are BIT-IDENTICAL (a piece that
+    did not land before its barrier would show here)."""
+    from visualdet3d_amd import _lib, hip_ops as ops
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(Cin + H)
+    x = torch.randn(B, H, W, Cin, generator=g).cuda().to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+    res = torch.randn(B, H, W, Cout, generator=g).cuda().to(dtype)
+    pc = ops.pack_conv(w, None, None, dtype, 1, 1, 1)
+    outs = []
+    for tile in (50, 54):
+        with forced_tile(tile):
+            a = ops.conv2d(x, pc, residual=res, relu=True)
+            with _lib.test_switch('VD3D_CONV_NO_STAGGER'):
+                b = ops.conv2d(x, pc, residual=res, relu=True)
+            for _ in range(3):                                    # run to run as well
+                assert torch.equal(ops.conv2d(x, pc, residual=res, relu=True).view(torch.int16), a.view(torch.int16))
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16)), 'tile %d: staggered schedule differs (max %.3e)' % (tile, (a.float() - b.float()).abs().max().item())
+        outs.append(a)

@@ -234,6 +234,10 @@ def test_fused_head_matches_unfused():
             fused_maps = head2.forward_nhwc(x)
             with _lib.test_switch('VD3D_HEAD_PARKED'):
                 parked_maps = head2.forward_nhwc(x)
+            with _lib.test_switch('VD3D_HEAD_NO_STAGGER'):          # every wave on one DMA schedule: same arithmetic, bit-identical
+                plain_maps = head2.forward_nhwc(x)
+            for k in fused_maps:
+                assert torch.equal(fused_maps[k], plain_maps[k]), (k, shape, dt)
             head2.fuse_head = False
             ref_maps = head2.forward_nhwc(x)
         for k in ref_maps:

@@ -787,7 +787,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         // -- behind the barrier both waves of a SIMD are in lock step, so both sat in their DMA bursts (60 - 185 issue cycles per piece, ten
         // pieces per slice and wave) at the same time and the MFMA pipe idled; the upper half issues all four groups of slice t + 1 at
         // fragment STG of slice t instead (its stage was freed by the barrier of slice t - 1), the lower half keeps the schedule below
-        const bool hiw = STG > 0 && wave >= NW / 2;
+        // STG < 100: two phases (upper half at fragment STG); STG = 100 + d: FOUR phases -- wave pairs (0,1) (2,3) (4,5) (6,7) at the base
+        // schedule, d, 2d, 3d: SIMD mates (w, w + 4) are 2d fragments apart and the CU's texture path sees four bursts of 20 pieces
+        const int ph = STG >= 100 ? (wave >> 1) : (STG > 0 && wave >= NW / 2 ? 1 : 0);
+        const bool hiw = ph != 0;
         if (!hiw) {
             issue_group(1, 0, nk_l > 1);
             issue_group(1, 1, nk_l > 1);
@@ -845,11 +848,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     }
                 }
                 if constexpr (STG > 0) {
-                    if (f == STG && hiw) {
+                    constexpr int NPH = STG >= 100 ? 4 : 2, DPH = STG >= 100 ? STG - 100 : STG;
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) issue_group(st ^ 1, g4, more1);
-                        advance_k();
-                    }
+                    for (int k = 1; k < NPH; ++k)
+                        if (f == k * DPH && ph == k) {
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) issue_group(st ^ 1, g4, more1);
+                            advance_k();
+                        }
                 }
 #pragma unroll
                 for (int j = 0; j < TM; ++j) MmaShape<T, MS>::run(fa[f % R], fb[ks & 1][j], acc[i][j]);
@@ -1314,6 +1320,25 @@ int dispatch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
     return launch_splitk<T, 128, 2, 2, true>(a, stream, pl);
 }
 
+// The 16x16x32 column strips with the STAGGERED DMA schedule (round 4; STG template parameter of conv_igemm_dma_kernel): waves 4-7 issue all
+// ten pieces of slice t + 1 at fragment 8 (352 strip: 22 fragments per slice, barrier at 20) / 5 (288 strip with its ring of six: 18
+// fragments, barrier at 12) of slice t while waves 0-3 keep the schedule "half right behind the barrier, half at the top of the next
+// slice" -- SIMD mates no longer sit in their DMA bursts at the same time.  Same k order: bit-identical results.  Measured, same box,
+// round-robin (tools/bench_conv.py): 1408 -> 1408 1315-1373 -> 1413 TF/s (STG 6 / 7 / 8 / 12: 1389-1401 / 1408-1412 / 1413-1425 / 1322-1357),
+// 2176 -> 2176 on the 352 strip 1098-1109 -> 1168-1179; 1152 -> 1152 on the 288 strip 1352 -> 1363-1365 (STG 3 / 4 / 5 / 8: 1350 / 1354-1359 /
+// 1363-1365 / 1304-1310).  Four phases (wave pairs at 0 / d / 2d / 3d) are 10-25 % SLOWER: a piece issued 8 fragments before the barrier does not
+// land in time.  VD3D_CONV_NO_STAGGER=1: every wave on the old schedule (A/B).
+template <typename T>
+int launch_strip352(ConvArgs& a, hipStream_t stream) {
+    if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER)) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream);
+    return launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 8>(a, stream);
+}
+template <typename T>
+int launch_strip288(ConvArgs& a, hipStream_t stream) {
+    if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER)) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream);
+    return launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 5>(a, stream);
+}
+
 // Tile override: 0 = heuristic, otherwise a config id (vd3d_test_force_conv_tile, csrc/test_hooks.h: a TEST hook, thread-local,
 // not declared in include/vd3d.h).  The PRODUCT build only knows the ids of the
 // tiles the heuristic below can pick (tests/test_conv_tiles_gpu.py forces each of them on awkward shapes and compares with
@@ -1343,8 +1368,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 42: return launch<T, 256, 256, 2, 4, true, true>(a, stream);
         case 40: return launch<T, 256, 352, 8, 1, true, true>(a, stream);
         case 41: return launch<T, 256, 288, 8, 1, true, true>(a, stream);
-        case 50: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16>(a, stream));
-        case 54: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream));
+        case 50: VD3D_BF16_ONLY(launch_strip352<T>(a, stream));
+        case 54: VD3D_BF16_ONLY(launch_strip288<T>(a, stream));
         case 12: return launch<T, 128, 352, 4, 1, true>(a, stream);
         case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 76: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16>(a, stream));
@@ -1423,9 +1448,16 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 96: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 6>(a, stream));
         case 97: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 7>(a, stream));
         // staggered DMA issue of the two waves of a SIMD (STG = the fragment at which the upper half issues)
-        case 55: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 4>(a, stream));
+        case 55: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 7>(a, stream));
         case 56: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 8>(a, stream));
         case 57: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 4>(a, stream));
+        case 31: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 6>(a, stream));
+        case 35: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 10>(a, stream));
+        case 36: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 3>(a, stream));
+        case 37: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 5>(a, stream));
+        case 32: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 104>(a, stream));
+        case 33: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 105>(a, stream));
+        case 34: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 103>(a, stream));
         case 74: VD3D_BF16_ONLY(launch<T, 64, 144, 2, 1, true, true, 16>(a, stream));
         case 75: VD3D_BF16_ONLY(launch<T, 128, 288, 2, 2, true, true, 16>(a, stream));
         case 71: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream));
@@ -1534,10 +1566,10 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         // strips: bf16 uses 16x16x32 MFMAs so that a wave owns 64 pixels x half the strip (0.68 KB of fragment reads per
         // 32x32x16-equivalent instead of 1.09 for 32 x the whole strip): +11 % (352) / +8 % (288) measured
         case 2:
-            if constexpr (sizeof(T) == 2) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream);
+            if constexpr (sizeof(T) == 2) return launch_strip352<T>(a, stream);
             else return launch<T, 256, 352, 8, 1, true, true>(a, stream);
         case 3:
-            if constexpr (sizeof(T) == 2) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream);   // ring of 6: +4 % over 2
+            if constexpr (sizeof(T) == 2) return launch_strip288<T>(a, stream);   // ring of 6: +4 % over 2
             else return launch<T, 256, 288, 8, 1, true, true>(a, stream);
         case 4: return launch<T, 128, 352, 4, 1, true>(a, stream);
         case 5:     // bf16: 8 waves of 32 x 144 on 16x16x32 MFMAs (+20 % over 128x192 tiles on the 1408 -> 576 reg output conv)

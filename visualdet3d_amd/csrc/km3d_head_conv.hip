@@ -25,7 +25,11 @@ constexpr int kW2 = 2 * kStage, kB1 = kW2 + 16384, kB2 = kB1 + 1024;    // W2 im
 constexpr int kMeet = kStage, kOut = kStage + 32768;                    // (inside stage 1, free between two tiles)
 constexpr int kHeadLds = kB2 + 256;
 
-template <typename T>
+// STG > 0 (round 4): the two waves of a SIMD (w and w + 4) issue their DMA pieces at different points of a slice -- the lower four as before
+// (half right behind the slice's barrier, half at the top of the next slice), the upper four all eight pieces of slice t + 1 at fragment STG of
+// slice t: behind the barrier SIMD mates run in lock step, so both sat in their DMA bursts (60 - 185 issue cycles per piece) at the same time
+// with the MFMA pipe idle (conv_igemm.hip, same idea on the 352 strips: +3.6 %).  Results do not depend on STG (same k order).
+template <typename T, int STG>
 __global__ void __launch_bounds__(kNW * 64) km3d_head_kernel(const ConvArgs p) {
     constexpr int TM = 2, TN = 4, NSUB = 4, WTM = 64, WTN = 128, A_PIECES = 4, NPIECE = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -140,10 +144,13 @@ __global__ void __launch_bounds__(kNW * 64) km3d_head_kernel(const ConvArgs p) {
     write_hd(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const bool hiw = STG > 0 && wave >= kNW / 2;
     for (;;) {
         // slice 0 has landed for everybody and the head constants are in LDS; half of slice 1 now, the rest inside slice 0
-        issue_group(1, 0, p.nk > 1);
-        issue_group(1, 1, p.nk > 1);
+        if (!hiw) {
+            issue_group(1, 0, p.nk > 1);
+            issue_group(1, 1, p.nk > 1);
+        }
         f32x16 acc[TN][TM];
         {
             // one LDS read per accumulator quad, as volatile asm (the two pixel blocks read the same four biases separately, which the
@@ -181,8 +188,10 @@ __global__ void __launch_bounds__(kNW * 64) km3d_head_kernel(const ConvArgs p) {
                         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         asm volatile("" ::: "memory");
-                        issue_group(st, 0, more2);
-                        issue_group(st, 1, more2);
+                        if (!hiw) {
+                            issue_group(st, 0, more2);
+                            issue_group(st, 1, more2);
+                        }
                     }
                     if ((i == 0 && ks < NSUB - 1) || f == F0) {
                         const int k2 = f == F0 ? NSUB - 1 : ks;
@@ -191,9 +200,19 @@ __global__ void __launch_bounds__(kNW * 64) km3d_head_kernel(const ConvArgs p) {
                         __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
                     }
                     if (i == 0 && ks == 0) {
-                        issue_group(st ^ 1, 2, more1);
-                        issue_group(st ^ 1, 3, more1);
-                        advance_k();
+                        if (!hiw) {
+                            issue_group(st ^ 1, 2, more1);
+                            issue_group(st ^ 1, 3, more1);
+                            advance_k();
+                        }
+                    }
+                    if constexpr (STG > 0) {
+                        // (no pieces at all past the last slice: stage 1 is where the partial sums of the epilogue meet)
+                        if (f == STG && hiw && more1) {
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; ++g4) issue_group(st ^ 1, g4, true);
+                            advance_k();
+                        }
                     }
 #pragma unroll
                     for (int j = 0; j < TM; ++j) Fmt16<T>::mfma32(fa[f % R], fb[ks & 1][j], acc[i][j]);
@@ -312,14 +331,19 @@ int launch_km3d_head(ConvArgs& a, hipStream_t stream, int fmt) {
     const int cus = vd3d_device_cu_count();
     if (cus <= 0) return VD3D_ELAUNCH;
     const int grid = total < cus ? (int)total : cus;
-    static Vd3dLdsLimit lim16, limbf;
-    if (fmt == VD3D_F16) {
-        if (const int rc = vd3d_raise_lds_limit((const void*)km3d_head_kernel<hf16>, kHeadLds, lim16, "hipFuncSetAttribute(km3d_head)")) return rc;
-        hipLaunchKernelGGL(km3d_head_kernel<hf16>, dim3(grid), dim3(kNW * 64), kHeadLds, stream, a);
-    } else {
-        if (const int rc = vd3d_raise_lds_limit((const void*)km3d_head_kernel<short>, kHeadLds, limbf, "hipFuncSetAttribute(km3d_head)")) return rc;
-        hipLaunchKernelGGL(km3d_head_kernel<short>, dim3(grid), dim3(kNW * 64), kHeadLds, stream, a);
-    }
+    // VD3D_HEAD_NO_STAGGER=1: every wave on the same DMA schedule (A/B; bit-identical results)
+    const bool stg = !vd3d_switch(VD3D_SW_HEAD_NO_STAGGER);
+    auto go = [&](auto kern, Vd3dLdsLimit& lim) -> int {
+        if (const int rc = vd3d_raise_lds_limit((const void*)kern, kHeadLds, lim, "hipFuncSetAttribute(km3d_head)")) return rc;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kNW * 64), kHeadLds, stream, a);
+        return 0;
+    };
+    static Vd3dLdsLimit lim[4];
+    constexpr int kStg = 5;
+    int rc;
+    if (fmt == VD3D_F16) rc = stg ? go(km3d_head_kernel<hf16, kStg>, lim[0]) : go(km3d_head_kernel<hf16, 0>, lim[1]);
+    else rc = stg ? go(km3d_head_kernel<short, kStg>, lim[2]) : go(km3d_head_kernel<short, 0>, lim[3]);
+    if (rc) return rc;
     return vd3d_check_launch("km3d_head");
 }
 
