@@ -246,6 +246,30 @@ def test_window_kernel_is_bit_identical_to_the_global_gather_kernel(dtype, B, H,
     with _lib.test_switch('VD3D_DCN_WINDOW'):                     # opt-in kernel (measured slower than the gather kernel: not the default)
         a = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], buf[..., 64:], 'nhwc', **kw)
     b = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
+    # round-4 kernels, both opt-in: VD3D_DCN_BF=1 = dcn_bf64_kernel (8 x 16 tiles, corners from an LDS window, blended B fragments in registers,
+    # no barrier in the K loop; corners outside the window -- sigma 4.0: most of them -- per lane from global memory), VD3D_DCN_LWIN=1 = the gather
+    # kernel with its corners from an LDS window.  `b` above is the all-global gather kernel (the default).  Also from a channel-slice INPUT
+    # view (pixel stride 128 elements) with a ragged tile grid, and into a channel-slice OUTPUT view.
+    gk = b
+    with _lib.test_switch('VD3D_DCN_BF'):
+        bf = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
+    assert torch.equal(bf, gk), 'barrier-free kernel differs from the gather kernel: max diff %.3e at sigma %.1f' % ((bf.float() - gk.float()).abs().max().item(), sigma)
+    with _lib.test_switch('VD3D_DCN_LWIN'):
+        lw = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
+    assert torch.equal(lw, gk), 'lds-window gather kernel differs from the gather kernel'
+    xwide = torch.full((B, H, W, 128), 9.0, dtype=dtype, device='cuda')
+    xwide[..., 64:] = xd
+    for sw in ('VD3D_DCN_BF', 'VD3D_DCN_LWIN'):
+        with _lib.test_switch(sw):
+            bs = ops.deform_conv_general(xwide[..., 64:], pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
+            bo = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
+            ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], bo[..., 64:], 'nhwc', **kw)
+        assert torch.equal(bs, gk), 'window kernels on a channel-slice input view (%s)' % sw
+        assert torch.equal(bo[..., 64:], gk) and bool((bo[..., :64] == 3.0).all()), 'window kernels into a channel-slice output view (%s)' % sw
+    # logits in a layout the coalesced loader of the barrier-free kernel does not take (27 channels, separate mask tensor): its generic path
+    with _lib.test_switch('VD3D_DCN_BF'):
+        bg = ops.deform_conv_general(xd, pd, logits[..., :18].contiguous(), logits[..., 18:27].contiguous(), torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
+    assert torch.equal(bg, gk), 'barrier-free kernel, generic logits layout'
     buf2 = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
     with _lib.test_switch('VD3D_DCN_KSPLIT'):                     # the K-split window kernel: two partial sums added in fp32 -> not bit-identical
         c = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], buf2[..., :64], 'nhwc', **kw)
@@ -292,11 +316,16 @@ def test_opt_in_packed_fp16_blend(C, O, B, H, W):
 
     base = run()
     with _lib.test_switch('VD3D_DCN_PK16'):
-        pk = run()
+        pk = run()                                       # the gather kernel
         if C == 64 and O == 64:
+            gk = pk
+            with _lib.test_switch('VD3D_DCN_BF'):
+                pk = run()
+            with _lib.test_switch('VD3D_DCN_LWIN'):
+                lw = run()
             with _lib.test_switch('VD3D_DCN_WINDOW'):
                 win = run()
-            assert torch.equal(win, pk), 'window kernel differs from the gather kernel under the packed blend'
+            assert torch.equal(gk, pk) and torch.equal(win, pk) and torch.equal(lw, pk), 'the 64 -> 64 kernels differ under the packed blend'
     torch.cuda.synchronize()
     assert not torch.equal(pk, base), 'the switch selected nothing'
     d = (pk.float() - base.float()).abs()
