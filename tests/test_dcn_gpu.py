@@ -336,3 +336,26 @@ def test_opt_in_packed_fp16_blend(C, O, B, H, W):
                                        1, 1, 1, 1, 1, rnd=rnd)
     got = pk.float().cpu().permute(0, 3, 1, 2)
     assert ((got - want).abs().max() / want.abs().max()).item() < 2.5e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('C,O,B,H,W', [(64, 64, 2, 21, 37), (128, 64, 1, 16, 24), (256, 256, 1, 9, 13), (64, 128, 2, 8, 8)])
+def test_logit_staging_of_the_gather_kernel_is_bit_identical(dtype, C, O, B, H, W):
+    """dcn_nhwc_kernel stages the tile's offset / mask logits through LDS with coalesced 16-byte loads when they come in the engine's own
+    layout (32 fp32 per pixel: offsets | mask | pad); VD3D_DCN_NO_LSTAGE=1 reads them lane = pixel from global memory as before.  The same
+    values either way: bit-identical outputs, ragged last tile and all three block widths."""
+    from visualdet3d_amd import _lib, hip_ops as ops
+    g = torch.Generator().manual_seed(C + O + H)
+    x = torch.randn(B, H, W, C, generator=g).cuda().to(dtype)
+    pd = ops.pack_dcn_weight((torch.randn(O, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).cuda(), dtype)
+    logits = (torch.randn(B, H, W, 32, generator=g) * 1.5).cuda()
+    kw = dict(bias=(torch.randn(O, generator=g) * 0.1).cuda(), stride=(1, 1), padding=(1, 1), dilation=(1, 1), mask_sigmoid=True, relu=True)
+
+    def run():
+        return ops.deform_conv_general(x, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
+
+    a = run()
+    with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
+        b = run()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), 'max diff %.3e' % (a.float() - b.float()).abs().max().item()

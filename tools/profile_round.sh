@@ -27,8 +27,12 @@ run trace_serial --kernel-trace --stats -d $OUT/trace_serial -- python $ROOT/ben
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-other-configs
 run pmc_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -- python $ROOT/bench.py --steps 4 --warmup 1 --no-graph --no-cpu-baseline --no-other-configs
 run pmc_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-overlap --no-cpu-baseline --no-other-configs
+VD3D_CONV_NO_STAGGER=1 run pmc_sq_nostg --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_sq_nostg -- python $ROOT/bench.py --steps 3 --warmup 1 --no-graph --no-overlap --no-cpu-baseline --no-other-configs
 run trace_c3 --kernel-trace --stats -d $OUT/trace_c3 -- python $ROOT/tools/bench_configs.py "C3 Stereo3D R50 +"
 run trace_c5 --kernel-trace --stats -d $OUT/trace_c5 -- python $ROOT/tools/bench_configs.py "fp16 (as BASELINE"
+# the reference's own call pattern: one frame per module([...]) call through the hipGraph cache (BASELINE config 1 and the stereo pair at batch 1)
+run trace_b1_mono --kernel-trace --stats -d $OUT/trace_b1_mono -- python $ROOT/tools/bench_b1.py --calls 30 mono
+run trace_b1_stereo --kernel-trace --stats -d $OUT/trace_b1_stereo -- python $ROOT/tools/bench_b1.py --calls 30 stereo
 # config 5's own SQ / traffic passes (DCN and fused-head kernels), eager launches so that every dispatch carries its counters
 run pmc_c5_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_c5_sq -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
 run pmc_c5_valu --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/pmc_c5_valu -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
@@ -43,12 +47,19 @@ grep '^{' $OUT/trace_serial.log | tail -1 > $OUT/${TAG}_serial_bench.json
 grep '^{' $OUT/trace_overlap.log | tail -1 > $OUT/${TAG}_overlap_bench_under_rocprof.json
 python tools/pmc_traffic.py $OUT/pmc_fetch $OUT/pmc_write $OUT/${TAG}_pmc_traffic.json
 python tools/rocpd_pmc_table.py $OUT/pmc_sq conv_ > $OUT/${TAG}_sq_pmc.txt
+python tools/family_busy.py $OUT/${TAG}_sq_pmc.txt > $OUT/${TAG}_family_mfma_busy.txt
+python tools/rocpd_pmc_table.py $OUT/pmc_sq_nostg conv_ > $OUT/${TAG}_sq_pmc_no_stagger.txt
+{ echo "# the same SQ pass with VD3D_CONV_NO_STAGGER=1 (every wave of the 352 / 288 strips on one DMA schedule)"; python tools/family_busy.py $OUT/${TAG}_sq_pmc_no_stagger.txt; } >> $OUT/${TAG}_family_mfma_busy.txt
 { echo "# BASELINE config 5 (KM3D DLA-34, fp16, 16 x 512 x 1760), eager launches: DCN, fused-head (km3d_head_kernel) and level-pair kernels"; echo "## SQ pass"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_sq conv_pair_kernel | tail -n +2;
   echo "## instruction mix"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu conv_pair_kernel | tail -n +2;
   echo "## FETCH_SIZE (x2 for bytes on gfx950: 32-byte units reported as 64)"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch conv_pair_kernel | tail -n +2;
   echo "## WRITE_SIZE"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write conv_pair_kernel | tail -n +2; } > $OUT/${TAG}_c5_pmc.txt 2>&1
 python tools/serial_roofline_check.py $OUT/${TAG}_serial_kernel_stats.csv $OUT/${TAG}_serial_bench.json > $OUT/${TAG}_serial_roofline_check.txt
 cat $OUT/${TAG}_serial_roofline_check.txt
+python tools/rocpd_timeline.py $(db trace_b1_mono) > $OUT/${TAG}_b1_mono_timeline.txt
+python tools/rocpd_timeline.py $(db trace_b1_stereo) > $OUT/${TAG}_b1_stereo_timeline.txt
+grep 'ms per' $OUT/trace_b1_mono.log $OUT/trace_b1_stereo.log > $OUT/${TAG}_b1_under_rocprof.txt
+python tools/bench_b1.py 2>/dev/null | grep 'ms per' > $OUT/${TAG}_b1_calls.txt
 python tools/rocpd_stats.py $(db trace_c3) > $OUT/${TAG}_c3_kernel_stats.csv
 python tools/rocpd_stats.py $(db trace_c5) > $OUT/${TAG}_c5_km3d_kernel_stats.csv
 grep 'img/s' $OUT/trace_c3.log $OUT/trace_c5.log > $OUT/${TAG}_c3_c5_under_rocprof.txt
@@ -56,5 +67,5 @@ python tools/layer_table.py "C3 Stereo3D R50 +" 2>/dev/null | grep -v amdgpu > $
 python tools/layer_table.py "fp16 (as BASELINE" 2>/dev/null | grep -v amdgpu > $OUT/${TAG}_c5_km3d_conv_layers.txt
 python tools/bench_configs.py 2>/dev/null | grep 'img/s' > $OUT/${TAG}_bench_configs.txt
 # the rocpd databases stay on the box (too big); only the summaries travel back
-rm -rf $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5 $OUT/pmc_c5_sq $OUT/pmc_c5_valu $OUT/pmc_c5_fetch $OUT/pmc_c5_write
+rm -rf $OUT/pmc_sq_nostg $OUT/trace_b1_mono $OUT/trace_b1_stereo $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5 $OUT/pmc_c5_sq $OUT/pmc_c5_valu $OUT/pmc_c5_fetch $OUT/pmc_c5_write
 ls -la $OUT

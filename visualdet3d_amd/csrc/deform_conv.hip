@@ -39,6 +39,7 @@ struct DcnArgs {
     int64_t msk_sb, msk_sc, msk_sy, msk_sx;
     int64_t out_sb, out_sc, out_sy, out_sx;
     int mask_sigmoid, relu;
+    int no_lstage = 0;                       // VD3D_DCN_NO_LSTAGE=1: logits read lane = pixel from global memory (A/B; same values)
     int pk16 = 0;                            // fp16, OPT-IN (VD3D_DCN_PK16=1): blend on v_pk_fma_f16 (below); 0 = fp32 blend on v_fma_mix_f32
 };
 
@@ -298,6 +299,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     // and overlap the MFMAs of slice k.
     // a thread owns ONE pixel (lane) and every fourth tap (wave): the pixel's row / column is divided out once and the tap's
     // (ti, tj) is wave-uniform (scalar)
+    // Round 4: the logits in the engine's own layout (one pixel = 32 contiguous fp32: offsets 0..17 | mask 18..26 | pad -- what the offset conv
+    // writes) are STAGED through LDS first: two fully coalesced 16-byte loads per thread (8 lanes = one pixel's 128 bytes) into the first
+    // operand stage (idle until the K loop), rows padded to 33 floats so that the per-pixel reads below are bank-conflict free.  Read from global
+    // memory lane = pixel, every one of the nine 4-byte loads per thread touched 64 different cache lines (timing ablation of the same phase in
+    // dcn_lw64_kernel: 51 of 372 us).  Any other layout (NCHW offsets of the reference's extension entry points, 27-channel tensors) keeps the old path.
+    const bool packed_logits = !p.no_lstage && KK == 9 && p.mask && p.off_sc == 1 && p.msk_sc == 1 && p.mask == p.offset + 18 && p.msk_sb == p.off_sb &&
+                               p.msk_sy == p.off_sy && p.msk_sx == p.off_sx && (p.off_sx & 3) == 0 && (p.off_sy & 3) == 0 && (p.off_sb & 3) == 0 &&
+                               p.off_sx >= 28 && ((uintptr_t)p.offset & 15) == 0;
+    constexpr int LROW = 33;                         // floats per staged pixel row
+    float* lstage = (float*)smem;
+    if (packed_logits) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int spx = (tid >> 3) + 32 * r, v = tid & 7, spix = pix0 + spx;
+            if (spix < HoWo && v < 7) {
+                const int soy = spix / p.Wo, sox = spix - soy * p.Wo;
+                const f32x4 val = *(const f32x4*)(p.offset + b * p.off_sb + soy * p.off_sy + sox * p.off_sx + 4 * v);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) lstage[spx * LROW + 4 * v + c] = val[c];
+            }
+        }
+        __syncthreads();
+    }
     {
     const int px = lane, pix = pix0 + px;
     const int oy = pix / p.Wo, ox = pix - oy * p.Wo;
@@ -314,9 +338,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
             const int tap = t0 + 4 * u;
             oh[u] = ow[u] = ml[u] = 0.f;
             if (tap < KK && pix < HoWo) {
-                oh[u] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
-                ow[u] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
-                if (p.mask) ml[u] = p.mask[mb + (int64_t)tap * p.msk_sc];
+                if (packed_logits) {
+                    oh[u] = lstage[px * LROW + 2 * tap];
+                    ow[u] = lstage[px * LROW + 2 * tap + 1];
+                    ml[u] = lstage[px * LROW + 18 + tap];
+                } else {
+                    oh[u] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
+                    ow[u] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
+                    if (p.mask) ml[u] = p.mask[mb + (int64_t)tap * p.msk_sc];
+                }
             }
         }
 #pragma unroll
@@ -2011,6 +2041,7 @@ int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
     a.msk_sb = q->mask_strides[0]; a.msk_sc = q->mask_strides[1]; a.msk_sy = q->mask_strides[2]; a.msk_sx = q->mask_strides[3];
     a.out_sb = q->out_strides[0]; a.out_sc = q->out_strides[1]; a.out_sy = q->out_strides[2]; a.out_sx = q->out_strides[3];
     a.mask_sigmoid = q->mask_sigmoid; a.relu = q->relu;
+    a.no_lstage = vd3d_switch(VD3D_SW_DCN_NO_LSTAGE) ? 1 : 0;
     a.pk16 = (q->dtype == VD3D_F16 && vd3d_switch(VD3D_SW_DCN_PK16)) ? 1 : 0;      // opt-in: leaves the 2-ulp bar (see dcn_blend8_pk)
     if (a.Ho <= 0 || a.Wo <= 0 || q->B <= 0) { vd3d_set_error("deform_conv: empty output"); return VD3D_EINVAL; }
     // channel-contiguous activations, one group: the NHWC fast path (everything the detectors launch)
