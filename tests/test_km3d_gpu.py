@@ -317,7 +317,9 @@ def test_fp16_mode_config5_at_size_512x1760():
         print('[KM3D fp16 512x1760] %-9s vs fp16-rounded oracle: rms %.2e, max %.2e; max vs fp32 reference golden (4096 samples) %.2e' % (h, rms, eo, eg))
         worst_rms, worst_max = max(worst_rms, rms), max(worst_max, eo)
     # measured: rms 7.7e-3 (reg) ... 2.3e-2 (hm) ... 5.2e-2 (prob: one channel, small dynamic range); max 4.8e-2 ... 1.7e-1
-    assert worst_rms < 8e-2 and worst_max < 0.35, (worst_rms, worst_max)
+    # (bars tightened in round 4 from 8e-2 / 0.35 to 1.25 x / 1.5 x the measured values: every stage of this path is now held to <= 1 ulp teacher-forced
+    # AT SIZE -- tests/test_stage_taps_c5_c3_gpu.py -- so what is left here is the amplification of those flips through 16 DCN layers, a deterministic number)
+    assert worst_rms < 6.5e-2 and worst_max < 0.25, (worst_rms, worst_max)
     s, b, l = [t.cpu() for t in outs[0]]
     ref = (g['f0_scores'], g['f0_boxes'], g['f0_labels'])
     # Detection level.  The keypoint decode (peaks of two heat maps, top-K, keypoint <-> heat-map association with hard thresholds,

@@ -32,7 +32,7 @@ cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
 def skip(c, Cout):
     if c in (61, 68, 69, 28, 29):
         return False
-    return (Cout <= 64 and 1 <= c < 30) or (Cout <= 64 and c >= 36 and c not in (60, 84, 85, 86, 87)) or (Cout > 64 and c in (20, 26, 28, 30, 35)) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 31)
+    return (Cout <= 64 and 1 <= c < 30) or (Cout <= 64 and c >= 31 and c not in (60, 84, 85, 86, 87)) or (Cout > 64 and c in (20, 26, 28, 30, 35)) or (Cout != 256 and c in (23, 24)) or (Cout > 128 and Cout != 256 and 20 <= c < 31)
 
 import os
 if os.environ.get('VD3D_SHAPES'):

@@ -1447,17 +1447,18 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 95: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 5>(a, stream));
         case 96: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 6>(a, stream));
         case 97: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 7>(a, stream));
-        // staggered DMA issue of the two waves of a SIMD (STG = the fragment at which the upper half issues)
+        // staggered DMA issue of the two waves of a SIMD (STG = the fragment at which the upper half issues): sweep variants
+        case 31: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 6>(a, stream));
         case 55: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 7>(a, stream));
         case 56: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 8>(a, stream));
-        case 57: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 4>(a, stream));
-        case 31: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 6>(a, stream));
-        case 35: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 10>(a, stream));
-        case 36: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 3>(a, stream));
-        case 37: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 5>(a, stream));
         case 32: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 104>(a, stream));
-        case 33: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 105>(a, stream));
-        case 34: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 103>(a, stream));
+        case 36: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 2, 0, false, 6>(a, stream));      // 288 strip, ring 2 (barrier at 16 of 18)
+        case 37: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 2, 0, false, 8>(a, stream));
+        case 57: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 3, 0, false, 6>(a, stream));      // ring 3 (barrier at 15)
+        case 34: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 6>(a, stream));      // ring 6 (production: STG 5)
+        case 33: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 5>(a, stream));
+        case 38: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16, 0, 0, false, 6>(a, stream));      // 128 x 288 (1408 -> 576): 18 fragments, barrier at 16
+        case 39: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16, 0, 0, false, 8>(a, stream));
         case 74: VD3D_BF16_ONLY(launch<T, 64, 144, 2, 1, true, true, 16>(a, stream));
         case 75: VD3D_BF16_ONLY(launch<T, 128, 288, 2, 2, true, true, 16>(a, stream));
         case 71: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream));
