@@ -1330,12 +1330,14 @@ int dispatch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
 // land in time.  VD3D_CONV_NO_STAGGER=1: every wave on the old schedule (A/B).
 template <typename T>
 int launch_strip352(ConvArgs& a, hipStream_t stream) {
-    if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER)) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream);
+    if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER) || a.group_m > 0) return launch<T, 256, 352, 4, 2, true, true, 16>(a, stream);
     return launch<T, 256, 352, 4, 2, true, true, 16, 0, 0, false, 8>(a, stream);
 }
 template <typename T>
 int launch_strip288(ConvArgs& a, hipStream_t stream) {
-    if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER)) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream);
+    // (not for the grouped 1x1 GEMMs over an operand streamed from HBM -- config 3's 19 584-deep column GEMM: a later issue point has
+    // HBM latency to cover, 3 344 against 3 206 us)
+    if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER) || a.group_m > 0) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream);
     return launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 5>(a, stream);
 }
 
