@@ -836,7 +836,9 @@ __global__ void __launch_bounds__(256) dcn_lw64_kernel(const DcnArgs p, int tile
 // Same blend, same fold, same k order: bit-identical to the gather kernel.  LDS 81 664 B: two workgroups (8 waves) per CU.
 // MEASURED (16 x 128 x 440 fp16, same box, gather kernel 372 / 390 / 402 us at offsets sigma 0.3 / 1.5 / 4.0): first version (nine taps fully
 // unrolled, logits as fifteen strided 4-byte loads per thread) 351 / 384 / 494 us; + rolled tap loop (the unrolled kernel was 80 KB of code), coalesced
-// logits, software-pipelined taps: 345 / 388 us; config 5 9.21 against 9.06 ms per step -- NOT faster inside the model, hence opt-in.  Cycle stamps of
+// logits, software-pipelined taps: 345 / 388 us; config 5 9.21 against 9.06 ms per step -- NOT faster inside the model, hence opt-in: under rocprofv3 the
+// model's five 64 -> 64 launches take 319 - 331 us on the gather kernel and 331 - 384 us here (profiles/r04_c5_timeline_*.txt) -- the model's offsets are smooth, so the
+// gathers of neighbouring pixels hit the same cache lines; the micro-benchmark's independent random offsets (372 us) flatter every window design.  Cycle stamps of
 // one workgroup (tools/dcn_stamps.py, -DVD3D_STAMPS): 50k cycles = logits + window issue 5k, geometry 12-13k, drain + barrier 6k, nine taps 2.0-2.4k each
 // (21k; 2-4k before the pipelining), epilogue 4k.  Instruction count: ~12k wave-instructions of VALU per 128-pixel workgroup (geometry ~110 per
 // (pixel, tap), run on 5 of 8 lanes; blend 128 v_fma_mix + 16 conversions per tap and lane) = 157 us per launch at 100 % VALU issue: every variant of
