@@ -673,7 +673,7 @@ def main():
                        'side_streams': not args.no_overlap, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world),
                        'feed': args.feed if not feed else 'host: %d uint8 bytes uploaded per step and rank (2 x %d frames of %dx%dx3) + vd3d_preprocess_image inside the step'
                                % (feed.bytes_per_step, B, feed.HS, feed.WS)},
-            'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw / conv_ksplit256 / conv_small / conv_pw (all %d launches per step)' % nl,
+            'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw / conv_ksplit256 / conv_small / conv_pw, split-K launches incl. their splitk_reduce (all %d vd3d_conv2d_igemm calls per step)' % nl,
                          'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                          'traffic': traffic, 'traffic_source': traffic_source, 'traffic_stale': traffic_stale,
                          'library_sources_sha16': lib_hash, 'library_matches_tree': library_current,

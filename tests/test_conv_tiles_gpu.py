@@ -413,3 +413,32 @@ def test_staggered_dma_schedule_of_the_strips_is_bit_identical(shape, dtype):
         torch.cuda.synchronize()
         assert torch.equal(a.view(torch.int16), b.view(torch.int16)), 'tile %d: staggered schedule differs (max %.3e)' % (tile, (a.float() - b.float()).abs().max().item())
         outs.append(a)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_two_way_split_on_the_288_strips(dtype):
+    """Config 2's reg-tower output conv (1408 -> 576 at 8 x 24 x 80, fp32 output): its 256 x 288 strip tiles fill less than half the chip (120 tiles), so
+    natural dispatch runs the strips with K split in two + the reduction launch (conv_igemm.hip plan_splitk_strip).  Against the oracle at the fp32-output bar,
+    against the unsplit path (VD3D_NO_STRIP_SPLIT=1) to summation noise, run-to-run bit-identical; and a 16-bit-output variant with residual + ReLU."""
+    from visualdet3d_amd import _lib, hip_ops as ops
+    ulp, rel = run_case(8, 24, 80, 1408, 576, dtype=dtype, seed=3, cfg=0, out_f32=True, bn=False, relu=False)
+    assert rel <= 1e-4, rel
+    ulp, rel = run_case(8, 24, 80, 1408, 576, dtype=dtype, seed=4, cfg=0, residual=True)
+    assert ulp <= 1.0, (ulp, rel)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(8, 24, 80, 1408, generator=g).cuda().to(dtype)
+    pc = ops.pack_conv((torch.randn(576, 1408, 3, 3, generator=g) * (2.0 / (9 * 1408)) ** 0.5).cuda(), None, None, dtype, 1, 1, 1)
+    seen = []
+    orig = _lib.lib().vd3d_conv2d_workspace_bytes
+    try:
+        _lib.lib().vd3d_conv2d_workspace_bytes = lambda p: (seen.append(orig(p)), seen[-1])[1]
+        a = ops.conv2d(x, pc, relu=False, out_f32=True)
+    finally:
+        _lib.lib().vd3d_conv2d_workspace_bytes = orig
+    assert seen and seen[-1] == 2 * 120 * 256 * 288 * 4, seen          # the split path was what ran
+    b = ops.conv2d(x, pc, relu=False, out_f32=True)
+    with _lib.test_switch('VD3D_NO_STRIP_SPLIT'):
+        c = ops.conv2d(x, pc, relu=False, out_f32=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert ((a - c).abs().max() / c.abs().max()).item() < 2e-5

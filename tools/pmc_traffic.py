@@ -10,7 +10,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from visualdet3d_amd import build as _build  # noqa: E402
 
-CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small', 'conv_pw')
+CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small', 'conv_pw', 'splitk_reduce')      # (the reduction launch of a split-K convolution is part of that convolution)
 
 
 def per_kernel(path, counter):

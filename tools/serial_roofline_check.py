@@ -5,7 +5,7 @@ import csv
 import json
 import sys
 
-CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small', 'conv_pw')
+CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small', 'conv_pw', 'splitk_reduce')      # (the reduction launch of a split-K convolution is part of that convolution)
 rows = list(csv.DictReader(open(sys.argv[1])))
 line = json.loads(open(sys.argv[2]).read())
 fwd = max(int(r['calls']) for r in rows if 'head_nms_kernel' in r['name'])

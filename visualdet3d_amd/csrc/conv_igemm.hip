@@ -1204,7 +1204,8 @@ struct SplitPlan { int bn = 0; int splits = 1; int64_t ws_bytes = 0; };     // b
 
 // Low-parallelism shapes only: fewer 128-row tiles than ~1.2 x CUs (a batch-1 / batch-2 call at stride 16 or 32) AND a K deep enough
 // (>= 24 slices) that the extra reduction launch (~6 us) pays.  Splits fill two workgroup slots per CU, keep >= 4 slices per split.
-// Nothing the batch-8 ... batch-32 configurations launch gets here (their tile counts are in the thousands).
+// Of the batched configurations only the two thin cls-tower convs of config 2 qualify (1408 -> 256 and 256 -> 144 at 8 x 24 x 80: 240 / 120 tiles;
+// measured there: 114 -> 105 us against the halo tile, 38.6 -> 32.7 us against the 128 x 128 tile); every other batched layer has thousands of tiles.
 static SplitPlan plan_splitk(const ConvArgs& a, bool forced) {
     SplitPlan pl;
     const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
@@ -1228,9 +1229,9 @@ static SplitPlan plan_splitk(const ConvArgs& a, bool forced) {
 // splits are added in index order (deterministic), then the ordinary epilogue: folded BN, residual, ReLU, 16-bit or fp32 store.
 // Fully parallel (M x N / 4 threads): with the reduction inside the tile kernel (one workgroup per tile walking the splits one after
 // the other) a 30-tile x 17-split layer spent 24 us here, more than in its MFMA pass.
-template <typename T, int BN, int WARPS_M, int WARPS_N>
+template <typename T, int BN, int WARPS_M, int WARPS_N, int BM = 128, int MS = 32>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, int64_t total) {
-    constexpr int BM = 128, NW = WARPS_M * WARPS_N, WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / 32, TN = WTN / 32, NV = TN * TM * 4;
+    constexpr int NW = WARPS_M * WARPS_N, WTM = BM / WARPS_M, WTN = BN / WARPS_N, TM = WTM / MS, TN = WTN / MS, AV = MS * MS / 256, NV = TN * TM * AV;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;           // vector index inside one split's partial image
     if (g >= total) return;
     const f32x4* src = (const f32x4*)p.ks_ws + g;
@@ -1252,9 +1253,16 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, in
     const int wave = r % NW, tl = r / NW;
     const int tile_n = tl / p.tiles_m, tile_m = tl - tile_n * p.tiles_m;
     const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
-    const int i = vi / (TM * 4), j = (vi >> 2) % TM, v = vi & 3, lr = lane & 31, half = lane >> 5;
-    const int m = tile_m * BM + wm * WTM + j * 32 + lr;
-    const int n = tile_n * BN + wn * WTN + i * 32 + 8 * v + 4 * half;
+    int m, n;
+    if constexpr (MS == 32) {
+        const int i = vi / (TM * 4), j = (vi >> 2) % TM, v = vi & 3, lr = lane & 31, half = lane >> 5;
+        m = tile_m * BM + wm * WTM + j * 32 + lr;
+        n = tile_n * BN + wn * WTN + i * 32 + 8 * v + 4 * half;
+    } else {                                     // 16x16x32 tiles: one f32x4 per tile, lane (pixel l16, quad q) holds channels 4q .. 4q + 3
+        const int i = vi / TM, j = vi - i * TM;
+        m = tile_m * BM + wm * WTM + j * 16 + (lane & 15);
+        n = tile_n * BN + wn * WTN + i * 16 + 4 * (lane >> 4);
+    }
     if (m >= p.M || n >= p.Cout) return;
     constexpr int ES = (int)sizeof(T);
     float o[4];
@@ -1293,9 +1301,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, in
     }
 }
 
-template <typename T, int BN, int WARPS_M, int WARPS_N, bool PIPE>
+template <typename T, int BN, int WARPS_M, int WARPS_N, bool PIPE, int BM = 128, int MS = 32, int RING = 0>
 int launch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
-    constexpr int BM = 128, NT = WARPS_M * WARPS_N * 64;
+    constexpr int NT = WARPS_M * WARPS_N * 64;
     constexpr int LDS = 2 * (BM + BN) * 128 + 2 * BN * 4;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
@@ -1304,18 +1312,37 @@ int launch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
     a.ks_per = (a.nk + pl.splits - 1) / pl.splits;
     a.ks_phase = 1;
     static Vd3dLdsLimit lim;
-    auto kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, 32, 0, 0, false, 1>;
+    auto kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, 0, false, 1>;
     if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_igemm split-K)")) return rc;
     const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
     if (tiles <= 0 || tiles * pl.splits > 0x7fffffff) return VD3D_EINVAL;
     hipLaunchKernelGGL(kern, dim3((unsigned)(tiles * pl.splits)), dim3(NT), LDS, stream, a);
     const int64_t total = tiles * (BM * BN / 4);                         // f32x4 vectors of one split's partial image
-    hipLaunchKernelGGL((splitk_reduce_kernel<T, BN, WARPS_M, WARPS_N>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
+    hipLaunchKernelGGL((splitk_reduce_kernel<T, BN, WARPS_M, WARPS_N, BM, MS>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a, total);
     return vd3d_check_launch("conv_igemm split-K");
+}
+
+// Two-way split-K on the 256 x 288 column strips (round 4): a layer whose strip tiles fill LESS THAN HALF the chip (config 2's 1408 -> 576
+// reg-tower output conv: 60 x 2 = 120 tiles) ran on 128 x 288 tiles instead (240 tiles, one round, 38 % MFMA busy: 11 bytes of LDS fill per
+// KFLOP against 6.7 on the strips); with K split in two the strips fill 240 CUs at their own efficiency and the 70 MB of fp32 partials cost
+// less than the difference.  Exactly two splits, K >= 48 slices, 16-bit formats (see dispatch()).
+static SplitPlan plan_splitk_strip(const ConvArgs& a) {
+    SplitPlan pl;
+    const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
+    const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 287) / 288);
+    const int pad_n = (a.Cout + 287) / 288 * 288 - a.Cout;             // columns of the last strip beyond Cout: at most 1 / 16 wasted
+    if (a.Cout <= 288 || pad_n * 16 > a.Cout || a.nk < 48 || tiles * 2 > cus || tiles * 3 <= cus) return pl;
+    pl.bn = 288;
+    pl.splits = 2;
+    pl.ws_bytes = 2 * tiles * 256 * 288 * 4;
+    return pl;
 }
 
 template <typename T>
 int dispatch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
+    if constexpr (sizeof(T) == 2) {
+        if (pl.bn == 288) return launch_splitk<T, 288, 4, 2, true, 256, 16, 6>(a, stream, pl);
+    }
     if (pl.bn == 64) return launch_splitk<T, 64, 4, 1, false>(a, stream, pl);
     return launch_splitk<T, 128, 2, 2, true>(a, stream, pl);
 }
@@ -1492,6 +1519,8 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     if (g_force_cfg == 0 && a.ks_ws && sizeof(T) == 2) {
         const SplitPlan pl = plan_splitk(a, false);
         if (pl.splits >= 2 && a.ks_ws_bytes >= pl.ws_bytes) return dispatch_splitk<T>(a, stream, pl);
+        const SplitPlan ps = vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? SplitPlan() : plan_splitk_strip(a);
+        if (ps.splits >= 2 && a.ks_ws_bytes >= ps.ws_bytes) return dispatch_splitk<T>(a, stream, ps);
     }
     // Cout <= 32: 8 waves of 32 pixels x 32 channels, pipelined loop (+8 % on the ghost 24 -> 24 conv, +27 % on KM3D's 64 -> 27
     // offset convs over the 4-wave barrier-per-slice version)
@@ -1692,7 +1721,9 @@ extern "C" int64_t vd3d_conv2d_workspace_bytes(const vd3d_conv_params* p) {
     } else {
         return 0;                                   // fp32 never splits under natural dispatch (see dispatch())
     }
-    return plan_splitk(a, false).ws_bytes;
+    const SplitPlan pl = plan_splitk(a, false);
+    if (pl.splits >= 2) return pl.ws_bytes;
+    return vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? 0 : plan_splitk_strip(a).ws_bytes;
 }
 
 extern "C" int vd3d_conv2d_pair(const vd3d_conv_params* pa, const vd3d_conv_params* pb, void* stream) {
