@@ -275,7 +275,7 @@ def test_batch1_shapes_natural_dispatch_vs_oracle(case, dtype):
 
 
 def test_splitk_is_what_batch1_dispatch_picks_and_is_deterministic():
-    """vd3d_conv2d_workspace_bytes > 0 exactly for the low-parallelism deep-K shapes (and 0 for the batched bench shapes: nothing
+    """vd3d_conv2d_workspace_bytes > 0 exactly for the low-parallelism deep-K shapes (and 0 for the full-chip batched shapes: nothing
     changes for them); without a workspace the same call runs unsplit and agrees to fp32 summation noise; two split runs are
     bit-identical (partials are added in split order, no atomics)."""
     import ctypes as C
@@ -298,7 +298,18 @@ def test_splitk_is_what_batch1_dispatch_picks_and_is_deterministic():
         c = ops.conv2d(x, pc, relu=True)
     finally:
         _lib.lib().vd3d_conv2d_workspace_bytes = orig
-    assert seen and seen[0] == 3 * 165 * 128 * 128 * 4, seen
+    assert seen and seen[0] == 6 * 40 * 256 * 288 * 4, seen          # 8 x 5 strip tiles of 256 x 288, six splits (plan_splitk_strip)
+    with _lib.test_switch('VD3D_NO_STRIP_SPLIT'):                    # the 128 x 128-tile plan: 15 x 11 tiles, three splits
+        assert orig is not None and _lib.lib().vd3d_conv2d_workspace_bytes is orig
+        seen.clear()
+        try:
+            _lib.lib().vd3d_conv2d_workspace_bytes = lambda p: (seen.append(orig(p)), seen[-1])[1]
+            a2 = ops.conv2d(x, pc, relu=True)
+        finally:
+            _lib.lib().vd3d_conv2d_workspace_bytes = orig
+        assert seen[0] == 3 * 165 * 128 * 128 * 4, seen
+        d2 = (a.float() - a2.float()).abs().max().item() / a2.float().abs().max().item()
+        assert d2 < 2.0 ** -7, d2
     d = (a.float() - c.float()).abs().max().item() / c.float().abs().max().item()
     assert 0 < d < 2.0 ** -7, d            # a different summation order (so it really was another path), within one bf16 ulp
     x8, pc8 = params(8, 24, 80, 1408, 1408)

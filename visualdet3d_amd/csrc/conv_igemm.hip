@@ -1322,19 +1322,28 @@ int launch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
     return vd3d_check_launch("conv_igemm split-K");
 }
 
-// Two-way split-K on the 256 x 288 column strips (round 4): a layer whose strip tiles fill LESS THAN HALF the chip (config 2's 1408 -> 576
-// reg-tower output conv: 60 x 2 = 120 tiles) ran on 128 x 288 tiles instead (240 tiles, one round, 38 % MFMA busy: 11 bytes of LDS fill per
-// KFLOP against 6.7 on the strips); with K split in two the strips fill 240 CUs at their own efficiency and the 70 MB of fp32 partials cost
-// less than the difference.  Exactly two splits, K >= 48 slices, 16-bit formats (see dispatch()).
+// Split-K on the 256 x 288 column strips (round 4): a layer whose strip tiles fill LESS THAN HALF the chip.  (i) config 2's 1408 -> 576 reg-tower
+// output conv at batch 8 (60 x 2 = 120 tiles) ran on 128 x 288 tiles instead (240 tiles, one round, 38 % MFMA busy: 11 bytes of LDS fill per KFLOP
+// against 6.7 on the strips); with K split in two the strips fill 240 CUs at their own efficiency and the 70 MB of fp32 partials cost less than
+// the difference (246.7 -> 187.1 us).  (ii) the deep layers of a BATCH-1 call (1408 -> 1408 at 1 x 24 x 80: 8 x 5 = 40 strip tiles x 6 splits) -- before:
+// 128 x 128 tiles x 3 splits.  Taken when the split strips fill >= 85 % of the CUs with >= 16 slices per split, <= 1/16 of the last strip's columns
+// and <= 1/12 of the last tile's pixel rows wasted; 16-bit formats (see dispatch()); partials added in split order.
 static SplitPlan plan_splitk_strip(const ConvArgs& a) {
     SplitPlan pl;
     const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
-    const int64_t tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 287) / 288);
-    const int pad_n = (a.Cout + 287) / 288 * 288 - a.Cout;             // columns of the last strip beyond Cout: at most 1 / 16 wasted
-    if (a.Cout <= 288 || pad_n * 16 > a.Cout || a.nk < 48 || tiles * 2 > cus || tiles * 3 <= cus) return pl;
+    const int tm = (a.M + 255) / 256, tn = (a.Cout + 287) / 288;
+    const int64_t tiles = (int64_t)tm * tn;
+    const int pad_n = tn * 288 - a.Cout, pad_m = tm * 256 - a.M;
+    if (a.Cout <= 288 || pad_n * 16 > a.Cout || pad_m * 12 > a.M || tiles * 2 > cus) return pl;
+    int sp = (int)(cus / tiles);
+    if (sp > a.nk / 16) sp = a.nk / 16;
+    if (sp > 16) sp = 16;
+    if (sp < 2 || tiles * sp * 100 < (int64_t)cus * 85) return pl;
+    const int per = (a.nk + sp - 1) / sp;
+    pl.splits = (a.nk + per - 1) / per;               // every split is non-empty
+    if (pl.splits < 2) { pl.splits = 1; return pl; }
     pl.bn = 288;
-    pl.splits = 2;
-    pl.ws_bytes = 2 * tiles * 256 * 288 * 4;
+    pl.ws_bytes = (int64_t)pl.splits * tiles * 256 * 288 * 4;
     return pl;
 }
 
@@ -1517,10 +1526,10 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
     // 16-bit formats only: the split changes the fp32 summation order with the tile count, i.e. with the batch size -- fp32 is the
     // validation mode, whose results must not depend on how many frames share a call (tests: batch-1 == slice of the batched call)
     if (g_force_cfg == 0 && a.ks_ws && sizeof(T) == 2) {
-        const SplitPlan pl = plan_splitk(a, false);
-        if (pl.splits >= 2 && a.ks_ws_bytes >= pl.ws_bytes) return dispatch_splitk<T>(a, stream, pl);
         const SplitPlan ps = vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? SplitPlan() : plan_splitk_strip(a);
         if (ps.splits >= 2 && a.ks_ws_bytes >= ps.ws_bytes) return dispatch_splitk<T>(a, stream, ps);
+        const SplitPlan pl = plan_splitk(a, false);
+        if (pl.splits >= 2 && a.ks_ws_bytes >= pl.ws_bytes) return dispatch_splitk<T>(a, stream, pl);
     }
     // Cout <= 32: 8 waves of 32 pixels x 32 channels, pipelined loop (+8 % on the ghost 24 -> 24 conv, +27 % on KM3D's 64 -> 27
     // offset convs over the 4-wave barrier-per-slice version)
@@ -1721,9 +1730,9 @@ extern "C" int64_t vd3d_conv2d_workspace_bytes(const vd3d_conv_params* p) {
     } else {
         return 0;                                   // fp32 never splits under natural dispatch (see dispatch())
     }
-    const SplitPlan pl = plan_splitk(a, false);
-    if (pl.splits >= 2) return pl.ws_bytes;
-    return vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? 0 : plan_splitk_strip(a).ws_bytes;
+    const SplitPlan ps = vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? SplitPlan() : plan_splitk_strip(a);
+    if (ps.splits >= 2) return ps.ws_bytes;
+    return plan_splitk(a, false).ws_bytes;
 }
 
 extern "C" int vd3d_conv2d_pair(const vd3d_conv_params* pa, const vd3d_conv_params* pb, void* stream) {
