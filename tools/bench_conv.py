@@ -22,6 +22,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('head 1408->1408', 8, 24, 80, 1408, 1408),
     ('head 1408->576', 8, 24, 80, 1408, 576),
     ('r50head 2176->2176', 16, 18, 80, 2176, 2176),
+    ('r50 reg 2176->576', 32, 18, 80, 2176, 576),
+    ('r50 cls 2176->256', 32, 18, 80, 2176, 256),
     ('head 1408->256', 8, 24, 80, 1408, 256),
     ('cls 256->144', 8, 24, 80, 256, 144),
     ('cls 256->256', 8, 24, 80, 256, 256),
