@@ -95,3 +95,113 @@ def test_mono_calls_replay_and_host_calibration():
     e = m([img[:1], P2[:1]])
     assert _same(a, e) and _same(b, e)
     assert m.graph_stats['eager'] == 1 and m.graph_stats['replays'] == 2
+
+
+def _other_calib(P2, scale=1.07, shift=9.0):
+    """a different camera: focal length scaled, principal point moved (the ground filter, the decode and the clip all read it)"""
+    Q = P2.clone()
+    Q[:, 0, 0] *= scale
+    Q[:, 1, 1] *= scale
+    Q[:, 0, 2] += shift
+    Q[:, 1, 2] -= shift / 2
+    return Q
+
+
+@pytest.mark.parametrize('form', ['device_f32', 'host_f64', 'device_f64_strided'])
+def test_replay_with_a_different_calibration_equals_eager(form):
+    """the calibration of a LATER frame must reach the kernels of a replay, whatever form it arrives in.  The
+    first call captures with P2; the second call hands over a DIFFERENT calibration as host float64 / strided device float64 / plain
+    device fp32; each must equal the eager result for that calibration -- and differ from the first frame's."""
+    m, cfg, (L, R, P2, P3), _ = _stereo()
+    Q = _other_calib(P2[:1])
+    if form == 'host_f64':
+        q = Q.cpu().double()
+    elif form == 'device_f64_strided':
+        wide = torch.zeros((1, 3, 8), dtype=torch.float64, device=Q.device)
+        wide[:, :, :4] = Q.double()
+        q = wide[:, :, :4]
+        assert not q.is_contiguous()
+    else:
+        q = Q
+    first_form = P2[:1].cpu().double() if form != 'device_f32' else P2[:1]
+    a = m([L[:1], R[:1], first_form, P3[:1]])                   # capture with the first calibration
+    b = m([L[:1], R[:1], q, P3[:1]])                            # replay with another one
+    c = m([L[:1], R[:1], first_form, P3[:1]])                   # and back
+    assert m.graph_stats['captures'] == 1 and m.graph_stats['replays'] == 3
+    m.use_graph = False
+    ea = m([L[:1], R[:1], P2[:1], P3[:1]])
+    eb = m([L[:1], R[:1], Q, P3[:1]])
+    assert _same(a, ea) and _same(c, ea)
+    assert _same(b, eb), 'replay decoded with a stale calibration'
+    assert not _same(ea, eb), 'the second calibration does not change the result: the test proves nothing'
+
+
+def test_mono_replay_with_a_different_host_calibration():
+    """the mono detectors read P2 in three places (LookGround, ground filter, decode): same statement as above"""
+    from visualdet3d_amd.networks.utils.registry import DETECTOR_DICT
+    import visualdet3d_amd.networks.detectors  # noqa: F401
+    g = load_golden('groundaware_r34_96x320')
+    cfg, (img, P2), winit = mono_case_from_golden(g, 'groundaware_r34_96x320')
+    m = DETECTOR_DICT[cfg.name](cfg)
+    m.load_state_dict(syn.seeded_state_dict(m.state_dict(), **winit))
+    m = m.cuda().eval()
+    img, P2 = img.cuda(), P2.cuda()
+    Q = _other_calib(P2[:1])
+    a = m([img[:1], P2[:1].cpu().double()])
+    b = m([img[:1], Q.cpu().double()])
+    assert m.graph_stats['captures'] == 1
+    m.use_graph = False
+    assert _same(a, m([img[:1], P2[:1]]))
+    eb = m([img[:1], Q])
+    assert _same(b, eb) and not _same(a, eb)
+
+
+def test_a_larger_batch_does_not_free_the_scratch_of_a_cached_graph():
+    """the B = 1 graph bakes the address of the head's candidate scratch; a later B = 8 call used to replace (and
+    free) that buffer.  Now every batch size keeps its own for the life of the head: the B = 1 replay after the batched call -- and
+    after other allocations have had the chance to land on a freed block -- still equals the eager launches."""
+    m, cfg, (L, R, P2, P3), _ = _stereo()
+    B = L.shape[0]
+    x1 = [L[:1], R[:1], P2[:1], P3[:1]]
+    a = m(x1)
+    ws1 = m.bbox_head._workspace
+    p1 = ws1.data_ptr()
+    reps = (8 + B - 1) // B
+    Lb, Rb, P2b = L.repeat(reps, 1, 1, 1)[:8], R.repeat(reps, 1, 1, 1)[:8], P2.repeat(reps, 1, 1)[:8]
+    outs = m.test_forward_batched(Lb, Rb, P2b)
+    assert m.bbox_head._workspace.data_ptr() != p1 and m.bbox_head._workspaces[(1, m.bbox_head.max_candidates, L.device)] is ws1
+    junk = [torch.full((n,), 255, dtype=torch.uint8, device='cuda') for n in (ws1.numel(), ws1.numel() // 2, 4096, 1 << 20)]   # would land on a freed block
+    b = m(x1)
+    torch.cuda.synchronize()
+    assert m.graph_stats['captures'] == 2 and m.graph_stats['cached'] == 2
+    assert _same(a, b) and _same(outs[0], a)
+    m.use_graph = False
+    assert _same(a, m(x1))
+    del junk
+
+
+def test_cache_is_lru_and_keyed_on_the_anchor_filter():
+    """a hit refreshes the entry (least recently USED is evicted); the anchor filter thresholds the select kernel
+    reads at launch are part of the key."""
+    from visualdet3d_amd.networks.lib import graphed
+    m, cfg, (L, R, P2, P3), _ = _stereo()
+    x = [L[:1], R[:1], P2[:1], P3[:1]]
+    r0 = m(x)
+    st = m._graph_state()
+    k0 = next(iter(st['entries']))
+    old = graphed._MAX_GRAPHS
+    graphed._MAX_GRAPHS = 2
+    try:
+        m.bbox_head.anchors.filter_x_threshold = 20.0            # a launch-time setting: its own graph
+        r1 = m(x)
+        assert m.graph_stats['captures'] == 2
+        m.bbox_head.anchors.filter_x_threshold = 40.0
+        assert _same(m(x), r0) and m.graph_stats['captures'] == 2          # hit: k0 is now the most recently used
+        m.bbox_head.anchors.filter_x_threshold = 10.0
+        m(x)                                                               # third key: evicts the 20.0 graph, not k0
+        assert m.graph_stats['captures'] == 3 and k0 in st['entries'] and len(st['entries']) == 2
+    finally:
+        graphed._MAX_GRAPHS = old
+    m.use_graph = False
+    m.bbox_head.anchors.filter_x_threshold = 20.0
+    assert _same(r1, m(x))

@@ -49,8 +49,9 @@ def _best_level(vals, lo_cnt, hi_cnt, min_level=-1e30, also=None, need=0):
     return best
 
 
-def design_margin_head(x_pen, mask):
-    """x_pen [B,256,H,W]: the oracle's input of the last cls conv; mask [B,H,W,A].  -> (weight [A*NC,256,3,3], bias [A*NC], info)."""
+def design_margin_head(x_pen, mask, cnt0=(24, 200), cnt1=(8, 160), need1=8, cnt2=(2, 200)):
+    """x_pen [B,256,H,W]: the oracle's input of the last cls conv; mask [B,H,W,A].  -> (weight [A*NC,256,3,3], bias [A*NC], info).
+    cnt*: (fewest, most) candidates allowed above the level of channel 0 / 1 / 2 over all frames."""
     B, C, H, W = x_pen.shape
     P = F.unfold(x_pen, 3, padding=1).permute(0, 2, 1).reshape(-1, C * 9).double()
     mu = P.mean(0)
@@ -61,7 +62,7 @@ def design_margin_head(x_pen, mask):
         for sgn in (1.0, -1.0):
             u = (U[:, -pc] * sgn).float()
             r = F.conv2d(x_pen, u.view(1, C, 3, 3), padding=1)[:, 0] - u.dot(mu.float())
-            g0 = _best_level(r[mask[..., CH[0][0]]], 24, 200)
+            g0 = _best_level(r[mask[..., CH[0][0]]], *cnt0)
             if g0[1] is None:
                 continue
             # channel 1 (same centres, next scale, half the gain) must sit ABOVE channel 0's level: then logit0 - logit1 =
@@ -69,11 +70,11 @@ def design_margin_head(x_pen, mask):
             # (and at least 8 of its candidates must sit where anchor 16 passes the ground filter too, so that NMS has suppressions
             # to decide: the filter depends on the anchor's prior depth, the two masks differ at the image border)
             m1 = mask[..., CH[1][0]]
-            g1 = _best_level(r[m1], 8, 160, min_level=g0[1] + 0.5 * g0[0], also=mask[..., CH[0][0]][m1], need=8)
+            g1 = _best_level(r[m1], *cnt1, min_level=g0[1] + 0.5 * g0[0], also=mask[..., CH[0][0]][m1], need=need1)
             if g1[1] is None:
                 continue
             # channel 2's candidates are removed by the z-prior filter before NMS: its level is free
-            g2 = _best_level(r[mask[..., CH[2][0]]], 2, 200)
+            g2 = _best_level(r[mask[..., CH[2][0]]], *cnt2)
             if g2[1] is None:
                 continue
             fom = min(g0[0], g1[0], g2[0])
@@ -96,66 +97,63 @@ def design_margin_head(x_pen, mask):
     return w.view(A * NC, C, 3, 3), b, info
 
 
-def test_config2_batch8_bf16_margin_controlled_detection_set_is_identical():
-    case = c2_bf16_case()
-    m, sd, st, B, H, W = case['model'], case['sd'], case['stages'], case['B'], case['H'], case['W']
-    taps = {t['key']: t for t in case['taps'] if t['kind'] == 'conv'}
-    x_cls = taps['bbox_head.cls_feature_extraction.6']['x']
-    x_reg = taps['bbox_head.reg_feature_extraction.3']['x']
+def _margin_identity(m, cls_mod, reg_mod, w_cls, b_cls, w_reg, b_reg, x_cls, x_reg, anchors, mean_std, mask_flat, inputs, N, REP, H, W,
+                     info, title, thr=0.75, iou_thr=0.4, round16=orc.bf16_round):
+    """The literal bar on a designed head.  The oracle holds N frames (its penultimate tower features ``x_cls`` / ``x_reg``); the HIP
+    network runs N * REP frames end to end (frame f is oracle frame f % N) with the two designed last convs; EVERY replica must give
+    the oracle's detection set.  Measures the noise between the implementations and asserts the margins against it first."""
     H16, W16 = x_cls.shape[2:]
-    mask = st['mask'].view(B, H16, W16, A)
-    w_cls, b_cls, info = design_margin_head(x_cls, mask)
-    w_reg = sd['bbox_head.reg_feature_extraction.3.weight'] * 0.0625
-    b_reg = sd['bbox_head.reg_feature_extraction.3.bias']
-    print('\n[margin workload] filter: PC%d (sign %+d), gain %g, (level, gap, candidates) per channel: %s'
-          % (info['pc'], info['sign'], info['gain'], info['levels']))
-    # ---- oracle: the two last convs on the oracle's own (bf16-rounded) tower features, then the reference post-processing
+    mask = mask_flat.view(N, H16, W16, A)
+    print('\n[%s] filter: PC%d (sign %+d), gain %g, (level, gap, candidates) per channel: %s'
+          % (title, info['pc'], info['sign'], info['gain'], info['levels']))
+    # ---- oracle: the two last convs on the oracle's own (16-bit-rounded) tower features, then the reference post-processing
     with torch.no_grad():
-        cls_o = orc.anchor_flatten(F.conv2d(x_cls, orc.bf16_round(w_cls), b_cls, padding=1), NC)
-        reg_o = orc.anchor_flatten(F.conv2d(x_reg, orc.bf16_round(w_reg), b_reg, padding=1), 12)
-    thr, iou_thr = 0.75, 0.4
-    ref = [orc.get_bboxes(cls_o[b], reg_o[b], st['anchors'], st['mean_std'], st['mask'][b], (H, W), 2, thr, iou_thr) for b in range(B)]
+        cls_o = orc.anchor_flatten(F.conv2d(x_cls, round16(w_cls), b_cls, padding=1), NC)
+        reg_o = orc.anchor_flatten(F.conv2d(x_reg, round16(w_reg), b_reg, padding=1), 12)
+    ref = [orc.get_bboxes(cls_o[b], reg_o[b], anchors, mean_std, mask_flat[b], (H, W), 2, thr, iou_thr) for b in range(N)]
     # ---- HIP: the whole network end to end with the same two last convs
-    cls_mod, reg_mod = m.bbox_head.cls_feature_extraction[6], m.bbox_head.reg_feature_extraction[3]
-    saved = [p.detach().clone() for p in (cls_mod.weight, cls_mod.bias, reg_mod.weight)]
+    saved = [p.detach().clone() for p in (cls_mod.weight, cls_mod.bias, reg_mod.weight, reg_mod.bias)]
     try:
         with torch.no_grad():
             cls_mod.weight.copy_(w_cls.cuda())
             cls_mod.bias.copy_(b_cls.cuda())
             reg_mod.weight.copy_(w_reg.cuda())
-            scores, boxes, labels, aidx, count = [t.cpu() for t in m.forward_device(case['L'].cuda(), case['R'].cuda(), case['P2'].cuda())]
+            reg_mod.bias.copy_(b_reg.cuda())
+            scores, boxes, labels, aidx, count = [t.cpu() for t in m.forward_device(*[t.cuda() for t in inputs])]
             cls_h, reg_h = [t.float().cpu() for t in m._last_raw]
     finally:
         with torch.no_grad():
-            for p, v in zip((cls_mod.weight, cls_mod.bias, reg_mod.weight), saved):
+            for p, v in zip((cls_mod.weight, cls_mod.bias, reg_mod.weight, reg_mod.bias), saved):
                 p.copy_(v)
-    assert int(count.min()) >= 0
+    B = N * REP
+    assert cls_h.shape[0] == B and int(count.min()) >= 0
     # ---- observed noise between the two implementations, per live channel (their gains differ by powers of two, and so do their
-    # noise and their margins), on the anchors the ground filter lets through
+    # noise and their margins), on the anchors the ground filter lets through, worst over every replica
     live = [a * NC + c for a, c, _ in CH]
-    lo, lh = cls_o.view(B, -1, A * NC)[..., live], cls_h.view(B, -1, A * NC)[..., live]           # [B, HW, 3]
+    lo = cls_o.view(N, -1, A * NC)[..., live]                                                     # [N, HW, 3]
+    lh = cls_h.view(REP, N, -1, A * NC)[..., live]                                                # [REP, N, HW, 3]
     thr_l = math.log(thr / (1 - thr))
     noise = 0.0
     for j, (a, c, rel) in enumerate(CH):
-        mj = mask[..., a].reshape(B, -1)
-        nj = (lo[..., j] - lh[..., j]).abs()[mj].max().item()
+        mj = mask[..., a].reshape(N, -1)
+        nj = max((lo[..., j] - lh[r, ..., j]).abs()[mj].max().item() for r in range(REP))
         margin_j = (lo[..., j] - thr_l).abs()[mj].min().item()
-        dsj = (torch.sigmoid(lo[..., j]) - torch.sigmoid(lh[..., j])).abs()[mj].max().item()
-        print('[margin workload] channel (anchor %d, class %d, gain x%g): observed logit noise %.3e (score %.2e); nearest logit to the '
-              'threshold %.3f = %.1f x noise' % (a, c, rel, nj, dsj, margin_j, margin_j / nj))
+        dsj = max((torch.sigmoid(lo[..., j]) - torch.sigmoid(lh[r, ..., j])).abs()[mj].max().item() for r in range(REP))
+        print('[%s] channel (anchor %d, class %d, gain x%g): observed logit noise %.3e (score %.2e); nearest logit to the '
+              'threshold %.3f = %.1f x noise' % (title, a, c, rel, nj, dsj, margin_j, margin_j / nj))
         assert margin_j > MARGIN * nj, 'channel %d: threshold margin %.3f is not > 10 x the observed noise %.3e' % (j, margin_j, nj)
         noise = max(noise, nj)
     dead = torch.ones(A * NC, dtype=torch.bool)
     dead[live] = False
     dead[2::NC] = False
-    assert cls_h.view(B, -1, A * NC)[..., dead].max().item() < -5 and cls_o.view(B, -1, A * NC)[..., dead].max().item() < -5
+    assert cls_h.view(B, -1, A * NC)[..., dead].max().item() < -5 and cls_o.view(N, -1, A * NC)[..., dead].max().item() < -5
     # ---- margins between competing candidates (oracle side): every pair that overlaps at all is separated by > 10 x noise in
     # logit, and no IoU sits near the NMS threshold
     n_pairs, n_sup, n_det = 0, 0, 0
-    for b in range(B):
-        cand = torch.nonzero((torch.sigmoid(cls_o[b, :, :2]).max(dim=1).values > thr) & st['mask'][b])[:, 0]
+    for b in range(N):
+        cand = torch.nonzero((torch.sigmoid(cls_o[b, :, :2]).max(dim=1).values > thr) & mask_flat[b])[:, 0]
         s_c, l_c = cls_o[b, cand, :2].max(dim=1)
-        bx, zm = orc.decode(st['anchors'][cand], reg_o[b, cand], st['mean_std'][cand, l_c], torch.ones(len(cand)))
+        bx, zm = orc.decode(anchors[cand], reg_o[b, cand], mean_std[cand, l_c], torch.ones(len(cand)))
         bx, s_c = bx[zm, :4], s_c[zm]
         x1, y1 = torch.max(bx[:, None, 0], bx[None, :, 0]), torch.max(bx[:, None, 1], bx[None, :, 1])
         x2, y2 = torch.min(bx[:, None, 2], bx[None, :, 2]), torch.min(bx[:, None, 3], bx[None, :, 3])
@@ -169,29 +167,103 @@ def test_config2_batch8_bf16_margin_controlled_detection_set_is_identical():
         assert not bool(((iou > iou_thr - 0.05) & (iou < iou_thr + 0.05)).any()), 'frame %d: an IoU within 0.05 of the NMS threshold' % b
         gaps = (s_c[:, None] - s_c[None, :]).abs()[iou > iou_thr]
         assert gaps.numel() == 0 or gaps.min().item() > MARGIN * noise, 'frame %d: competing candidates %.3f apart' % (b, gaps.min().item())
-    # ---- the literal bar
+    # ---- the literal bar, every replica
     worst_f, worst_s = 0.0, 0.0
-    for b in range(B):
-        k = int(count[b])
+    for f in range(B):
+        b = f % N
+        k = int(count[f])
         s_o, b_o, l_o, i_o = ref[b]
-        n_det += len(i_o)
-        got = {int(a): j for j, a in enumerate(aidx[b, :k].tolist())}
+        n_det += len(i_o) if f < N else 0
+        got = {int(a): j for j, a in enumerate(aidx[f, :k].tolist())}
         want = {int(a): j for j, a in enumerate(i_o.tolist())}
-        assert set(got) == set(want), 'frame %d: detection sets differ: only HIP %s, only oracle %s' % (
-            b, sorted(set(got) - set(want)), sorted(set(want) - set(got)))
+        assert set(got) == set(want), 'frame %d (oracle frame %d): detection sets differ: only HIP %s, only oracle %s' % (
+            f, b, sorted(set(got) - set(want)), sorted(set(want) - set(got)))
         scale = b_o.abs().amax(dim=0).clamp_min(1.0)
         for a, j in want.items():
             gj = got[a]
-            assert int(labels[b, gj]) == int(l_o[j]), 'frame %d anchor %d: label' % (b, a)
-            worst_f = max(worst_f, float(((boxes[b, gj] - b_o[j]).abs() / scale).max()))
-            worst_s = max(worst_s, abs(float(scores[b, gj] - s_o[j])))
+            assert int(labels[f, gj]) == int(l_o[j]), 'frame %d anchor %d: label' % (f, a)
+            worst_f = max(worst_f, float(((boxes[f, gj] - b_o[j]).abs() / scale).max()))
+            worst_s = max(worst_s, abs(float(scores[f, gj] - s_o[j])))
         # output order = decreasing score: identical wherever consecutive oracle scores are more than the margin apart
         so = torch.logit(s_o.double().clamp(max=1 - 1e-12))
-        assert bool((scores[b, 1:k] <= scores[b, :k - 1]).all())
+        assert bool((scores[f, 1:k] <= scores[f, :k - 1]).all())
         for j in range(len(i_o) - 1):
             if float(so[j] - so[j + 1]) > MARGIN * noise:
-                assert got[int(i_o[j])] < got[int(i_o[j + 1])], 'frame %d: order of anchors %d / %d' % (b, int(i_o[j]), int(i_o[j + 1]))
-    print('[margin workload] %d detections over %d frames (%d overlapping candidate pairs, %d suppressions decided by NMS): sets and '
-          'labels identical; worst box field %.2e of its scale, worst score difference %.2e' % (n_det, B, n_pairs, n_sup, worst_f, worst_s))
-    assert n_det >= 3 * B and n_sup >= B, 'workload must exercise NMS (%d detections, %d suppressions)' % (n_det, n_sup)
+                assert got[int(i_o[j])] < got[int(i_o[j + 1])], 'frame %d: order of anchors %d / %d' % (f, int(i_o[j]), int(i_o[j + 1]))
+    print('[%s] %d detections over %d oracle frames x %d replicas (%d overlapping candidate pairs, %d suppressions decided by NMS): sets '
+          'and labels identical in every replica; worst box field %.2e of its scale, worst score difference %.2e'
+          % (title, n_det, N, REP, n_pairs, n_sup, worst_f, worst_s))
+    assert n_det >= 3 * N and n_sup >= N, 'workload must exercise NMS (%d detections, %d suppressions)' % (n_det, n_sup)
+    return worst_f, worst_s
+
+
+def test_config2_batch8_bf16_margin_controlled_detection_set_is_identical():
+    case = c2_bf16_case()
+    m, sd, st, B, H, W = case['model'], case['sd'], case['stages'], case['B'], case['H'], case['W']
+    taps = {t['key']: t for t in case['taps'] if t['kind'] == 'conv'}
+    x_cls = taps['bbox_head.cls_feature_extraction.6']['x']
+    x_reg = taps['bbox_head.reg_feature_extraction.3']['x']
+    H16, W16 = x_cls.shape[2:]
+    w_cls, b_cls, info = design_margin_head(x_cls, st['mask'].view(B, H16, W16, A))
+    w_reg = sd['bbox_head.reg_feature_extraction.3.weight'] * 0.0625
+    b_reg = sd['bbox_head.reg_feature_extraction.3.bias']
+    worst_f, worst_s = _margin_identity(m, m.bbox_head.cls_feature_extraction[6], m.bbox_head.reg_feature_extraction[3], w_cls, b_cls, w_reg, b_reg,
+                                        x_cls, x_reg, st['anchors'], st['mean_std'], st['mask'], (case['L'], case['R'], case['P2']), B, 1, H, W,
+                                        info, 'margin workload C2')
+    assert worst_f <= 1e-3 and worst_s <= 1e-3
+
+
+def test_config3_r50_dcn_head_batch32_bf16_margin_controlled_detection_set_is_identical():
+    """BASELINE config 3 in its timed type at its timed size: YOLOStereo3D ResNet-50 core + base (DCNv2) head, 32 pairs of 288 x 1280,
+    bf16 -- the statement of the C2 test above, for the configuration whose reg tower opens with a 2176 -> 2176 DCNv2
+    (heads/detection_3d_head.py:69-79).  Same weights / inputs as bench.py's `other_configs[C3]` with three controlled choices:
+      * the DCN's offset conv is scaled to SUB-PIXEL offsets (x 1/32: the reference zero-initialises it, lib/ops/dcn/deform_conv.py:453-457;
+        with the seeded N(0, 1 px) offsets every 1-ulp flip upstream moves a sampling position);
+      * the last cls conv is the designed margin head, the last reg conv the seeded one x 1/16 (as for C2);
+      * thresholds 0.75 / 0.4 (the levels the head is designed against).
+    The bf16-rounded oracle runs TWO frames on the host; the HIP network runs the bench's batch of 32 (the two frames x 16 replicas, so the
+    at-size dispatch runs: `dcn_columns` + the 19 584-deep GEMM or its fused successor, `group_m`, `conv_pw`); every replica must
+    reproduce the oracle's detection set."""
+    import tempfile
+
+    from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3DBaseHead
+    from visualdet3d_amd.utils import synthetic as syn
+    N, REP, H, W = 2, 16, 288, 1280
+    tmp = tempfile.mkdtemp()
+    cfg = syn.stereo3d_cfg(tmp, depth=50, score_thr=0.75, nms_iou_thr=0.4)
+    syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+    m = Stereo3DBaseHead(cfg)
+    sd = syn.seeded_state_dict(m.state_dict(), seed=6, head_std=0.006)           # bench.py OTHER_CONFIGS[C3]
+    q = 'bbox_head.reg_feature_extraction.0.conv_offset.'
+    sd[q + 'weight'] = sd[q + 'weight'] / 32          # seeded: rms 8.4 px over the 2176 input channels -> 0.26 px, max 0.94 px
+    sd[q + 'bias'] = sd[q + 'bias'] / 32
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    m.compute_dtype = torch.bfloat16
+    L, R = syn.stereo_pair(N, H, W, seed=3)
+    P2, _ = syn.kitti_calib(W, batch=N)
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    taps = []
+    with torch.no_grad():
+        c = orc.Ctx(sd, orc.bf16_round, taps)
+        feats, _ = orc.stereo_core(c, L, R, 50)
+        orc.dcn_head(c, feats, len(cfg.obj_types) + 1)
+        mean_npy, std_npy = orc.load_priors(cfg.head.preprocessed_path, cfg.obj_types)
+        anchors, means, mean_std = orc.anchors_for_image(H, W, cfg.head.anchors_cfg, mean_npy, std_npy)
+        mask_flat = orc.anchor_mask(anchors, means, P2.float())
+    off = [t for t in taps if t['kind'] == 'dcn_head'][0]['logits'][:, :18]
+    print('\n[margin workload C3] DCN offsets: rms %.3f px, max %.2f px' % (off.pow(2).mean().sqrt().item(), off.abs().max().item()))
+    assert off.abs().max().item() < 1.0, 'offsets are meant to be sub-pixel'
+    convs = {t['key']: t for t in taps if t['kind'] == 'conv'}
+    x_cls = convs['bbox_head.cls_feature_extraction.6']['x']
+    x_reg = convs['bbox_head.reg_feature_extraction.6']['x']
+    H16, W16 = x_cls.shape[2:]
+    # two frames of 18 x 80 cells: fewer candidates than C2's eight frames of 24 x 80, hence wider gaps at the top of the tail
+    w_cls, b_cls, info = design_margin_head(x_cls, mask_flat.view(N, H16, W16, A), cnt0=(12, 120), cnt1=(6, 100), need1=4, cnt2=(2, 120))
+    w_reg = sd['bbox_head.reg_feature_extraction.6.weight'] * 0.0625
+    b_reg = sd['bbox_head.reg_feature_extraction.6.bias']
+    rp = lambda t: t.repeat(REP, *([1] * (t.dim() - 1)))                                         # noqa: E731
+    worst_f, worst_s = _margin_identity(m, m.bbox_head.cls_feature_extraction[6], m.bbox_head.reg_feature_extraction[6], w_cls, b_cls, w_reg, b_reg,
+                                        x_cls, x_reg, anchors, mean_std, mask_flat, (rp(L), rp(R), rp(P2)), N, REP, H, W,
+                                        info, 'margin workload C3')
     assert worst_f <= 1e-3 and worst_s <= 1e-3

@@ -1383,6 +1383,26 @@ int launch_strip288(ConvArgs& a, hipStream_t stream) {
 // the oracle); a forced tile that cannot run the given convolution is an error, never a silent fallback.  Experimental
 // tiles and the timing ablations (results wrong by construction) exist only in a -DVD3D_TUNING build
 // (`python -m visualdet3d_amd.build --tuning` -> libvd3d_hip_tuning.so, used by tools/bench_conv.py).
+// Which of the resident-weight / streaming kernels takes a 16-bit shape under natural dispatch (ROUTE_NONE: the tile kernels, possibly
+// split over K).  The ONE statement of that choice: dispatch() launches by it and vd3d_conv2d_workspace_bytes() sizes the split-K
+// scratch by it, so the two cannot drift apart.
+enum SpecialRoute { ROUTE_NONE = 0, ROUTE_REGW, ROUTE_KSPLIT, ROUTE_SMALL, ROUTE_NARROW, ROUTE_PW, ROUTE_RES64 };
+static SpecialRoute special_route(const ConvArgs& a) {
+    if (a.Cin == 128 && regw_shape_ok(a)) return ROUTE_REGW;
+    if (ksplit_shape_ok(a)) return ROUTE_KSPLIT;
+    if (small_shape_ok(a)) return ROUTE_SMALL;
+    if (narrow_shape_ok(a) && !vd3d_switch(VD3D_SW_NO_NARROW)) return ROUTE_NARROW;
+    if (pw_shape_ok(a)) return ROUTE_PW;
+    if (a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.wide_store && !a.out_f32) return ROUTE_RES64;
+    return ROUTE_NONE;
+}
+// The split-K plan of a 16-bit shape under natural dispatch (splits < 2: no split); shared by dispatch() and the workspace query.
+static SplitPlan natural_split_plan(const ConvArgs& a) {
+    const SplitPlan ps = vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? SplitPlan() : plan_splitk_strip(a);
+    if (ps.splits >= 2) return ps;
+    return plan_splitk(a, false);
+}
+
 static thread_local int g_force_cfg = 0;      // per calling thread: a test forcing a tile cannot leak into other threads' launches
 
 static int forced_tile_error(const char* why) {
@@ -1506,29 +1526,30 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         default: return forced_tile_error("is not a tile of this build");
     }
     if constexpr (std::is_same<T, short>::value || std::is_same<T, hf16>::value) {
-        // register-resident weights (v6), Cin 128: +25 % over the 8x32x128 halo tile on ResNet layer2
         constexpr int fmt = std::is_same<T, hf16>::value ? VD3D_F16 : VD3D_BF16;
-        if (g_force_cfg != 60 && a.Cin == 128 && regw_shape_ok(a)) return launch_regw(a, stream, fmt);
-        // Cin 256: the 8-wave K-split resident kernel (v7): +3.5 % over the 8x16x256 halo tiles on layer3 (781 vs 754 TF/s), +50 % on
-        // the 256 -> 256 cls conv whose 120 halo tiles leave half the chip idle (690 vs 441; the 4-wave v6 kernel: 641 - 704)
-        if (g_force_cfg != 60 && ksplit_shape_ok(a)) return launch_ksplit(a, stream, fmt);
-        // small-channel streaming kernel (DLA level 0 / 1, DCN offset convs): input staged once, HBM-bound instead of LDS-fill-bound
-        if (g_force_cfg != 60 && small_shape_ok(a)) return launch_small(a, stream, fmt);
-        // the same tile walked over 64-channel chunks for the deep offset convs (Cin 128 ... 2176 -> 27): 2-4x over the 256 x 32 tiles
-        if (g_force_cfg != 60 && narrow_shape_ok(a) && !vd3d_switch(VD3D_SW_NO_NARROW)) return launch_narrow(a, stream, fmt);
-        // point-wise expansions with one or two K slices (ResNet-50 conv3 / down-sample of the first two stages): streaming kernel
-        if (g_force_cfg != 60 && pw_shape_ok(a)) return launch_pw(a, stream, fmt);
-        if (g_force_cfg != 60 && a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
-            a.wide_store && !a.out_f32)
-            return launch_resident64(a, stream, fmt);
+        // the resident-weight / streaming kernels (ONE predicate, `special_route`, shared with vd3d_conv2d_workspace_bytes: a shape one
+        // of these takes never splits over K)
+        if (g_force_cfg != 60) switch (special_route(a)) {
+            // register-resident weights (v6), Cin 128: +25 % over the 8x32x128 halo tile on ResNet layer2
+            case ROUTE_REGW: return launch_regw(a, stream, fmt);
+            // Cin 256: the 8-wave K-split resident kernel (v7): +3.5 % over the 8x16x256 halo tiles on layer3 (781 vs 754 TF/s), +50 % on
+            // the 256 -> 256 cls conv whose 120 halo tiles leave half the chip idle (690 vs 441; the 4-wave v6 kernel: 641 - 704)
+            case ROUTE_KSPLIT: return launch_ksplit(a, stream, fmt);
+            // small-channel streaming kernel (DLA level 0 / 1, DCN offset convs): input staged once, HBM-bound instead of LDS-fill-bound
+            case ROUTE_SMALL: return launch_small(a, stream, fmt);
+            // the same tile walked over 64-channel chunks for the deep offset convs (Cin 128 ... 2176 -> 27): 2-4x over the 256 x 32 tiles
+            case ROUTE_NARROW: return launch_narrow(a, stream, fmt);
+            // point-wise expansions with one or two K slices (ResNet-50 conv3 / down-sample of the first two stages): streaming kernel
+            case ROUTE_PW: return launch_pw(a, stream, fmt);
+            case ROUTE_RES64: return launch_resident64(a, stream, fmt);
+            default: break;
+        }
     }
     // low-parallelism shapes with a deep K (batch-1 calls: 1408 -> 1408 at 24 x 80 is 165 tiles for 512 workgroup slots): split-K.
     // 16-bit formats only: the split changes the fp32 summation order with the tile count, i.e. with the batch size -- fp32 is the
     // validation mode, whose results must not depend on how many frames share a call (tests: batch-1 == slice of the batched call)
     if (g_force_cfg == 0 && a.ks_ws && sizeof(T) == 2) {
-        const SplitPlan ps = vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? SplitPlan() : plan_splitk_strip(a);
-        if (ps.splits >= 2 && a.ks_ws_bytes >= ps.ws_bytes) return dispatch_splitk<T>(a, stream, ps);
-        const SplitPlan pl = plan_splitk(a, false);
+        const SplitPlan pl = natural_split_plan(a);
         if (pl.splits >= 2 && a.ks_ws_bytes >= pl.ws_bytes) return dispatch_splitk<T>(a, stream, pl);
     }
     // Cout <= 32: 8 waves of 32 pixels x 32 channels, pipelined loop (+8 % on the ghost 24 -> 24 conv, +27 % on KM3D's 64 -> 27
@@ -1722,17 +1743,10 @@ extern "C" int64_t vd3d_conv2d_workspace_bytes(const vd3d_conv_params* p) {
     if (fill_conv_args(&q, a)) return -1;
     if (g_force_cfg == 144 || g_force_cfg == 130) return plan_splitk(a, true).ws_bytes;
     if (g_force_cfg != 0) return 0;
-    // the split-K path sits behind the resident-weight / streaming kernels in dispatch(): a shape one of those takes never splits
-    if (p->dtype != VD3D_F32) {
-        if ((a.Cin == 128 && regw_shape_ok(a)) || ksplit_shape_ok(a) || small_shape_ok(a) || narrow_shape_ok(a) || pw_shape_ok(a) ||
-            (a.Cin == 64 && a.Cout == 64 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.wide_store && !a.out_f32))
-            return 0;
-    } else {
-        return 0;                                   // fp32 never splits under natural dispatch (see dispatch())
-    }
-    const SplitPlan ps = vd3d_switch(VD3D_SW_NO_STRIP_SPLIT) ? SplitPlan() : plan_splitk_strip(a);
-    if (ps.splits >= 2) return ps.ws_bytes;
-    return plan_splitk(a, false).ws_bytes;
+    // fp32 never splits under natural dispatch (see dispatch()); a shape one of the resident-weight / streaming kernels takes never splits
+    if (p->dtype == VD3D_F32 || special_route(a) != ROUTE_NONE) return 0;
+    const SplitPlan pl = natural_split_plan(a);
+    return pl.splits >= 2 ? pl.ws_bytes : 0;
 }
 
 extern "C" int vd3d_conv2d_pair(const vd3d_conv_params* pa, const vd3d_conv_params* pb, void* stream) {

@@ -80,7 +80,9 @@ class Yolo3D(GraphedForward, nn.Module):
     def test_forward_batched(self, img_batch, P2):
         if not img_batch.is_cuda:
             raise RuntimeError('Yolo3D runs on the MI355X HIP path only: move the model and inputs to cuda')
-        P2 = torch.as_tensor(P2).to(device=img_batch.device)
+        # the calibration in kernel form (contiguous fp32 on the device) BEFORE the graph cache: the graph's static input is then what the
+        # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
+        P2 = torch.as_tensor(P2).to(device=img_batch.device, dtype=torch.float32).contiguous()
         # through the hipGraph cache (lib/graphed.py); post_optimization runs inside get_bboxes_batched, i.e. inside the graph
         return clone_results(self.bbox_head.unpad(self._graphed(img_batch, P2)))
 

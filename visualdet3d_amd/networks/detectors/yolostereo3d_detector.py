@@ -51,7 +51,9 @@ class Stereo3D(GraphedForward, nn.Module):
         cache (lib/graphed.py): the first call for a shape captures ``forward_device``, later calls replay it."""
         if not left_images.is_cuda:
             raise RuntimeError('Stereo3D runs on the MI355X HIP path only: move the model and inputs to cuda')
-        P2 = torch.as_tensor(P2).to(device=left_images.device)
+        # the calibration in kernel form (contiguous fp32 on the device) BEFORE the graph cache: the graph's static input is then what the
+        # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
+        P2 = torch.as_tensor(P2).to(device=left_images.device, dtype=torch.float32).contiguous()
         return clone_results(self.bbox_head.unpad(self._graphed(left_images, right_images, P2)))
 
     @torch.no_grad()

@@ -61,7 +61,8 @@ class AnchorBasedDetection3DHead(nn.Module):
         self._side_streams = {}
         self.overlap_towers = True   # False: run the towers back to back on one stream (per-kernel profiling)
         self.max_candidates = 4096   # per-sample capacity of the device candidate list (power of two <= 8192)
-        self._workspace = None
+        self._workspaces = {}        # candidate scratch per (batch size, capacity, device): never reallocated (hipGraphs bake its address)
+        self._workspace = None       # the one the last call used
         self.overlap_select = True   # candidate selection (needs only the cls logits) on the cls tower's side stream, under the reg tower
         self._preselected = None
 
@@ -125,6 +126,7 @@ class AnchorBasedDetection3DHead(nn.Module):
         """The two towers are independent: the (small) cls tower runs on a side HIP stream so its workgroups fill the
         CUs the reg tower's partially-filled last tile rounds leave idle (fork/join is captured into the hipGraph)."""
         feat = inputs['features']
+        self._p2_conv = None         # a calibration conversion is shared by the stages of ONE forward only (see _device_p2)
         if not self.overlap_towers:
             return self._cls_forward_nhwc(feat), self._reg_forward_nhwc(feat, inputs)
         main = torch.cuda.current_stream()
@@ -208,22 +210,33 @@ class AnchorBasedDetection3DHead(nn.Module):
         return args, kw
 
     def _ensure_workspace(self, B, dev):
-        need = ops._lib.lib().vd3d_head_workspace_bytes(B, self.max_candidates)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
-        return self._workspace
+        """The candidate scratch of a B-frame call.  One buffer per (B, capacity, device), kept for the life of the head: a captured
+        hipGraph bakes the address into its launches, so a buffer that a later, larger call replaced (and handed back to the caching
+        allocator) would be written by every replay of the older graph.  A few hundred KB per batch size."""
+        key = (int(B), int(self.max_candidates), dev)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            need = ops._lib.lib().vd3d_head_workspace_bytes(B, self.max_candidates)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            if not torch.cuda.is_current_stream_capturing():     # (first seen inside a capture: it lives in that graph's private pool
+                self._workspaces[key] = ws                       #  like the activations do, and is not shared with anything else)
+        self._workspace = ws
+        return ws
 
     def _device_p2(self, P2s, dev):
-        """The calibration matrices as a contiguous fp32 device tensor.  Already in that form: returned as is.  Otherwise converted ONCE
-        per source tensor (identity + version), so that the early selection and the NMS stage of one forward see the very same
-        tensor (the preselection key holds its data_ptr)."""
+        """The calibration matrices as a contiguous fp32 device tensor.  Already in that form: returned as is.  Otherwise converted once
+        per FORWARD (``forward_nhwc`` clears the slot), so that the early selection and the NMS stage of one forward see the very same
+        tensor (the preselection key holds its data_ptr).  The slot never outlives a forward and never crosses a capture boundary: a
+        conversion cached during the eager warm-up passes and then HIT inside the capture would leave the conversion out of the graph,
+        and every replay would decode with the warm-up frame's calibration."""
         if P2s.device == dev and P2s.dtype == torch.float32 and P2s.is_contiguous():
             return P2s
+        capturing = torch.cuda.is_current_stream_capturing() if P2s.is_cuda or dev.type == 'cuda' else False
         hit = getattr(self, '_p2_conv', None)
-        if hit is not None and hit[0] is P2s and hit[1] == P2s._version and hit[2].device == dev:
+        if hit is not None and hit[0] is P2s and hit[1] == P2s._version and hit[2].device == dev and hit[3] == capturing:
             return hit[2]
         conv = P2s.to(device=dev, dtype=torch.float32).contiguous()
-        self._p2_conv = (P2s, P2s._version, conv)
+        self._p2_conv = (P2s, P2s._version, conv, capturing)
         return conv
 
     @staticmethod

@@ -45,6 +45,7 @@ class KM3DHead(nn.Module):
         self.clipper = ClipBoxes()
         self._cache = fused.PackCache()
         self.max_peaks = 8192      # per (sample, heat-map channel) capacity of the peak list (LDS sort size)
+        self._workspaces = {}
         self._workspace = None
         self.fuse_head = True        # bf16: the nine head branches in one launch (vd3d_km3d_head_fused)
 
@@ -114,9 +115,16 @@ class KM3DHead(nn.Module):
         dev = hm.device
         K = self.TOPK
         J = self.num_joints
-        need = _lib.lib().vd3d_km3d_workspace_bytes(B, ncls, J, self.max_peaks, K)
-        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
-            self._workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        # one scratch buffer per (batch, capacities, device), kept for the life of the head: hipGraphs bake its address, so it is never
+        # replaced by a larger one (a later B = 16 call must not free the buffer a cached B = 1 graph writes on every replay)
+        wkey = (B, ncls, J, self.max_peaks, K, dev)
+        ws = self._workspaces.get(wkey)
+        if ws is None:
+            need = _lib.lib().vd3d_km3d_workspace_bytes(B, ncls, J, self.max_peaks, K)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            if not torch.cuda.is_current_stream_capturing():     # (first seen inside a capture: private to that graph's pool)
+                self._workspaces[wkey] = ws
+        self._workspace = ws
         scores = torch.empty((B, K), dtype=torch.float32, device=dev)
         boxes = torch.empty((B, K, 11), dtype=torch.float32, device=dev)
         cls = torch.empty((B, K), dtype=torch.int32, device=dev)

@@ -26,7 +26,21 @@ import torch
 from ... import _lib
 
 _VERSION = attrgetter('_version')
-_MAX_GRAPHS = 8          # per model; each holds the activations of its shape in a private pool (LRU beyond that)
+_MAX_GRAPHS = 8          # per model; each holds the activations of its shape in a private pool (least recently USED goes first)
+
+
+def _plain(v):
+    """a hashable, by-value form of a launch-time setting (tuples / lists / numpy scalars / tensors of the anchor filter)"""
+    if isinstance(v, torch.Tensor):
+        return tuple(v.detach().reshape(-1).tolist())
+    if isinstance(v, (list, tuple)):
+        return tuple(_plain(x) for x in v)
+    if hasattr(v, 'item') and not isinstance(v, (int, float, bool)):
+        try:
+            return v.item()
+        except Exception:                        # noqa: BLE001 -- not a scalar: its repr will do
+            return repr(v)
+    return v
 
 
 class _Entry:
@@ -67,8 +81,12 @@ class GraphedForward:
         core = getattr(self, 'core', None)
         tc = getattr(head, 'test_cfg', None)
         knobs = [self.compute_dtype, self.training, _lib.hook_epoch()]
-        for obj, names in ((head, ('overlap_towers', 'overlap_select', 'max_candidates', 'max_peaks', 'TOPK')), (core, ('overlap_neck',))):
-            knobs += [getattr(obj, n, None) for n in names]
+        anchors = getattr(head, 'anchors', None)
+        for obj, names in ((head, ('overlap_towers', 'overlap_select', 'max_candidates', 'max_peaks', 'TOPK')), (core, ('overlap_neck',)),
+                           (anchors, ('filter_y_threshold_min_max', 'filter_x_threshold', 'is_filtering', 'readConfigFile'))):
+            knobs += [_plain(getattr(obj, n, None)) for n in names]
+        for cfg_name in ('loss_cfg',):           # filter_anchor of the loss config is the eval default (detection_3d_head._is_filtering)
+            knobs += [_plain(getattr(getattr(head, cfg_name, None), 'filter_anchor', None))]
         if tc is not None:
             knobs += [repr(sorted(tc.items())) if hasattr(tc, 'items') else repr(tc)]
         return tuple(knobs)
@@ -85,6 +103,8 @@ class GraphedForward:
         ent = st['entries'].get(key)
         if ent is not None and ent.versions != versions:
             ent = None                           # weights changed in place since the capture
+        if ent is not None:
+            st['entries'].move_to_end(key)       # LRU: a hit makes the shape the most recently used
         if ent is None:
             ent = self._capture(inputs, versions)
             st['entries'][key] = ent
