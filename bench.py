@@ -192,6 +192,9 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
     try:
         with torch.no_grad():
             for _ in range(reps):
+                # a ~1 ms spin kernel ahead of every pass: the host gets ahead of the device, so that an event pair brackets the launch's DEVICE time
+                # and not the host's dispatch latency into an idle queue (the first launches of a pass read 2x too long otherwise)
+                torch.cuda._sleep(2_000_000)
                 model.forward_device(*inputs)
         torch.cuda.synchronize()
     finally:
@@ -528,9 +531,9 @@ def time_api_config(c, device, calls=100, warm=10):
         cfg = syn.stereo3d_cfg(tmp, depth=34, score_thr=0.75, nms_iou_thr=0.4)
         syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
     m = DETECTOR_DICT[cfg.name](cfg)
-    # mono: the golden case's head scale (tests/golden/groundaware_*: head_std 0.02) -- with 0.0005 no anchor passed score_thr 0.75 and the timed
-    # decode / NMS ran on an empty candidate list
-    m.load_state_dict(syn.seeded_state_dict(m.state_dict(), seed=1, head_std=0.00042 if c['kind'] == 'stereo' else c.get('head_std', 0.02)))
+    # mono: head scale 0.015 -> 31 candidates / 26 detections on this frame in fp32 (the CPU oracle), a KITTI-like count.  With round 4's 0.0005 no
+    # anchor passed score_thr 0.75 and the timed decode / NMS ran on an empty candidate list; the golden cases' 0.02 gives 151.
+    m.load_state_dict(syn.seeded_state_dict(m.state_dict(), seed=1, head_std=0.00042 if c['kind'] == 'stereo' else c.get('head_std', 0.015)))
     m = m.to(device).eval()
     m.compute_dtype = torch.bfloat16
     P2, P3 = syn.kitti_calib(1280, batch=1)

@@ -293,11 +293,14 @@ def test_splitk_is_what_batch1_dispatch_picks_and_is_deterministic():
     assert torch.equal(a, b)
     orig = _lib.lib().vd3d_conv2d_workspace_bytes
     seen = []
+    assert list(pc.ws_need.values()) == [6 * 40 * 256 * 288 * 4]     # hip_ops asks the library once per launch geometry and remembers the answer
     try:
+        pc.ws_need.clear()
         _lib.lib().vd3d_conv2d_workspace_bytes = lambda p: (seen.append(orig(p)), 0)[1]     # hip_ops then passes no workspace: unsplit
         c = ops.conv2d(x, pc, relu=True)
     finally:
         _lib.lib().vd3d_conv2d_workspace_bytes = orig
+        pc.ws_need.clear()
     assert seen and seen[0] == 6 * 40 * 256 * 288 * 4, seen          # 8 x 5 strip tiles of 256 x 288, six splits (plan_splitk_strip)
     with _lib.test_switch('VD3D_NO_STRIP_SPLIT'):                    # the 128 x 128-tile plan: 15 x 11 tiles, three splits
         assert orig is not None and _lib.lib().vd3d_conv2d_workspace_bytes is orig

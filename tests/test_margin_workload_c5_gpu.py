@@ -136,7 +136,8 @@ def design_hm_head(hid, hid_twin, centres, n_cls, lo_cnt, hi_cnt):
     thr_l = _thr_logit()
     # the gain maps the STRONGEST peak to TOP_LOGIT (beyond ~15 the fp32 sigmoid stops being strictly monotone and neighbours tie); every
     # margin-to-noise ratio is independent of the gain (logit noise scales with it)
-    g = (TOP_LOGIT - thr_l) / (best['top'] - best['l0'][2])
+    # ... except the SCORE error p (1 - p) g nu <= g nu / 4, which the literal bar holds to 1e-3: the gain is capped by the proxy noise
+    g = min((TOP_LOGIT - thr_l) / (best['top'] - best['l0'][2]), 2.5e-3 / best['nu'])
     g = 2.0 ** math.floor(math.log2(g))                                      # a power of two: scales u's fp16 mantissas exactly
     w = torch.zeros(n_cls, C)
     b = torch.full((n_cls,), -9.0)
