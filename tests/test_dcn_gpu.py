@@ -221,14 +221,15 @@ def test_deform_columns_wave_kernel_matches_thread_per_vector_kernel(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize('B,H,W,sigma', [(2, 21, 37, 0.5), (1, 64, 120, 0.5), (2, 16, 24, 4.0), (1, 40, 56, 1.7), (3, 8, 8, 0.3)])
-def test_window_kernel_is_bit_identical_to_the_global_gather_kernel(dtype, B, H, W, sigma):
-    """dcn_win64_kernel (C = O = 64, 3x3 / s1 / p1: corners gathered from an LDS-staged 15 x 15 window, weights resident in LDS,
-    persistent workgroups; opt-in with VD3D_DCN_WINDOW=1) against dcn_nhwc_kernel (the default: every corner through the global-memory path): the same
-    blend order, the same modulation fold, the same K order on the matrix cores -> BIT-IDENTICAL outputs.  sigma = spread of the
-    learned offsets in pixels: 0.5 stays inside the window (the fast path), 4.0 leaves it for most (wave, tap)s (the per-wave
-    fallback), 1.7 mixes both; ragged tile grids (H, W not multiples of 8), image borders, bias + folded BN + ReLU epilogue, and
-    a channel-slice output view.  Both kernels against the oracle once per case."""
+@pytest.mark.parametrize('B,H,W,sigma', [(2, 21, 37, 0.5), (1, 64, 120, 0.5), (2, 16, 24, 4.0), (1, 40, 56, 1.7), (3, 8, 8, 0.3), (2, 33, 50, 40.0)])
+def test_64_to_64_kernel_views_layouts_and_oracle(dtype, B, H, W, sigma):
+    """The 64 -> 64 launch shape of KM3D's full-resolution DLA-Up nodes: dcn_geo64_kernel (round 5: barrier-free K loop, corners from global memory;
+    the four alternative kernels of rounds 3 - 4 were removed from the library, see csrc/deform_conv.hip) BIT-IDENTICAL to the tap-by-tap
+    dcn_nhwc_kernel<T, 64> it replaces (same blend order, modulation fold and k order; `VD3D_DCN_NO_GEO64=1`): sigma = spread of the learned offsets in pixels (0.3 ... 4.0, one sample far
+    outside the image); ragged pixel counts, image borders, bias + folded BN + ReLU epilogue; a channel-slice INPUT view and a channel-slice
+    OUTPUT view give the same bits as dense tensors; the logits as one packed [pixel][32] tensor (what the offset conv writes: staged through LDS)
+    and as separate 18- / 9-channel tensors (the generic loader) give the same bits; and the result against the oracle (pinned to the reference's
+    own im2col code)."""
     from visualdet3d_amd import _lib, hip_ops as ops
     g = torch.Generator().manual_seed(int(B * 1000 + H * 10 + sigma * 7))
     C = O = 64
@@ -242,47 +243,29 @@ def test_window_kernel_is_bit_identical_to_the_global_gather_kernel(dtype, B, H,
     pd = ops.pack_dcn_weight(wt.cuda(), dtype)
     logits = torch.cat([off, msk, torch.zeros(B, H, W, 5)], dim=3).cuda()     # (o1 | o2 | mask | pad) like the offset conv writes it
     kw = dict(bias=bias.cuda(), scale=scale.cuda(), shift=shift.cuda(), stride=(1, 1), padding=(1, 1), dilation=(1, 1), mask_sigmoid=True, relu=True)
+
+    def run(xin, out, o1=logits[..., :18], m1=logits[..., 18:27]):
+        return ops.deform_conv_general(xin, pd, o1, m1, out, 'nhwc', **kw)
+
+    b = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'))
     buf = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
-    with _lib.test_switch('VD3D_DCN_WINDOW'):                     # opt-in kernel (measured slower than the gather kernel: not the default)
-        a = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], buf[..., 64:], 'nhwc', **kw)
-    b = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
-    # round-4 kernels, both opt-in: VD3D_DCN_BF=1 = dcn_bf64_kernel (8 x 16 tiles, corners from an LDS window, blended B fragments in registers,
-    # no barrier in the K loop; corners outside the window -- sigma 4.0: most of them -- per lane from global memory), VD3D_DCN_LWIN=1 = the gather
-    # kernel with its corners from an LDS window.  `b` above is the all-global gather kernel (the default).  Also from a channel-slice INPUT
-    # view (pixel stride 128 elements) with a ragged tile grid, and into a channel-slice OUTPUT view.
-    gk = b
-    with _lib.test_switch('VD3D_DCN_BF'):
-        bf = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
-    assert torch.equal(bf, gk), 'barrier-free kernel differs from the gather kernel: max diff %.3e at sigma %.1f' % ((bf.float() - gk.float()).abs().max().item(), sigma)
-    with _lib.test_switch('VD3D_DCN_LWIN'):
-        lw = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
-    assert torch.equal(lw, gk), 'lds-window gather kernel differs from the gather kernel'
+    a = run(xd, buf[..., 64:])                                                # channel-slice output view
     xwide = torch.full((B, H, W, 128), 9.0, dtype=dtype, device='cuda')
     xwide[..., 64:] = xd
-    for sw in ('VD3D_DCN_BF', 'VD3D_DCN_LWIN'):
-        with _lib.test_switch(sw):
-            bs = ops.deform_conv_general(xwide[..., 64:], pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
-            bo = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
-            ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], bo[..., 64:], 'nhwc', **kw)
-        assert torch.equal(bs, gk), 'window kernels on a channel-slice input view (%s)' % sw
-        assert torch.equal(bo[..., 64:], gk) and bool((bo[..., :64] == 3.0).all()), 'window kernels into a channel-slice output view (%s)' % sw
-    # logits in a layout the coalesced loader of the barrier-free kernel does not take (27 channels, separate mask tensor): its generic path
-    with _lib.test_switch('VD3D_DCN_BF'):
-        bg = ops.deform_conv_general(xd, pd, logits[..., :18].contiguous(), logits[..., 18:27].contiguous(), torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
-    assert torch.equal(bg, gk), 'barrier-free kernel, generic logits layout'
-    buf2 = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
-    with _lib.test_switch('VD3D_DCN_KSPLIT'):                     # the K-split window kernel: two partial sums added in fp32 -> not bit-identical
-        c = ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], buf2[..., :64], 'nhwc', **kw)
+    bs = run(xwide[..., 64:], torch.empty((B, H, W, O), dtype=dtype, device='cuda'))     # channel-slice input view (pixel stride 128 elements)
+    bg = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'), logits[..., :18].contiguous(), logits[..., 18:27].contiguous())
+    with _lib.test_switch('VD3D_DCN_NO_GEO64'):                   # the tap-by-tap kernel (dcn_nhwc_kernel<T, 64>), both of its logit loaders
+        old = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'))
+        with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
+            bn = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'))
+        buf_o = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
+        ao = run(xwide[..., 64:], buf_o[..., 64:])
     torch.cuda.synchronize()
-    assert bool((buf[..., :64] == 3.0).all()) and bool((buf2[..., 64:] == 3.0).all()), 'wrote outside the channel slice'
-    assert torch.equal(a, b), 'max diff %.3e at sigma %.1f' % ((a.float() - b.float()).abs().max().item(), sigma)
-    # K-split: (sum over channels 0-31) + (sum over channels 32-63) instead of one 64-long MFMA chain per tap: same operands, fp32
-    # summation order differs -> within one ulp of the format (+ the summation noise of a 576-long dot product)
-    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
-    dd = (c.float() - b.float()).abs()
-    assert bool((dd <= b.float().abs() * ulp + 3e-5 * b.float().abs().max()).all()), 'k-split kernel: max diff %.3e' % dd.max().item()
-    assert (dd > 0).float().mean().item() < 0.05
-    # and against the oracle (pinned to the reference's own im2col code): same bar as the engine-path test above
+    assert torch.equal(a, b) and bool((buf[..., :64] == 3.0).all()), 'channel-slice output view'
+    assert torch.equal(bs, b), 'channel-slice input view'
+    assert torch.equal(bg, b), 'separate offset / mask tensors (the tap-by-tap kernel takes those) differ from the packed logits (dcn_geo64_kernel)'
+    assert torch.equal(old, b) and torch.equal(bn, b) and torch.equal(ao[..., :], b) and bool((buf_o[..., :64] == 3.0).all()), \
+        'dcn_geo64_kernel is not bit-identical to the tap-by-tap kernel: max diff %.3e at sigma %.1f' % ((old.float() - b.float()).abs().max().item(), sigma)
     rnd = lambda t: t.to(dtype).float()                             # noqa: E731
     y = dcn_ref.deform_conv_forward(rnd(x).permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), torch.sigmoid(msk).permute(0, 3, 1, 2), wt, bias,
                                     1, 1, 1, 1, 1, rnd=rnd)
@@ -296,8 +279,7 @@ def test_opt_in_packed_fp16_blend(C, O, B, H, W):
     """VD3D_DCN_PK16=1 (fp16 only, NOT the default): the four-corner blend on v_pk_fma_f16 with the modulated weights rounded to fp16 --
     what the reference's own half instantiation does (deform_conv_cuda_kernel.cu:467-497 in scalar_t = half), 2 x fewer VALU
     instructions.  Three more fp16 roundings than the default fp32 blend: held to 4 fp16 ulp of the default kernel's output (+ 1e-3 of
-    the scale for the 9 C-long sum of moved products) and to the oracle bar of the engine-path test; with C = O = 64 the LDS-window
-    kernel under the same switch stays bit-identical to the gather kernel."""
+    the scale for the 9 C-long sum of moved products) and to the oracle bar of the engine-path test."""
     from visualdet3d_amd import _lib, hip_ops as ops
     g = torch.Generator().manual_seed(C + H)
     dtype = torch.float16
@@ -316,16 +298,7 @@ def test_opt_in_packed_fp16_blend(C, O, B, H, W):
 
     base = run()
     with _lib.test_switch('VD3D_DCN_PK16'):
-        pk = run()                                       # the gather kernel
-        if C == 64 and O == 64:
-            gk = pk
-            with _lib.test_switch('VD3D_DCN_BF'):
-                pk = run()
-            with _lib.test_switch('VD3D_DCN_LWIN'):
-                lw = run()
-            with _lib.test_switch('VD3D_DCN_WINDOW'):
-                win = run()
-            assert torch.equal(gk, pk) and torch.equal(win, pk) and torch.equal(lw, pk), 'the 64 -> 64 kernels differ under the packed blend'
+        pk = run()
     torch.cuda.synchronize()
     assert not torch.equal(pk, base), 'the switch selected nothing'
     d = (pk.float() - base.float()).abs()
@@ -354,8 +327,9 @@ def test_logit_staging_of_the_gather_kernel_is_bit_identical(dtype, C, O, B, H, 
     def run():
         return ops.deform_conv_general(x, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
 
-    a = run()
-    with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
-        b = run()
+    with _lib.test_switch('VD3D_DCN_NO_GEO64'):               # (16-bit 64 -> 64 would otherwise run dcn_geo64_kernel, which has one loader only)
+        a = run()
+        with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
+            b = run()
     torch.cuda.synchronize()
     assert torch.equal(a, b), 'max diff %.3e' % (a.float() - b.float()).abs().max().item()

@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
     // writes) are STAGED through LDS first: two fully coalesced 16-byte loads per thread (8 lanes = one pixel's 128 bytes) into the first
     // operand stage (idle until the K loop), rows padded to 33 floats so that the per-pixel reads below are bank-conflict free.  Read from global
     // memory lane = pixel, every one of the nine 4-byte loads per thread touched 64 different cache lines (timing ablation of the same phase in
-    // dcn_lw64_kernel: 51 of 372 us).  Any other layout (NCHW offsets of the reference's extension entry points, 27-channel tensors) keeps the old path.
+    // the round-4 LDS-window variant of this kernel: 51 of 372 us).  Any other layout (NCHW offsets of the reference's extension entry points, 27-channel tensors) keeps the old path.
     const bool packed_logits = !p.no_lstage && KK == 9 && p.mask && p.off_sc == 1 && p.msk_sc == 1 && p.mask == p.offset + 18 && p.msk_sb == p.off_sb &&
                                p.msk_sy == p.off_sy && p.msk_sx == p.off_sx && (p.off_sx & 3) == 0 && (p.off_sy & 3) == 0 && (p.off_sb & 3) == 0 &&
                                p.off_sx >= 28 && ((uintptr_t)p.offset & 15) == 0;
@@ -556,1200 +556,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
         }
 }
 
-// ---- 64 -> 64 channel DCNv2 3x3 / s1 / p1 (round 4, OPT-IN VD3D_DCN_LWIN=1): dcn_nhwc_kernel with its corners read from LDS ----------------
-// MEASURED (16 x 128 x 440 fp16, same box): 389 us against 396 us for the gather kernel at offsets sigma 0.3, 398 / 402 at 1.5, 456 / 410 at 4.0;
-// config 5 9.59 against 9.44 ms per step.  Taking 260 KB of gathers per workgroup off the L1 request path changed NOTHING: the hypothesis of
-// round 2 / 3 ("bound by the 64 B / clk texture path") is refuted -- see the ablations in front of dcn_bf64_kernel.
-// dcn_nhwc_kernel<T, 64> is bound by the CU's L1 / texture request path (64 B / clk): per 64-pixel workgroup and tap every thread issues
-// 8 corner gathers of 16 B, i.e. 295 KB of gathers + 74 KB of weights per workgroup, 5.1 GB per launch at 16 x 128 x 440 = 150 us of
-// request-path time under a 350 us kernel -- every input pixel passes through L1 ~36 times.  Two earlier attempts moved the corners to an
-// LDS window (dcn_win64 / dcn_ks64 below, opt-in): both persistent, one wave or two per SIMD, and both lost to their own per-tile
-// synchronisation (3.4 us of barrier / geometry / bookkeeping per 64-pixel tile with nothing else on the CU to run meanwhile).
-// This kernel changes ONE thing about the gather kernel and keeps everything that hides its latencies -- one tile per workgroup, four
-// waves, several workgroups per CU running out of phase, geometry table in LDS, the weight tile of a tap through registers into LDS, the
-// blended columns as an LDS tile feeding 32x32x16 MFMAs, one barrier per tap:
-//   * the workgroup's 64 pixels are an 8 x 8 TILE; its (8 + 2 * 3 + 1)^2 = 15 x 15-pixel input window (28.1 KB) is staged ONCE by LDS-DMA at
-//     kernel start (29 pieces, under the geometry phase; out-of-image pixels arrive as zeros);
-//   * a corner is one ds_read_b128 from the window (XOR-swizzled on the 16-byte slot by the window pixel: the eight lanes of a pixel read
-//     its 128 contiguous bytes) -- the geometry entry holds the corner's LDS offset;
-//   * a corner that lies outside the window (a learned offset beyond ~2 pixels) keeps its GLOBAL offset in the entry (sign bit set) and is
-//     fetched exactly as before, per lane, behind a wave-uniform "any such corner in this wave?" test: the cost grows with the number of
-//     far samples instead of falling off a cliff (config 5's five full-resolution launches: 0 - 17 % of the samples beyond 2 pixels).
-// Request-path bytes per workgroup: 29 KB window + 74 KB weights + 7 KB logits instead of 370 KB.  LDS: 2 x 16 KB stages + 18 KB geometry +
-// 29 KB window + constants = 79.75 KB: two workgroups per CU (the gather kernel: three).  Same blend order, same modulation fold, same k
-// order on the matrix cores: BIT-IDENTICAL to dcn_nhwc_kernel (tests/test_dcn_gpu.py).
-constexpr int kLwP = 3, kLwD = 8 + 2 * kLwP + 1, kLwPix = kLwD * kLwD;                   // 15 x 15 window pixels
-constexpr int kLwPieces = (kLwPix * 8 + 63) / 64, kLwWin = kLwPieces * 1024;              // 29 DMA pieces of 1 KiB
-constexpr int kLwStage = (64 + 64) * 128, kLwGeo = 2 * kLwStage, kLwCtab = kLwGeo + 9 * 64 * 32, kLwWinOff = kLwCtab + 3 * 64 * 4;
-constexpr int kLwLds = kLwWinOff + kLwWin;                                                // 81 664 B
+// ---- 64 -> 64 channel DCNv2 (KM3D's five full-resolution DLA-Up nodes): what was built, measured and REMOVED from the product library ----
+// Four alternatives to dcn_nhwc_kernel<T, 64> were built in rounds 3 - 4, each bit-identical (or within 1 ulp) to it and each measured
+// SLOWER or equal inside the model; they shipped as opt-in switches until round 5 and live on in the history (last present in commit
+// 3b99961, csrc/deform_conv.hip: dcn_win64_kernel -- corners from an LDS-staged 15 x 15 window, weights resident in LDS, persistent;
+// dcn_ks64_kernel -- the same with the weights K-split over the registers of 8 waves; dcn_lw64_kernel -- the gather kernel with its corners
+// from an LDS window; dcn_bf64_kernel -- barrier-free K loop, the blended vector is the MFMA B fragment).  What they established
+// (DESIGN.md sections 9, 10, 11): the operator is bound by VALU issue, not by the L1 request path (taking 70 % of the gathers off that path
+// changed nothing); the exact fp32 blend of 16-bit data is 32 v_fma_mix per 8 channels, corner and tap -- 36 wave-instructions per output pixel
+// before any geometry, address arithmetic or epilogue; every variant runs 73 - 78 wave-instructions per pixel at 40 - 75 % VALU utilisation.
+// The packed fp16 blend (dcn_blend8_pk above, OPT-IN, halves the blend) stays outside the 2-ulp bar the teacher-forced tests hold this path to.
 
-template <typename T>
-__global__ void __launch_bounds__(256) dcn_lw64_kernel(const DcnArgs p, int tiles_x) {
-    static_assert(sizeof(T) == 2, "16-bit formats only");
-    constexpr int ES = 2, VE = 8, BN = 64, KK = 9, GE = 32, WV = 2;
-    constexpr uint32_t kDcnOOB = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* geo_tab = smem + kLwGeo;                   // [tap][64 pixels] x {int32 a[4], float w[4]}
-    float* ctab = (float*)(smem + kLwCtab);
-    char* win = smem + kLwWinOff;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int ty0 = tyi * 8, tx0 = txi * 8;
-    const int wy0 = ty0 - kLwP, wx0 = tx0 - kLwP;    // image coordinates of window pixel (0, 0)
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in + (int64_t)b * p.in_sb * ES), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 64 * p.Kpad * ES, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// Round 5, a fifth one, built and removed in the same round (commit "EXPERIMENT dcn_geo64" in the history): the barrier-free kernel WITHOUT the LDS
+// window -- lane (pixel n, k-group g) gathers its own four corners straight from global memory and the blended vector is the MFMA B fragment; evenly
+// spread geometry phase, 63 wave-instructions per pixel (ISA count; the tap-by-tap kernel: 78), 51 KB of LDS and 137 - 165 registers: three workgroups per
+// CU; bit-identical.  MEASURED (16 x 128 x 440 fp16, one box): 698 / 720 / 646 us at offsets sigma 0.5 / 1.5 / 40 px against 358 / 375 / 385 us for
+// dcn_nhwc_kernel<T, 64>; config 5 11.0 against 9.1 ms per step.  TWICE as slow with 20 % fewer instructions: in the fragment mapping a corner load is
+// 16 pixels x 64 contiguous bytes (and an A-fragment load 16 weight rows x 64 bytes) -- 16 half-used cache lines per instruction where the gather mapping
+// of dcn_nhwc_kernel (eight lanes = one pixel's 128-byte run) touches 8 whole ones; the vector memory path serves scattered 16-byte lanes at about half
+// the rate.  The round-4 barrier-free kernel only looked viable because its corners came from LDS.  Lesson: for this operator the 8-lanes-per-pixel gather
+// mapping is not negotiable, so the blended columns MUST change lanes before the MFMA (an LDS tile), and with them comes the per-tap skeleton.
 
-    // ---- the window: piece q = wave + 4 it, chunk c = 64 q + lane -> window pixel pp = c >> 3, physical slot c & 7 holds the logical
-    // vector (slot ^ key(pp)), key(pp) = (pp >> 1) & 7 (the swizzle is applied to the SOURCE address: the DMA writes lane-linear)
-#pragma unroll
-    for (int it = 0; it < (kLwPieces + 3) / 4; ++it) {
-        const int q = wave + 4 * it;
-        if (q < kLwPieces) {                         // wave-uniform
-            const int c = q * 64 + lane, pp = c >> 3, v = (c & 7) ^ ((pp >> 1) & 7);
-            const int wy = pp / kLwD, wx = pp - wy * kLwD;
-            const int iy = wy0 + wy, ix = wx0 + wx;
-            const bool ok = pp < kLwPix && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint32_t off = ok ? (uint32_t)((iy * p.in_sy + ix * p.in_sx + v * VE) * ES) : kDcnOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(win + q * 1024), 16, off, 0, 0, 0);
-        }
-    }
-    for (int i = tid; i < BN; i += 256) {
-        ctab[i] = p.bias ? p.bias[i] : 0.f;
-        ctab[BN + i] = p.scale ? p.scale[i] : 1.f;
-        ctab[2 * BN + i] = p.shift ? p.shift[i] : 0.f;
-    }
-    // ---- phase 0: the sampling geometry of every (pixel, tap) of the tile, once, into LDS (as dcn_nhwc_kernel: a thread owns pixel `lane`
-    // and every fourth tap; the logits of three taps are requested up front)
-    {
-    const int px = lane;
-    const int oy = ty0 + (px >> 3), ox = tx0 + (px & 7);
-    const bool pvalid = oy < p.Ho && ox < p.Wo;
-    const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
-    const int64_t mb = b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx;
-    constexpr int TPW = 3;
-    float oh[TPW], ow[TPW], ml[TPW];
-#pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        const int tap = wave + 4 * u;
-        oh[u] = ow[u] = ml[u] = 0.f;
-        if (tap < KK && pvalid) {
-            oh[u] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
-            ow[u] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
-            if (p.mask) ml[u] = p.mask[mb + (int64_t)tap * p.msk_sc];
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-        const int tap = wave + 4 * u;
-        if (tap >= KK) break;
-        int ga[4] = {0, 0, 0, 0};                    // LDS offset 0: finite data, weight 0
-        float gw[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pvalid) {
-            const int ti = tap / 3, tj = tap - ti * 3;
-            const float h_im = (float)(oy - 1 + ti) + oh[u];
-            const float w_im = (float)(ox - 1 + tj) + ow[u];
-            if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                float m = 1.f;
-                if (p.mask) {
-                    m = ml[u];
-                    if (p.mask_sigmoid) m = __frcp_rn(1.0f + __expf(-m));
-                }
-                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int hc = h_low + (c >> 1), wc = w_low + (c & 1);
-                    if ((unsigned)hc < (unsigned)p.H && (unsigned)wc < (unsigned)p.W) {
-                        gw[c] = cw[c] * m;           // the modulation folded into the weights (16-bit formats), as dcn_nhwc_kernel
-                        const int wy = hc - wy0, wx = wc - wx0;
-                        if ((unsigned)wy < (unsigned)kLwD && (unsigned)wx < (unsigned)kLwD) {
-                            const int pp = wy * kLwD + wx;
-                            ga[c] = pp * 128 + (((pp >> 1) & 7) << 4);
-                        } else {
-                            ga[c] = (int)(0x80000000u | ((uint32_t)((hc * p.in_sy + wc * p.in_sx) * ES) >> 4));   // global: byte offset / 16
-                        }
-                    }
-                }
-            }
-        }
-        const int it = tap * 64 + px;
-        *(i32x4*)(geo_tab + (size_t)it * GE) = i32x4{ga[0], ga[1], ga[2], ga[3]};
-        *(f32x4*)(geo_tab + (size_t)it * GE + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
-    }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's window pieces have landed
-    __syncthreads();                                        // ... everybody's; the geometry table is complete
-
-    // Sampling map of the K loop (as dcn_nhwc_kernel): 8 consecutive lanes own the 8 16-byte vectors of ONE pixel's 128-byte channel run;
-    // a thread handles pixels prow0 and prow0 + 32, vector vslot
-    const int prow0 = tid >> 3, vslot = tid & 7, vs = vslot << 4;
-    struct Geo { int32_t a[4]; float w[4]; };
-    auto geometry = [&](int tap, int prow) {
-        Geo g;
-        const char* e = geo_tab + (size_t)(tap * 64 + prow) * GE;
-        const i32x4 ga = *(const i32x4*)e;
-        const f32x4 gw = *(const f32x4*)(e + 16);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { g.a[c] = ga[c]; g.w[c] = gw[c]; }
-        return g;
-    };
-    int w_voff[WV];
-#pragma unroll
-    for (int i = 0; i < WV; ++i) {
-        const int v = tid + 256 * i;
-        w_voff[i] = ((v >> 3) * p.Kpad + (v & 7) * VE) * ES;
-    }
-    Geo geo[2];
-    auto fetch = [&](int kt, i32x4 (&cv)[2][4], i32x4 (&wv)[WV]) {
-        geo[0] = geometry(kt, prow0);
-        geo[1] = geometry(kt, prow0 + 32);
-#pragma unroll
-        for (int i = 0; i < WV; ++i)
-            wv[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_voff[i], kt * 128, 0));
-        int far = 0;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int a = geo[i].a[c];
-                far |= a;
-                cv[i][c] = *(const i32x4*)(win + (a < 0 ? 0 : (a ^ vs)));
-            }
-        if (__builtin_amdgcn_ballot_w64(far < 0) != 0) {       // wave-uniform: some corner of this wave's samples lies outside the window
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int a = geo[i].a[c];
-                    if (a < 0) cv[i][c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(((uint32_t)a & 0x7fffffffu) << 4) + vs, 0, 0));
-                }
-        }
-    };
-    // registers -> LDS stage: blend the four corners (fp32, the gather kernel's order), round, store swizzled
-    auto stash = [&](int st, const i32x4 (&cv)[2][4], const i32x4 (&wv)[WV]) {
-        char* Cs = smem + st * kLwStage;
-        char* Ws = Cs + 64 * 128;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            Vec16<T> c1, c2, c3, c4, o;
-            c1.raw = cv[i][0]; c2.raw = cv[i][1]; c3.raw = cv[i][2]; c4.raw = cv[i][3];
-            float vals[VE];
-            bool packed = false;
-            if constexpr (std::is_same<T, hf16>::value) {
-                if (p.pk16) {
-                    o.raw = dcn_blend8_pk(cv[i][0], cv[i][1], cv[i][2], cv[i][3], dcn_pk_weight(geo[i].w[0]), dcn_pk_weight(geo[i].w[1]),
-                                          dcn_pk_weight(geo[i].w[2]), dcn_pk_weight(geo[i].w[3]));
-                    packed = true;
-                } else {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        vals[2 * d] = mix_fma_lo(cv[i][3][d], geo[i].w[3], mix_fma_lo(cv[i][2][d], geo[i].w[2], mix_fma_lo(cv[i][1][d], geo[i].w[1], mix_mul_lo(cv[i][0][d], geo[i].w[0]))));
-                        vals[2 * d + 1] = mix_fma_hi(cv[i][3][d], geo[i].w[3], mix_fma_hi(cv[i][2][d], geo[i].w[2], mix_fma_hi(cv[i][1][d], geo[i].w[1], mix_mul_hi(cv[i][0][d], geo[i].w[0]))));
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < VE; ++e)
-                    vals[e] = fmaf(geo[i].w[3], c4.get(e), fmaf(geo[i].w[2], c3.get(e), fmaf(geo[i].w[1], c2.get(e), geo[i].w[0] * c1.get(e))));
-            }
-            if (!packed) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
-            }
-            const int row = prow0 + 32 * i;
-            *(i32x4*)(Cs + row * 128 + ((vslot ^ ((row >> 1) & 7)) << 4)) = o.raw;
-        }
-#pragma unroll
-        for (int i = 0; i < WV; ++i) {
-            const int v = tid + 256 * i, row = v >> 3, slot = v & 7;
-            *(i32x4*)(Ws + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4)) = wv[i];
-        }
-    };
-
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int wn = wave & 1, wm = wave >> 1;         // 2 x 2 waves over (out-channel halves, pixel halves)
-    const int lr = lane & 31, half = lane >> 5;
-    i32x4 cv[2][4], wv[WV];
-    fetch(0, cv, wv);
-    stash(0, cv, wv);
-    __syncthreads();
-    for (int kt = 0; kt < KK; ++kt) {
-        const int st = kt & 1;
-        const bool more = kt + 1 < KK;
-        if (more) fetch(kt + 1, cv, wv);
-        const char* Cs = smem + st * kLwStage;
-        const char* Ws = Cs + 64 * 128;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int sk = 2 * ks + half;
-            const int rc = wm * 32 + lr, rw = wn * 32 + lr;
-            const i32x4 fb = *(const i32x4*)(Cs + rc * 128 + ((sk ^ ((rc >> 1) & 7)) << 4));
-            const i32x4 fa = *(const i32x4*)(Ws + rw * 128 + ((sk ^ ((rw >> 1) & 7)) << 4));
-            DMma<T>::run(fa, fb, acc);
-        }
-        if (more) stash(st ^ 1, cv, wv);
-        __syncthreads();
-    }
-    // ---- epilogue: bias, folded BN, ReLU; 4 consecutive channels per accumulator quad -> 8-byte NHWC stores ----
-    const int px = wm * 32 + lr;
-    const int oy = ty0 + (px >> 3), ox = tx0 + (px & 7);
-    if (oy >= p.Ho || ox >= p.Wo) return;
-    const int64_t ob = b * p.out_sb + oy * p.out_sy + ox * p.out_sx;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int lc = wn * 32 + 8 * g + 4 * half;
-        const f32x4 bz = *(const f32x4*)(ctab + lc), sc = *(const f32x4*)(ctab + BN + lc), sh = *(const f32x4*)(ctab + 2 * BN + lc);
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = (acc[4 * g + e] + bz[e]) * sc[e] + sh[e];
-            if (p.relu) x = fmaxf(x, 0.f);
-            v[e] = x;
-        }
-        i32x2 o2;
-        o2[0] = Fmt16<T>::pack2(v[0], v[1]);
-        o2[1] = Fmt16<T>::pack2(v[2], v[3]);
-        *(i32x2*)((char*)p.out + (ob + lc) * 2) = o2;
-    }
-}
-
-// ---- 64 -> 64 channel DCNv2 3x3 / s1 / p1, barrier-free K loop (round 4, OPT-IN VD3D_DCN_BF=1) ---------------------------------------------
-// Timing ablations of dcn_lw64_kernel above (16 x 128 x 440 fp16, 372 us; results wrong by construction, removed again): no corner reads
-// -25 us, no weight loads -24, no blend -40, no logit loads -51, no MFMA -23, ALL of them off: still 232 us -- the skeleton of "one tap at a
-// time: registers -> LDS column tile -> barrier -> fragments -> 4 MFMAs per wave" (ten barriers and ~0.3 MB of LDS staging traffic per 64-pixel
-// workgroup, two or three workgroups per CU) is 62 % of the kernel, whichever way the corners arrive.  This kernel has ONE barrier:
-//   * a workgroup owns an 8 x 16 tile; window (15 x 23 pixels, 43 KB, LDS-DMA) and geometry table (128 pixels x 9 taps x 32 B) as above;
-//   * a wave owns 32 pixels (two rows of the tile) x ALL 64 output channels on v_mfma_f32_16x16x32: lane (pixel n, k-group g) blends exactly
-//     the 8 channels it multiplies -- the blended vector IS the B fragment, no column tile, no barrier, the waves of a workgroup never meet
-//     again after the geometry phase (the operand mapping of dcn_win64_kernel);
-//   * the A fragments (weights, 16 output channels x 32 k) come straight from the packed [O][Kpad] matrix through the vector cache: one
-//     16-byte load per lane, shared by the wave's two pixel blocks; every wave streams the 72 KB panel once per 32 pixels (2.3 KB per
-//     pixel through the request path, 2.6 with the window, against 5.8 in the gather kernel);
-//   * corners outside the window: per lane from global memory, as above; outputs leave as whole 128-byte lines through the wave's own (dead)
-//     slice of the geometry table.
-// Same blend, same fold, same k order: bit-identical to the gather kernel.  LDS 81 664 B: two workgroups (8 waves) per CU.
-// MEASURED (16 x 128 x 440 fp16, same box, gather kernel 372 / 390 / 402 us at offsets sigma 0.3 / 1.5 / 4.0): first version (nine taps fully
-// unrolled, logits as fifteen strided 4-byte loads per thread) 351 / 384 / 494 us; + rolled tap loop (the unrolled kernel was 80 KB of code), coalesced
-// logits, software-pipelined taps: 345 / 388 us; config 5 9.21 against 9.06 ms per step -- NOT faster inside the model, hence opt-in: under rocprofv3 the
-// model's five 64 -> 64 launches take 319 - 331 us on the gather kernel and 331 - 384 us here (profiles/r04_c5_timeline_*.txt) -- the model's offsets are smooth, so the
-// gathers of neighbouring pixels hit the same cache lines; the micro-benchmark's independent random offsets (372 us) flatter every window design.  Cycle stamps of
-// one workgroup (tools/dcn_stamps.py, -DVD3D_STAMPS): 50k cycles = logits + window issue 5k, geometry 12-13k, drain + barrier 6k, nine taps 2.0-2.4k each
-// (21k; 2-4k before the pipelining), epilogue 4k.  Instruction count: ~12k wave-instructions of VALU per 128-pixel workgroup (geometry ~110 per
-// (pixel, tap), run on 5 of 8 lanes; blend 128 v_fma_mix + 16 conversions per tap and lane) = 157 us per launch at 100 % VALU issue: every variant of
-// this operator -- gather, LDS window, K-split, barrier-free -- sits at 40-45 % of THAT bound with 8-12 waves per CU.  What is left: a geometry fast
-// path (all four corners inside image and window: one test instead of four, ~50 instead of ~110 instructions), the ninth tap spread over the idle
-// lanes, and the packed fp16 blend (halves the K loop's VALU; outside the 2-ulp bar, see dcn_blend8_pk).
-#ifdef VD3D_STAMPS
-__device__ unsigned long long g_stamps[4][32];
-#define STAMP(i) do { if (blockIdx.x == 200 && blockIdx.z == 5 && lane == 0) g_stamps[wave][i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i) do {} while (0)
-#endif
-constexpr int kBfTH = 8, kBfTW = 16, kBfWR = kBfTH + 2 * kLwP + 1, kBfWC = kBfTW + 2 * kLwP + 1;     // window 15 rows x 23 columns
-constexpr int kBfPieces = 43, kBfWinPix = kBfPieces * 8, kBfWin = kBfPieces * 1024;                     // 344 of the 345 pixels (the last one: "far")
-constexpr int kBfGeoWave = 9 * 32 * 32, kBfGeo = 4 * kBfGeoWave;                                        // [wave][tap][32 pixels] x 32 B
-constexpr int kBfWinOff = kBfGeo, kBfLds = kBfWinOff + kBfWin + 768;                                    // 81 664 B
-
-template <typename T, bool PK>
-__global__ void __launch_bounds__(256) dcn_bf64_kernel(const DcnArgs p, int tiles_x) {
-    static_assert(sizeof(T) == 2, "16-bit formats only");
-    constexpr int ES = 2, KK = 9;
-    constexpr uint32_t kDcnOOB = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* geo_tab = smem;
-    char* win = smem + kBfWinOff;
-    float* ctab = (float*)(smem + kBfWinOff + kBfWin);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z;
-    const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
-    const int ty0 = tyi * kBfTH, tx0 = txi * kBfTW;
-    const int wy0 = ty0 - kLwP, wx0 = tx0 - kLwP;
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.in + (int64_t)b * p.in_sb * ES), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 64 * p.Kpad * ES, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    STAMP(0);
-
-    // One geometry entry: (pixel of the tile, tap, its three logits) -> {LDS offset | global offset of the four corners, modulated weights}
-    auto write_entry = [&](int prow, int pcol, int tap, bool pvalid, float off_h, float off_w, float mlog) {
-        int ga[4] = {0, 0, 0, 0};                    // LDS offset 0: finite data, weight 0
-        float gw[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pvalid) {
-            const int ti = tap / 3, tj = tap - ti * 3;
-            const float h_im = (float)(ty0 + prow - 1 + ti) + off_h;
-            const float w_im = (float)(tx0 + pcol - 1 + tj) + off_w;
-            if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                float m = 1.f;
-                if (p.mask) {
-                    m = mlog;
-                    if (p.mask_sigmoid) m = __frcp_rn(1.0f + __expf(-m));
-                }
-                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int hc = h_low + (c >> 1), wc = w_low + (c & 1);
-                    if ((unsigned)hc < (unsigned)p.H && (unsigned)wc < (unsigned)p.W) {
-                        gw[c] = cw[c] * m;           // the modulation folded into the weights (16-bit formats), as dcn_nhwc_kernel
-                        const int wy = hc - wy0, wx = wc - wx0;
-                        const int pp = wy * kBfWC + wx;
-                        if ((unsigned)wy < (unsigned)kBfWR && (unsigned)wx < (unsigned)kBfWC && pp < kBfWinPix)
-                            ga[c] = pp * 128 + (((pp >> 1) & 7) << 4);
-                        else
-                            ga[c] = (int)(0x80000000u | ((uint32_t)((hc * p.in_sy + wc * p.in_sx) * ES) >> 4));   // global: byte offset / 16
-                    }
-                }
-            }
-        }
-        // entry of (wave prow >> 1, tap, pixel (prow & 1) * 16 + pcol)
-        char* e = geo_tab + (prow >> 1) * kBfGeoWave + (tap * 32 + (prow & 1) * 16 + pcol) * 32;
-        *(i32x4*)e = i32x4{ga[0], ga[1], ga[2], ga[3]};
-        *(f32x4*)(e + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
-    };
-    // The logits of the tile.  Fast layout (what the offset conv of the engine writes: one pixel = 32 contiguous fp32 = offsets 0..17 | mask
-    // 18..26 | pad, 16-byte aligned): FOUR fully coalesced 16-byte loads per thread (8 lanes = one pixel's 128 bytes) instead of fifteen
-    // 4-byte loads at a 128-byte stride (64 cache lines per instruction: the geometry phase was 13k of a workgroup's 54k cycles, cycle stamps).
-    const bool packed_logits = p.mask && p.off_sc == 1 && p.msk_sc == 1 && p.mask == p.offset + 18 && p.msk_sb == p.off_sb && p.msk_sy == p.off_sy &&
-                               p.msk_sx == p.off_sx && (p.off_sx & 3) == 0 && (p.off_sy & 3) == 0 && (p.off_sb & 3) == 0 && p.off_sx >= 28 &&
-                               ((uintptr_t)p.offset & 15) == 0;
-    f32x4 lg[4];
-    float oh[5], ow[5], ml[5];
-    if (packed_logits) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int px = (tid >> 3) + 32 * r, v = tid & 7;
-            const int oy = ty0 + (px >> 4), ox = tx0 + (px & 15);
-            lg[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (oy < p.Ho && ox < p.Wo && v < 7) lg[r] = *(const f32x4*)(p.offset + b * p.off_sb + oy * p.off_sy + ox * p.off_sx + 4 * v);
-        }
-    } else {
-        const int px = tid & 127, par = tid >> 7;
-        const int oy = ty0 + (px >> 4), ox = tx0 + (px & 15);
-        const bool pvalid = oy < p.Ho && ox < p.Wo;
-        const int64_t ob = b * p.off_sb + oy * p.off_sy + ox * p.off_sx;
-        const int64_t mb = b * p.msk_sb + oy * p.msk_sy + ox * p.msk_sx;
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int tap = par + 2 * u;
-            oh[u] = ow[u] = ml[u] = 0.f;
-            if (tap < KK && pvalid) {
-                oh[u] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
-                ow[u] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
-                if (p.mask) ml[u] = p.mask[mb + (int64_t)tap * p.msk_sc];
-            }
-        }
-    }
-    STAMP(1);
-    // ---- the window (as dcn_lw64_kernel: physical slot c & 7 of window pixel pp holds the logical vector (c & 7) ^ key(pp)); issued while
-    // the logits travel ----
-#pragma unroll
-    for (int it = 0; it < (kBfPieces + 3) / 4; ++it) {
-        const int q = wave + 4 * it;
-        if (q < kBfPieces) {
-            const int c = q * 64 + lane, pp = c >> 3, v = (c & 7) ^ ((pp >> 1) & 7);
-            const int wy = pp / kBfWC, wx = pp - wy * kBfWC;
-            const int iy = wy0 + wy, ix = wx0 + wx;
-            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const uint32_t off = ok ? (uint32_t)((iy * p.in_sy + ix * p.in_sx + v * 8) * ES) : kDcnOOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(win + q * 1024), 16, off, 0, 0, 0);
-        }
-    }
-    if (tid < 64) {
-        ctab[tid] = p.bias ? p.bias[tid] : 0.f;
-        ctab[64 + tid] = p.scale ? p.scale[tid] : 1.f;
-        ctab[128 + tid] = p.shift ? p.shift[tid] : 0.f;
-    }
-    STAMP(2);
-    if (packed_logits) {
-        // lane v (0..4) of a pixel's 8-lane group owns taps 2v and 2v + 1: their offsets are components (0, 1) / (2, 3) of its own vector, their
-        // mask logits (18 + tap) sit in the vector of lane 4 + (v + 1) / 2 of the same group, components (2, 3) for even v, (0, 1) for odd v
-        const int v = tid & 7;
-        const int src = ((lane & ~7) + 4 + ((v + 1) >> 1)) << 2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int px = (tid >> 3) + 32 * r;
-            const int prow = px >> 4, pcol = px & 15;
-            const bool pvalid = ty0 + prow < p.Ho && tx0 + pcol < p.Wo;
-            float x[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) x[c] = i2f(__builtin_amdgcn_ds_bpermute(src, f2i(lg[r][c])));
-            const float m0 = (v & 1) ? x[0] : x[2], m1 = (v & 1) ? x[1] : x[3];
-            if (v < 5) write_entry(prow, pcol, 2 * v, pvalid, lg[r][0], lg[r][1], m0);
-            if (v < 4) write_entry(prow, pcol, 2 * v + 1, pvalid, lg[r][2], lg[r][3], m1);
-        }
-    } else {
-        const int px = tid & 127, par = tid >> 7;
-        const int prow = px >> 4, pcol = px & 15;
-        const bool pvalid = ty0 + prow < p.Ho && tx0 + pcol < p.Wo;
-#pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int tap = par + 2 * u;
-            if (tap < KK) write_entry(prow, pcol, tap, pvalid, oh[u], ow[u], ml[u]);
-        }
-    }
-    STAMP(3);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(4);
-    __syncthreads();                                  // the ONLY barrier: window, geometry table and constants are in LDS
-    STAMP(5);
-
-    // ---- K loop: tap-major, two 32-channel k-steps per tap; lane (n, g): pixel n of a 16-pixel block, k-group g ----
-    const int n = lane & 15, g = lane >> 4;
-    const char* G0 = geo_tab + wave * kBfGeoWave;
-    const int wlane = ((lane & 15) * p.Kpad + g * 8) * ES;        // A fragment: row blk * 16 + (lane & 15), k = tap * 64 + s * 32 + g * 8 ..
-    const int wblk = 16 * p.Kpad * ES;
-    f32x4 acc[2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) acc[j][blk] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // does ANY sample of this wave's 32 pixels leave the window?  (wave-uniform; the common case runs without a branch per corner)
-    bool wave_far = false;
-    {
-        int f = 0;
-#pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int e = r * 64 + lane;                       // 288 entries of this wave
-            if (e < 288) {
-                const i32x4 a = *(const i32x4*)(G0 + e * 32);
-                f |= a[0] | a[1] | a[2] | a[3];
-            }
-        }
-        wave_far = __builtin_amdgcn_ballot_w64(f < 0) != 0;
-    }
-    STAMP(6);
-    // The taps as a ROLLED loop, two taps per trip (fully unrolled with both corner paths and both blends the kernel was 9.8k instructions,
-    // 80 KB: more than the instruction cache two CUs share), SOFTWARE-PIPELINED by hand: nothing a (k-step, pixel block) unit consumes is
-    // requested inside that unit -- the A fragments and the geometry entries of tap t + 1 are requested at the top of tap t, the four corner
-    // vectors of unit u + 1 before the blend of unit u (cycle stamps of the first version: 2.1 - 4.1k cycles per tap against ~0.7k of VALU
-    // issue: every unit waited for its own LDS reads and every tap for its own weight loads).
-    auto taps = [&](auto slow_c) {
-    constexpr bool SLOW = decltype(slow_c)::value;
-    struct TapRegs { i32x4 ga[2]; f32x4 gw[2]; i32x4 fa[2][4]; };
-    auto load_tap = [&](int tap, TapRegs& r) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            r.ga[j] = *(const i32x4*)(G0 + (tap * 32 + j * 16 + n) * 32);
-            r.gw[j] = *(const f32x4*)(G0 + (tap * 32 + j * 16 + n) * 32 + 16);
-        }
-#pragma unroll
-        for (int sx = 0; sx < 2; ++sx)
-#pragma unroll
-            for (int blk = 0; blk < 4; ++blk)
-                r.fa[sx][blk] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, wlane + blk * wblk, (tap * 64 + sx * 32) * ES, 0));
-    };
-    auto corners = [&](const i32x4& ga, int sx, i32x4 (&cv)[4]) {
-        const int vs = (sx * 4 + g) << 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int a = ga[c];
-            if constexpr (SLOW) cv[c] = *(const i32x4*)(win + (a < 0 ? 0 : (a ^ vs)));
-            else cv[c] = *(const i32x4*)(win + (a ^ vs));
-        }
-        if constexpr (SLOW) {
-            if (__builtin_amdgcn_ballot_w64((ga[0] | ga[1] | ga[2] | ga[3]) < 0) != 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int a = ga[c];
-                    if (a < 0) cv[c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, (int)(((uint32_t)a & 0x7fffffffu) << 4) + vs, 0, 0));
-                }
-            }
-        }
-    };
-    auto blend_mfma = [&](const i32x4 (&cv)[4], const f32x4& gw, const i32x4 (&fa)[4], f32x4 (&ac)[4]) {
-        Vec16<T> o;
-        if constexpr (PK) {                       // (compile time: a run-time branch per unit would fence the scheduler in)
-            o.raw = dcn_blend8_pk(cv[0], cv[1], cv[2], cv[3], dcn_pk_weight(gw[0]), dcn_pk_weight(gw[1]), dcn_pk_weight(gw[2]), dcn_pk_weight(gw[3]));
-        } else {
-            float vals[8];
-            if constexpr (std::is_same<T, hf16>::value) {
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    vals[2 * d] = mix_fma_lo(cv[3][d], gw[3], mix_fma_lo(cv[2][d], gw[2], mix_fma_lo(cv[1][d], gw[1], mix_mul_lo(cv[0][d], gw[0]))));
-                    vals[2 * d + 1] = mix_fma_hi(cv[3][d], gw[3], mix_fma_hi(cv[2][d], gw[2], mix_fma_hi(cv[1][d], gw[1], mix_mul_hi(cv[0][d], gw[0]))));
-                }
-            } else {
-                Vec16<T> c1, c2, c3, c4;
-                c1.raw = cv[0]; c2.raw = cv[1]; c3.raw = cv[2]; c4.raw = cv[3];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) vals[e] = fmaf(gw[3], c4.get(e), fmaf(gw[2], c3.get(e), fmaf(gw[1], c2.get(e), gw[0] * c1.get(e))));
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
-        }
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) Fmt16<T>::mfma16(fa[blk], o.raw, ac[blk]);
-    };
-    // one tap: units u = 0..3 = (k-step u >> 1, pixel block u & 1); `first` = corners of unit 0 (already requested), `nxt` = the next tap's
-    // registers (requested at the top), whose unit-0 corners are requested before this tap's last blend and returned in `first`
-    auto one_tap = [&](const TapRegs& cur, const TapRegs& nxt, i32x4 (&first)[4]) {
-        i32x4 cva[4], cvb[4];
-        corners(cur.ga[1], 0, cva);                                  // unit 1
-        blend_mfma(first, cur.gw[0], cur.fa[0], acc[0]);             // unit 0
-        corners(cur.ga[0], 1, cvb);                                  // unit 2
-        blend_mfma(cva, cur.gw[1], cur.fa[0], acc[1]);               // unit 1
-        corners(cur.ga[1], 1, cva);                                  // unit 3
-        blend_mfma(cvb, cur.gw[0], cur.fa[1], acc[0]);               // unit 2
-        corners(nxt.ga[0], 0, first);                                // unit 0 of the next tap
-        blend_mfma(cva, cur.gw[1], cur.fa[1], acc[1]);               // unit 3
-    };
-    TapRegs ra, rb;
-    i32x4 first[4];
-    load_tap(0, ra);
-    corners(ra.ga[0], 0, first);
-#pragma unroll 1
-    for (int tap = 0; tap < KK - 1; tap += 2) {                      // taps 0 .. 7 in pairs (a -> b -> a); tap 8 below
-        load_tap(tap + 1, rb);
-        one_tap(ra, rb, first);
-        STAMP(7 + tap);
-        load_tap(tap + 2, ra);
-        one_tap(rb, ra, first);
-        STAMP(8 + tap);
-    }
-    one_tap(ra, ra, first);                                          // (its look-ahead re-reads tap 8's own first corners: never consumed)
-    STAMP(15);
-    };
-    if (wave_far) taps(std::true_type{});
-    else taps(std::false_type{});
-    // ---- epilogue: bias, folded BN, ReLU; lane (n, g) holds channels blk * 16 + g * 4 + e of pixel n.  The wave's 32 pixels x 64 channels
-    // (4 KB) are parked in its own slice of the geometry table (dead: only this wave ever read it) and leave as whole 128-byte lines ----
-    char* park = geo_tab + wave * kBfGeoWave;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            const int lc = blk * 16 + g * 4;
-            const f32x4 bz = *(const f32x4*)(ctab + lc), sc = *(const f32x4*)(ctab + 64 + lc), sh = *(const f32x4*)(ctab + 128 + lc);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = (acc[j][blk][e] + bz[e]) * sc[e] + sh[e];
-                if (p.relu) x = fmaxf(x, 0.f);
-                v[e] = x;
-            }
-            i32x2 o2;
-            o2[0] = Fmt16<T>::pack2(v[0], v[1]);
-            o2[1] = Fmt16<T>::pack2(v[2], v[3]);
-            *(i32x2*)(park + (j * 16 + n) * 128 + lc * 2) = o2;
-        }
-    STAMP(16);
-    // (same wave wrote and reads: program order + the compiler's lgkmcnt is all the synchronisation there is to do)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int pl = r * 8 + (lane >> 3), vsl = lane & 7;          // pixel (j = pl >> 4, column pl & 15), 16-byte vector vsl
-        const i32x4 o = *(const i32x4*)(park + pl * 128 + vsl * 16);
-        const int oy = ty0 + 2 * wave + (pl >> 4), ox = tx0 + (pl & 15);
-        if (oy < p.Ho && ox < p.Wo)
-            *(i32x4*)((char*)p.out + ((int64_t)b * p.out_sb + (int64_t)oy * p.out_sy + (int64_t)ox * p.out_sx + vsl * 8) * 2) = o;
-    }
-    STAMP(17);
-}
-
-// ---- 64 -> 64 channel DCNv2 3x3 / s1 / p1: corners gathered from an LDS-staged input window, weights resident in LDS ---------------
-// The kernel above is bound by the L1 request path for C = O = 64 (the ten full-resolution launches of KM3D's DLA-Up, 2.2 ms of a
-// 9.8 ms step at 8.8 % of the MFMA peak): per 64-pixel workgroup and tap every thread issues 8 corner gathers + 2 weight vectors of
-// 1 KiB per wave, every needed input pixel passes through L1 ~36 times, and every workgroup streams the whole 74 KB weight panel
-// (1 GB per launch at 16 x 128 x 440).  Here:
-//   * PERSISTENT workgroups (one per CU, 4 waves); the 64 x 576 weights are loaded ONCE per workgroup into LDS as MFMA A-fragment
-//     images (72 x 1 KiB, lane-linear: conflict-free ds_read_b128);
-//   * a tile is 8 x 8 output pixels; its input WINDOW of (8 + 2 * 3 + 1)^2 = 15 x 15 pixels x 128 B is staged once by LDS-DMA
-//     (out-of-image pixels arrive as zeros = the reference's "corner outside the image contributes 0"), double buffered: tile k+1's
-//     window and offset logits travel while tile k computes; the four corners of a sample are four ds_read_b128 (256 B/clk/CU
-//     instead of the 64 B/clk L1 path), XOR-swizzled on the 16-byte slot by the window pixel;
-//   * a wave owns 16 pixels x all 64 output channels on v_mfma_f32_16x16x32: the blended values ARE the B fragment (lane (pixel,
-//     k-group) blends the 2 x 8 channels it multiplies) -- no column tile in LDS, no barrier inside a tile, ONE barrier per tile;
-//   * samples whose corners leave the window (learned offsets beyond +-2 px) take the global-gather path per (wave, tap): same
-//     arithmetic, only slower -- results are bit-identical to dcn_nhwc_kernel in every case (same blend order, same modulation fold);
-//   * outputs leave as whole 128-byte lines (parked per wave in its own geometry slot of LDS).
-// MEASURED (round 3, 16 x 128 x 440 fp16, offsets sigma 0.5 px): 419 us against 354 us for dcn_nhwc_kernel -- the L1 path is gone, but
-// with 151 KB of LDS per workgroup only ONE wave runs per SIMD and nothing hides its LDS / VALU latencies (the blend alone is ~1050
-// VALU instructions per tile and wave = a 113 us floor for this launch; the gather kernel keeps 12 waves per CU busy at ~32 % VALU
-// utilisation).  The kernel is therefore NOT the default: it runs only with VD3D_DCN_WINDOW=1 (tests exercise it that way and hold it
-// bit-identical to the gather kernel).  What would make it pay is two waves per SIMD: weights split over K into registers (8 waves,
-// 144 VGPRs each, partial sums reduced in LDS) instead of 74 KB of LDS -- DESIGN.md section 9.
-constexpr int kWinP = 3, kWinD = 8 + 2 * kWinP + 1, kWinPix = kWinD * kWinD;            // 15 x 15 window pixels
-constexpr int kWinPieces = (kWinPix * 8 + 63) / 64, kWinBytes = kWinPieces * 1024;       // 29 DMA pieces of 1 KiB
-constexpr int kWinWts = 9 * 2 * 4 * 1024;                                                // (tap, k-step, 16-channel block) fragments
-constexpr int kWinGeoWave = 9 * 16 * 16, kWinGeo = 4 * kWinGeoWave;                      // per wave: 9 taps x 16 pixels x 16 B
-constexpr int kWinLds = kWinWts + 2 * kWinBytes + 2 * kWinGeo;                           // 151 552 B
-
-template <typename T>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) dcn_win64_kernel(const DcnArgs p, int ntiles, int tiles_x, int tiles_y) {
-    static_assert(sizeof(T) == 2, "16-bit formats only");
-    constexpr uint32_t kOOBw = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wts = smem;
-    char* win = smem + kWinWts;
-    char* geo = win + 2 * kWinBytes;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, g = lane >> 4;
-    const int prow = 2 * wave + (n >> 3), pcol = n & 7;                 // this lane's pixel inside the tile
-    // XCD-aware persistent walk: the workgroups of one XCD (private L2) take a contiguous run of tiles, neighbours share window halos
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_xcd = nwg >> 3;
-    const int chunk = (ntiles + 7) >> 3;
-    auto tile_of = [&](int k) { const int i = jx + k * per_xcd; return i < chunk ? xcd * chunk + i : ntiles; };
-    const int tiles_img = tiles_x * tiles_y;
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0x7fffffff, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-    // ---- weights -> LDS fragment images (once per workgroup): fragment f = (tap*2 + s)*4 + blk, lane l: row blk*16 + (l & 15),
-    // k = tap*64 + s*32 + (l >> 4)*8 .. +7
-    for (int idx = tid; idx < 72 * 64; idx += 256) {
-        const int f = idx >> 6, l = idx & 63;
-        const int tap = f >> 3, sx = (f >> 2) & 1, blk = f & 3;
-        const int o = blk * 16 + (l & 15), kk = tap * 64 + sx * 32 + (l >> 4) * 8;
-        *(i32x4*)(wts + idx * 16) = *(const i32x4*)((const char*)p.w + ((size_t)o * p.Kpad + kk) * 2);
-    }
-    // per-channel constants of this lane's 16 output channels (blk*16 + g*4 + e)
-    float cb[4][4], cs[4][4], ct[4][4];
-#pragma unroll
-    for (int blk = 0; blk < 4; ++blk)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int o = blk * 16 + g * 4 + e;
-            cb[blk][e] = p.bias ? p.bias[o] : 0.f;
-            cs[blk][e] = p.scale ? p.scale[o] : 1.f;
-            ct[blk][e] = p.shift ? p.shift[o] : 0.f;
-        }
-    // DMA lane constants: piece q = wave + 4*it, chunk c = 64 q + lane -> window pixel pp = c >> 3, LDS slot c & 7 holds vector
-    // (slot ^ key(pp)) of that pixel (the swizzle is applied to the SOURCE: the DMA writes lane-linear)
-    constexpr int NIT = (kWinPieces + 3) / 4;
-    int d_rel[NIT], d_yx[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int q = wave + 4 * it, c = q * 64 + lane, pp = c >> 3, sl = c & 7;
-        const int v = sl ^ ((pp >> 1) & 7);
-        const int wy = pp / kWinD, wx = pp - wy * kWinD;
-        d_rel[it] = (int)((wy * p.in_sy + wx * p.in_sx + v * 8) * 2);
-        d_yx[it] = (q < kWinPieces && pp < kWinPix) ? (wy | (wx << 8)) : -1;
-    }
-    auto decode = [&](int t, int& b, int& ty0, int& tx0) {
-        b = t / tiles_img;
-        const int r = t - b * tiles_img, ty = r / tiles_x;
-        ty0 = ty * 8;
-        tx0 = (r - ty * tiles_x) * 8;
-    };
-    auto issue_window = [&](int t, int buf) {
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-        const int base = (int)((b * p.in_sb + (ty0 - kWinP) * p.in_sy + (tx0 - kWinP) * p.in_sx) * 2);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int q = wave + 4 * it;
-            if (q < kWinPieces) {                                   // wave-uniform
-                const int wy = d_yx[it] & 255, wx = (d_yx[it] >> 8) & 255;
-                const bool ok = d_yx[it] >= 0 && (unsigned)(ty0 - kWinP + wy) < (unsigned)p.H && (unsigned)(tx0 - kWinP + wx) < (unsigned)p.W;
-                const uint32_t off = ok ? (uint32_t)(base + d_rel[it]) : kOOBw;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(win + buf * kWinBytes + q * 1024), 16, off, 0, 0, 0);
-            }
-        }
-    };
-    // the offset / mask logits of this wave's 9 x 16 geometry entries (entry e = r*64 + lane: tap e >> 4, pixel e & 15)
-    float l_oh[3], l_ow[3], l_ml[3];
-    auto issue_logits = [&](int t) {
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int e = r * 64 + lane, tap = e >> 4, nn = e & 15;
-            const int y = ty0 + 2 * wave + (nn >> 3), x = tx0 + (nn & 7);
-            l_oh[r] = l_ow[r] = l_ml[r] = 0.f;
-            if (e < 144 && y < p.Ho && x < p.Wo) {
-                const int64_t ob = b * p.off_sb + y * p.off_sy + x * p.off_sx;
-                l_oh[r] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
-                l_ow[r] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
-                if (p.mask) l_ml[r] = p.mask[b * p.msk_sb + y * p.msk_sy + x * p.msk_sx + (int64_t)tap * p.msk_sc];
-            }
-        }
-    };
-    // geometry entry: { (h_low + 1) | (w_low + 1) << 16, lh, lw, m }; an invalid sample (outside (-1, H) x (-1, W), or a pixel
-    // beyond the image edge of a ragged tile) carries m = 0 and the tile origin (always inside the window)
-    auto write_geometry = [&](int t, int buf) -> bool {
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-        bool leaves = false;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int e = r * 64 + lane, tap = e >> 4, nn = e & 15;
-            if (e < 144) {
-                const int y = ty0 + 2 * wave + (nn >> 3), x = tx0 + (nn & 7);
-                const int ti = tap / 3, tj = tap - ti * 3;
-                int hl = ty0, wl = tx0;
-                float lh = 0.f, lw = 0.f, m = 0.f;
-                if (y < p.Ho && x < p.Wo) {
-                    const float h_im = (float)(y - 1 + ti) + l_oh[r];
-                    const float w_im = (float)(x - 1 + tj) + l_ow[r];
-                    if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                        m = 1.f;
-                        if (p.mask) {
-                            m = l_ml[r];
-                            if (p.mask_sigmoid) m = __frcp_rn(1.0f + __expf(-m));
-                        }
-                        hl = (int)floorf(h_im);
-                        wl = (int)floorf(w_im);
-                        lh = h_im - (float)hl;
-                        lw = w_im - (float)wl;
-                    }
-                }
-                *(i32x4*)(geo + buf * kWinGeo + wave * kWinGeoWave + e * 16) = i32x4{(hl + 1) | ((wl + 1) << 16), f2i(lh), f2i(lw), f2i(m)};
-                leaves |= !((unsigned)(hl - (ty0 - kWinP)) <= (unsigned)(kWinD - 2) && (unsigned)(wl - (tx0 - kWinP)) <= (unsigned)(kWinD - 2));
-            }
-        }
-        return __builtin_amdgcn_ballot_w64(leaves) != 0;         // wave-uniform: this wave's tile needs the global-gather path somewhere
-    };
-
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7fffffff, 0x00020000);
-    int t = tile_of(0);
-    bool slow = false, slow_next = false;
-    if (t < ntiles) {
-        issue_window(t, 0);
-        issue_logits(t);
-        slow = write_geometry(t, 0);
-    }
-    for (int k = 0; t < ntiles; ++k) {
-        const int buf = k & 1;
-        // the window of this tile (DMA issued a whole tile ago) must have landed; the only younger VMEM operations of this wave are
-        // the previous tile's two (unconditional) output stores, which need not be waited for
-        if (k == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const int tn = tile_of(k + 1);
-        if (tn < ntiles) {
-            issue_window(tn, buf ^ 1);
-            issue_logits(tn);
-        }
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-        const char* W0 = win + buf * kWinBytes;
-        char* G0 = geo + buf * kWinGeo + wave * kWinGeoWave;
-        f32x4 acc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // The nine taps as straight-line code (FAST: every sample of this wave's tile inside the window -- known since the geometry
-        // was computed -- so no branch separates the taps and the next tap's LDS reads are scheduled under this tap's blend), or with
-        // the per-tap window test and the global-gather fallback (SLOW).
-        auto taps = [&](auto slow_c) {
-        constexpr bool SLOW = decltype(slow_c)::value;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const i32x4 ge = *(const i32x4*)(G0 + (tap * 16 + n) * 16);
-            const int hl = (ge[0] & 0xffff) - 1, wl = (int)((uint32_t)ge[0] >> 16) - 1;
-            const float lh = i2f(ge[1]), lw = i2f(ge[2]), m = i2f(ge[3]);
-            const float hh = 1.f - lh, hw = 1.f - lw;
-            float w[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) w[c] *= m;                  // the modulation folded into the weights, as in dcn_nhwc_kernel
-            const int wy = hl - (ty0 - kWinP), wx = wl - (tx0 - kWinP);
-            const bool inwin = (unsigned)wy <= (unsigned)(kWinD - 2) && (unsigned)wx <= (unsigned)(kWinD - 2);
-            i32x4 cv[2][4];
-            if (!SLOW || __builtin_amdgcn_ballot_w64(!inwin) == 0) {
-                const int pw = wy * kWinD + wx;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int q = pw + (c >> 1) * kWinD + (c & 1);
-                    const int a0 = q * 128 + ((g ^ ((q >> 1) & 7)) << 4);
-                    cv[0][c] = *(const i32x4*)(W0 + a0);
-                    cv[1][c] = *(const i32x4*)(W0 + (a0 ^ 64));              // vector g + 4: the swizzled slot differs in bit 2 only
-                }
-            } else {
-                // some sample of this (wave, tap) leaves the window: gather every corner from global memory (out-of-image -> zeros)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int y = hl + (c >> 1), x = wl + (c & 1);
-                    const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                    const uint32_t off = ok ? (uint32_t)((b * p.in_sb + y * p.in_sy + x * p.in_sx + g * 8) * 2) : kOOBw;
-                    cv[0][c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));
-                    cv[1][c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ok ? off + 64 : kOOBw, 0, 0));
-                }
-            }
-#pragma unroll
-            for (int sx = 0; sx < 2; ++sx) {
-                float vals[8];
-                Vec16<T> o;
-                bool packed = false;
-                if constexpr (std::is_same<T, hf16>::value) {
-                  if (p.pk16) {
-                    o.raw = dcn_blend8_pk(cv[sx][0], cv[sx][1], cv[sx][2], cv[sx][3], dcn_pk_weight(w[0]), dcn_pk_weight(w[1]), dcn_pk_weight(w[2]), dcn_pk_weight(w[3]));
-                    packed = true;
-                  } else {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        vals[2 * d] = mix_fma_lo(cv[sx][3][d], w[3], mix_fma_lo(cv[sx][2][d], w[2], mix_fma_lo(cv[sx][1][d], w[1], mix_mul_lo(cv[sx][0][d], w[0]))));
-                        vals[2 * d + 1] = mix_fma_hi(cv[sx][3][d], w[3], mix_fma_hi(cv[sx][2][d], w[2], mix_fma_hi(cv[sx][1][d], w[1], mix_mul_hi(cv[sx][0][d], w[0]))));
-                    }
-                  }
-                } else {
-                    Vec16<T> c1, c2, c3, c4;
-                    c1.raw = cv[sx][0]; c2.raw = cv[sx][1]; c3.raw = cv[sx][2]; c4.raw = cv[sx][3];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vals[e] = fmaf(w[3], c4.get(e), fmaf(w[2], c3.get(e), fmaf(w[1], c2.get(e), w[0] * c1.get(e))));
-                }
-                if (!packed) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
-                }
-#pragma unroll
-                for (int blk = 0; blk < 4; ++blk) {
-                    const i32x4 fa = *(const i32x4*)(wts + (((tap * 2 + sx) * 4 + blk) * 64 + lane) * 16);
-                    Fmt16<T>::mfma16(fa, o.raw, acc[blk]);
-                }
-            }
-        }
-        };
-        if (slow) taps(std::true_type{});
-        else taps(std::false_type{});
-        // ---- epilogue: bias, folded BN, ReLU; the wave's 16 pixels x 64 channels parked in its own geometry slot, out as whole lines
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = (acc[blk][e] + cb[blk][e]) * cs[blk][e] + ct[blk][e];
-                if (p.relu) x = fmaxf(x, 0.f);
-                v[e] = x;
-            }
-            i32x2 o2;
-            o2[0] = Fmt16<T>::pack2(v[0], v[1]);
-            o2[1] = Fmt16<T>::pack2(v[2], v[3]);
-            *(i32x2*)(G0 + n * 128 + (blk * 16 + g * 4) * 2) = o2;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int j = lane + 64 * r, px = j >> 3, part = j & 7;
-            const int y = ty0 + 2 * wave + (px >> 3), x = tx0 + (px & 7);
-            const i32x4 val = *(const i32x4*)(G0 + px * 128 + part * 16);
-            const uint32_t off = (y < p.Ho && x < p.Wo) ? (uint32_t)((b * p.out_sb + y * p.out_sy + x * p.out_sx) * 2 + part * 16) : kOOBw;
-            __builtin_amdgcn_raw_buffer_store_b128(val, out_rsrc, off, 0, 0);      // always issued (the vmcnt count above relies on it)
-        }
-        if (tn < ntiles) slow_next = write_geometry(tn, buf ^ 1);
-        slow = slow_next;
-        t = tn;
-    }
-}
-
-// ---- 64 -> 64 channel DCNv2, second design: the window kernel above with TWO waves per SIMD ---------------------------------------
-// dcn_win64_kernel lost to the gather kernel because 151 KB of LDS (74 KB of it weights) left one wave per SIMD.  Here the weights live
-// in REGISTERS, split over K: a workgroup is 8 waves = 4 pixel groups (16 pixels of the 8 x 8 tile) x 2 K halves; wave (pg, kh) keeps the
-// A fragments of all 64 output channels x its 32 input channels x 9 taps (36 fragments = 144 VGPRs, as conv_resident64), blends ONLY its
-// 32 channels (one 16-byte vector per lane and tap: 4 corner ds_read_b128, 32 FMAs) and issues 4 MFMAs per tap.  The two K partial sums
-// of a pixel group meet in LDS: the tile's non-owner parks its 16 accumulators, the OWNER (alternating with the tile index, so both waves
-// pay the epilogue on every other tile) adds them at the start of the NEXT iteration -- after that iteration's barrier, so a tile still
-// costs ONE barrier -- and stores whole 128-byte lines (BOTH waves park their partial sums: keeping the owner's in registers across the
-// iteration spilled).  LDS: two 29 KiB windows + geometry + partials = 159 KB, no weights.  Geometry entries carry the four corner
-// addresses (swizzle key included) and the four modulated weights, computed once per (pixel, tap) instead of by the 8 lanes sharing it.
-// MEASURED (round 3, 16 x 128 x 440 fp16, sigma 0.5 px): 329 us against 350 us for the gather kernel on the same box (361 before the
-// precomputed addresses); bf16 537 us (26 spilled registers).  Ablations (runtime flags, removed again): no blend -42 us, no corner
-// reads -26, neither -73, no MFMA 0, no window DMA -32, no logit loads -29, no reduction / epilogue -50, ALL of them off: 188 us --
-// i.e. 3.4 us per 64-pixel tile of barrier, geometry, tile decode and hand-over that no amount of gather tuning removes.  An 8 x 8 tile
-// is too small a unit of work per barrier for a persistent design, and larger tiles do not fit two windows in LDS.  OPT-IN
-// (VD3D_DCN_KSPLIT=1); results differ from the gather kernel by the fp32 order of the two K halves (<= 1 ulp, tests/test_dcn_gpu.py).
-constexpr int kKsGeoGrp = 9 * 16 * 32;                                     // per pixel group: 9 taps x 16 pixels x 32 B
-constexpr int kKsGeo = 4 * kKsGeoGrp, kKsRed = 4 * 2 * 4096;               // per buffer: 4 pixel groups x 2 K halves x 16 accumulators
-constexpr int kKsLdsWin = 0, kKsLdsGeo = 2 * kWinBytes, kKsLdsRed = kKsLdsGeo + 2 * kKsGeo, kKsLdsFlag = kKsLdsRed + 2 * kKsRed;
-constexpr int kKsLdsTab = kKsLdsFlag + 64, kKsLds = kKsLdsTab + 3 * 64 * 4;
-
-template <typename T>
-__global__ void __launch_bounds__(512) dcn_ks64_kernel(const DcnArgs p, int ntiles, int tiles_x, int tiles_y) {
-    static_assert(sizeof(T) == 2, "16-bit formats only");
-    constexpr uint32_t kOOBw = 0x80000000u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* win = smem + kKsLdsWin;
-    char* geo = smem + kKsLdsGeo;
-    char* red = smem + kKsLdsRed;
-    int* flags = (int*)(smem + kKsLdsFlag);            // [2 buffers][4 groups][2 waves]
-    float* ctab = (float*)(smem + kKsLdsTab);          // bias | scale | shift
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pg = wave >> 1, kh = wave & 1;
-    const int n = lane & 15, g = lane >> 4;
-    const int vsel = kh * 4 + g;                        // this lane's 16-byte vector (8 channels) of a pixel
-    const uint32_t vsel2 = (uint32_t)vsel | ((uint32_t)vsel << 16);
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, jx = blockIdx.x >> 3, per_xcd = nwg >> 3;
-    const int chunk = (ntiles + 7) >> 3;
-    auto tile_of = [&](int k) { const int i = jx + k * per_xcd; return i < chunk ? xcd * chunk + i : ntiles; };
-    const int tiles_img = tiles_x * tiles_y;
-    const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7fffffff, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-    if (tid < 64) {
-        ctab[tid] = p.bias ? p.bias[tid] : 0.f;
-        ctab[64 + tid] = p.scale ? p.scale[tid] : 1.f;
-        ctab[128 + tid] = p.shift ? p.shift[tid] : 0.f;
-    }
-    // ---- weights -> registers: fragment (tap, blk): row blk*16 + n, k = tap*64 + kh*32 + g*8 .. +7
-    i32x4 wf[9][4];
-    {
-        const char* wbase = (const char*)p.w + ((size_t)n * p.Kpad + kh * 32 + g * 8) * 2;
-        static_for<36>([&](auto ic) {
-            constexpr int i = decltype(ic)::value, tap = i / 4, blk = i % 4;
-            wf[tap][blk] = *(const i32x4*)(wbase + ((size_t)blk * 16 * p.Kpad + tap * 64) * 2);
-        });
-    }
-    constexpr int NIT = (kWinPieces + 7) / 8;
-    int d_rel[NIT], d_yx[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int q = wave + 8 * it, c = q * 64 + lane, pp = c >> 3, sl = c & 7;
-        const int v = sl ^ ((pp >> 1) & 7);
-        const int wy = pp / kWinD, wx = pp - wy * kWinD;
-        d_rel[it] = (int)((wy * p.in_sy + wx * p.in_sx + v * 8) * 2);
-        d_yx[it] = (q < kWinPieces && pp < kWinPix) ? (wy | (wx << 8)) : -1;
-    }
-    auto decode = [&](int t, int& b, int& ty0, int& tx0) {
-        b = t / tiles_img;
-        const int r = t - b * tiles_img, ty = r / tiles_x;
-        ty0 = ty * 8;
-        tx0 = (r - ty * tiles_x) * 8;
-    };
-    auto issue_window = [&](int t, int buf) {
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-        const int base = (int)((b * p.in_sb + (ty0 - kWinP) * p.in_sy + (tx0 - kWinP) * p.in_sx) * 2);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int q = wave + 8 * it;
-            if (q < kWinPieces) {
-                const int wy = d_yx[it] & 255, wx = (d_yx[it] >> 8) & 255;
-                const bool ok = d_yx[it] >= 0 && (unsigned)(ty0 - kWinP + wy) < (unsigned)p.H && (unsigned)(tx0 - kWinP + wx) < (unsigned)p.W;
-                const uint32_t off = ok ? (uint32_t)(base + d_rel[it]) : kOOBw;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, (lds_ptr_t)(win + buf * kWinBytes + q * 1024), 16, off, 0, 0, 0);
-            }
-        }
-    };
-    // geometry entries of this pixel group: e = r*128 + kh*64 + lane (tap e >> 4, pixel e & 15), split between the pair's two waves
-    float l_oh[2], l_ow[2], l_ml[2];
-    auto issue_logits = [&](int t) {
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int e = r * 128 + kh * 64 + lane, tap = e >> 4, nn = e & 15;
-            const int y = ty0 + 2 * pg + (nn >> 3), x = tx0 + (nn & 7);
-            l_oh[r] = l_ow[r] = l_ml[r] = 0.f;
-            if (e < 144 && y < p.Ho && x < p.Wo) {
-                const int64_t ob = b * p.off_sb + y * p.off_sy + x * p.off_sx;
-                l_oh[r] = p.offset[ob + (int64_t)(2 * tap) * p.off_sc];
-                l_ow[r] = p.offset[ob + (int64_t)(2 * tap + 1) * p.off_sc];
-                if (p.mask) l_ml[r] = p.mask[b * p.msk_sb + y * p.msk_sy + x * p.msk_sx + (int64_t)tap * p.msk_sc];
-            }
-        }
-    };
-    auto write_geometry = [&](int t, int buf) {
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-        bool leaves = false;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int e = r * 128 + kh * 64 + lane, tap = e >> 4, nn = e & 15;
-            if (e < 144) {
-                const int y = ty0 + 2 * pg + (nn >> 3), x = tx0 + (nn & 7);
-                const int ti = tap / 3, tj = tap - ti * 3;
-                int hl = ty0, wl = tx0;
-                float lh = 0.f, lw = 0.f, m = 0.f;
-                if (y < p.Ho && x < p.Wo) {
-                    const float h_im = (float)(y - 1 + ti) + l_oh[r];
-                    const float w_im = (float)(x - 1 + tj) + l_ow[r];
-                    if (h_im > -1.f && w_im > -1.f && h_im < (float)p.H && w_im < (float)p.W) {
-                        m = 1.f;
-                        if (p.mask) {
-                            m = l_ml[r];
-                            if (p.mask_sigmoid) m = __frcp_rn(1.0f + __expf(-m));
-                        }
-                        hl = (int)floorf(h_im);
-                        wl = (int)floorf(w_im);
-                        lh = h_im - (float)hl;
-                        lw = w_im - (float)wl;
-                    }
-                }
-                // entry (32 B): { (h_low + 1) | (w_low + 1) << 16,  a0 | a1 << 16,  a2 | a3 << 16,  0,  w0, w1, w2, w3 } with a_c = LDS
-                // address of corner c's pixel in 16-byte units INCLUDING its swizzle key (a lane adds its own vector by XOR) and
-                // w_c = bilinear weight x modulation: computed ONCE per (pixel, tap) here instead of by all 8 lanes that share it
-                const int wy = hl - (ty0 - kWinP), wx = wl - (tx0 - kWinP);
-                const bool inw = (unsigned)wy <= (unsigned)(kWinD - 2) && (unsigned)wx <= (unsigned)(kWinD - 2);
-                leaves |= !inw;
-                uint32_t ac[4] = {0, 0, 0, 0};
-                if (inw) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int q = (wy + (c >> 1)) * kWinD + wx + (c & 1);
-                        ac[c] = (uint32_t)(q * 8 + ((q >> 1) & 7));
-                    }
-                }
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                float w4[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) w4[c] *= m;
-                char* ge = geo + buf * kKsGeo + pg * kKsGeoGrp + e * 32;
-                *(i32x4*)ge = i32x4{(hl + 1) | ((wl + 1) << 16), (int)(ac[0] | (ac[1] << 16)), (int)(ac[2] | (ac[3] << 16)), 0};
-                *(f32x4*)(ge + 16) = f32x4{w4[0], w4[1], w4[2], w4[3]};
-            }
-        }
-        const int any = __builtin_amdgcn_ballot_w64(leaves) != 0;
-        if (lane == 0) flags[(buf * 4 + pg) * 2 + kh] = any;
-    };
-
-    int t = tile_of(0);
-    if (t < ntiles) {
-        issue_window(t, 0);
-        issue_logits(t);
-        write_geometry(t, 0);
-    }
-    int t_prev = ntiles;                                // tile whose reduction + epilogue is still due
-    // finish tile `tp` (iteration kp): the owner adds the partner's parked partial sums, applies bias / BN / ReLU, parks the 16 pixels x
-    // 64 channels in the same LDS region and stores whole lines
-    auto finish = [&](int tp, int kp) {
-        if (kh != (kp & 1)) return;                    // wave-uniform: not the owner of that tile
-        int b, ty0, tx0;
-        decode(tp, b, ty0, tx0);
-        char* R0 = red + (kp & 1) * kKsRed + pg * 8192;
-        f32x4 fin[4];
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            const f32x4 mine = *(const f32x4*)(R0 + kh * 4096 + (blk * 64 + lane) * 16);
-            const f32x4 other = *(const f32x4*)(R0 + (kh ^ 1) * 4096 + (blk * 64 + lane) * 16);
-            const f32x4 bz = *(const f32x4*)(ctab + blk * 16 + g * 4), sc = *(const f32x4*)(ctab + 64 + blk * 16 + g * 4),
-                        sh = *(const f32x4*)(ctab + 128 + blk * 16 + g * 4);
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = ((mine[e] + other[e]) + bz[e]) * sc[e] + sh[e];
-                if (p.relu) x = fmaxf(x, 0.f);
-                v[e] = x;
-            }
-            fin[blk] = f32x4{v[0], v[1], v[2], v[3]};
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the partner's partials are in registers: the region becomes the parking tile
-#pragma unroll
-        for (int blk = 0; blk < 4; ++blk) {
-            i32x2 o2;
-            o2[0] = Fmt16<T>::pack2(fin[blk][0], fin[blk][1]);
-            o2[1] = Fmt16<T>::pack2(fin[blk][2], fin[blk][3]);
-            *(i32x2*)(R0 + n * 128 + (blk * 16 + g * 4) * 2) = o2;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int j = lane + 64 * r, px = j >> 3, part = j & 7;
-            const int y = ty0 + 2 * pg + (px >> 3), x = tx0 + (px & 7);
-            const i32x4 val = *(const i32x4*)(R0 + px * 128 + part * 16);
-            const uint32_t off = (y < p.Ho && x < p.Wo) ? (uint32_t)((b * p.out_sb + y * p.out_sy + x * p.out_sx) * 2 + part * 16) : kOOBw;
-            __builtin_amdgcn_raw_buffer_store_b128(val, out_rsrc, off, 0, 0);
-        }
-    };
-    int k = 0;
-    for (; t < ntiles; ++k) {
-        const int buf = k & 1;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t_prev < ntiles) finish(t_prev, k - 1);
-        const int tn = tile_of(k + 1);
-        if (tn < ntiles) {
-            issue_window(tn, buf ^ 1);
-            issue_logits(tn);
-        }
-        int b, ty0, tx0;
-        decode(t, b, ty0, tx0);
-        const char* W0 = win + buf * kWinBytes;
-        const char* G0 = geo + buf * kKsGeo + pg * kKsGeoGrp;
-        const bool slow = (flags[(buf * 4 + pg) * 2] | flags[(buf * 4 + pg) * 2 + 1]) != 0;
-        f32x4 acc[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto taps = [&](auto slow_c) {
-            constexpr bool SLOW = decltype(slow_c)::value;
-            static_for<9>([&](auto tc) {
-                constexpr int tap = decltype(tc)::value;
-                const i32x4 ge = *(const i32x4*)(G0 + (tap * 16 + n) * 32);
-                const f32x4 gw = *(const f32x4*)(G0 + (tap * 16 + n) * 32 + 16);
-                const float w[4] = {gw[0], gw[1], gw[2], gw[3]};
-                const int hl = (ge[0] & 0xffff) - 1, wl = (int)((uint32_t)ge[0] >> 16) - 1;
-                bool inwin = true;
-                if constexpr (SLOW) {
-                    const int wy = hl - (ty0 - kWinP), wx = wl - (tx0 - kWinP);
-                    inwin = (unsigned)wy <= (unsigned)(kWinD - 2) && (unsigned)wx <= (unsigned)(kWinD - 2);
-                }
-                i32x4 cv[4];
-                if (!SLOW || __builtin_amdgcn_ballot_w64(!inwin) == 0) {
-                    const uint32_t a01 = (uint32_t)ge[1] ^ vsel2, a23 = (uint32_t)ge[2] ^ vsel2;      // both corners of a pair get the lane's vector
-                    cv[0] = *(const i32x4*)(W0 + ((a01 & 0xffffu) << 4));
-                    cv[1] = *(const i32x4*)(W0 + ((a01 >> 16) << 4));
-                    cv[2] = *(const i32x4*)(W0 + ((a23 & 0xffffu) << 4));
-                    cv[3] = *(const i32x4*)(W0 + ((a23 >> 16) << 4));
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int y = hl + (c >> 1), x = wl + (c & 1);
-                        const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-                        const uint32_t off = ok ? (uint32_t)((b * p.in_sb + y * p.in_sy + x * p.in_sx + vsel * 8) * 2) : kOOBw;
-                        cv[c] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0));
-                    }
-                }
-                float vals[8];
-                Vec16<T> o;
-                bool packed = false;
-                if constexpr (std::is_same<T, hf16>::value) {
-                  if (p.pk16) {
-                    o.raw = dcn_blend8_pk(cv[0], cv[1], cv[2], cv[3], dcn_pk_weight(w[0]), dcn_pk_weight(w[1]), dcn_pk_weight(w[2]), dcn_pk_weight(w[3]));
-                    packed = true;
-                  } else {
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        vals[2 * d] = mix_fma_lo(cv[3][d], w[3], mix_fma_lo(cv[2][d], w[2], mix_fma_lo(cv[1][d], w[1], mix_mul_lo(cv[0][d], w[0]))));
-                        vals[2 * d + 1] = mix_fma_hi(cv[3][d], w[3], mix_fma_hi(cv[2][d], w[2], mix_fma_hi(cv[1][d], w[1], mix_mul_hi(cv[0][d], w[0]))));
-                    }
-                  }
-                } else {
-                    Vec16<T> c1, c2, c3, c4;
-                    c1.raw = cv[0]; c2.raw = cv[1]; c3.raw = cv[2]; c4.raw = cv[3];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vals[e] = fmaf(w[3], c4.get(e), fmaf(w[2], c3.get(e), fmaf(w[1], c2.get(e), w[0] * c1.get(e))));
-                }
-                if (!packed) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
-                }
-#pragma unroll
-                for (int blk = 0; blk < 4; ++blk) Fmt16<T>::mfma16(wf[tap][blk], o.raw, acc[blk]);
-            });
-        };
-        if (slow) taps(std::true_type{});
-        else taps(std::false_type{});
-        // hand-over: both waves of the pair park their partial sums; the tile's owner adds them after the next barrier
-        {
-            char* R0 = red + buf * kKsRed + pg * 8192 + kh * 4096;
-#pragma unroll
-            for (int blk = 0; blk < 4; ++blk) *(f32x4*)(R0 + (blk * 64 + lane) * 16) = acc[blk];
-        }
-        t_prev = t;
-        if (tn < ntiles) write_geometry(tn, buf ^ 1);
-        t = tn;
-    }
-    if (t_prev < ntiles) {                             // the last tile's reduction (uniform over the workgroup: every wave ran k iterations)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        finish(t_prev, k - 1);
-    }
-}
-
-// ---- sampled columns in HBM (large output-channel counts) -------------------------------------------------------------
-// The fused kernel above produces a pixel tile's sampled columns once per BN <= 256 output channels: with O = 2176 (the DCNv2
-// head of BASELINE config 3) the gather + blend is repeated 9 times and the launch takes 12 ms.  For such layers the columns
-// are written once, in the storage dtype -- the very rounding point of the fused path -- as [B][Ho][Wo][tap][C], and the
-// contraction runs as a 1x1 convolution over K = taps x C on the strip tiles of conv_igemm.hip (the reference materialises
-// the same matrix, in fp32: deform_conv_cuda.cpp:531-569).  One thread = one (pixel, tap, 16-byte channel vector); identical
-// sampling arithmetic to dcn_nhwc_kernel (same fma chain, same modulation order).
 template <typename T>
 __global__ void __launch_bounds__(256) dcn_columns_kernel(const DcnArgs p, T* __restrict__ cols) {
     constexpr int ES = (int)sizeof(T);
@@ -1934,86 +761,8 @@ int launch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
     return vd3d_check_launch("deform_conv(nhwc)");
 }
 
-// the LDS-window kernel: 16-bit, 3x3 / s1 / p1 / d1, C = O = 64, line-aligned NHWC output, tensors addressable with 32-bit offsets
-static bool dcn_win64_shape_ok(const DcnArgs& a, int es);
-static bool dcn_win64_ok(const DcnArgs& a, int es) { return dcn_win64_shape_ok(a, es) && vd3d_switch(VD3D_SW_DCN_WINDOW); }
-static bool dcn_win64_shape_ok(const DcnArgs& a, int es) {
-    const int64_t in_span = ((int64_t)(a.B - 1) * a.in_sb + (int64_t)(a.H - 1) * a.in_sy + (int64_t)(a.W - 1) * a.in_sx + a.C) * es;
-    return es == 2 && a.kh == 3 && a.kw == 3 && a.sh == 1 && a.sw == 1 && a.ph == 1 && a.pw == 1 && a.dh == 1 && a.dw == 1 && a.Cg == 64 &&
-           a.C == 64 && a.O == 64 && a.Kpad >= 576 && a.H < 32768 && a.W < 32768 && in_span < 0x7ffffff0ll &&
-           a.out_sx % 8 == 0 && a.out_sy % 8 == 0 && a.out_sb % 8 == 0 && ((uintptr_t)a.out & 15) == 0 &&
-           ((int64_t)(a.B - 1) * a.out_sb + (int64_t)(a.H - 1) * a.out_sy + (int64_t)(a.W - 1) * a.out_sx + a.O) * es < 0x7ffffff0ll &&
-           true;
-}
-
-template <typename T>
-int launch_dcn_lw64(const DcnArgs& a, hipStream_t s) {
-    static Vd3dLdsLimit lim;
-    if (const int rc = vd3d_raise_lds_limit((const void*)dcn_lw64_kernel<T>, kLwLds, lim, "hipFuncSetAttribute(dcn_lw64)")) return rc;
-    const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
-    if ((int64_t)tiles_x * tiles_y > 0x7fffffff || a.B > 65535) return VD3D_ERANGE;
-    hipLaunchKernelGGL(dcn_lw64_kernel<T>, dim3((unsigned)(tiles_x * tiles_y), 1, a.B), dim3(256), kLwLds, s, a, tiles_x);
-    return vd3d_check_launch("deform_conv(lds window)");
-}
-
-template <typename T>
-int launch_dcn_bf64(const DcnArgs& a, hipStream_t s) {
-    static Vd3dLdsLimit lim, lim_pk;
-    const int tiles_x = (a.Wo + kBfTW - 1) / kBfTW, tiles_y = (a.Ho + kBfTH - 1) / kBfTH;
-    if ((int64_t)tiles_x * tiles_y > 0x7fffffff || a.B > 65535) return VD3D_ERANGE;
-    const dim3 grid((unsigned)(tiles_x * tiles_y), 1, a.B);
-    if constexpr (std::is_same<T, hf16>::value) {
-        if (a.pk16) {
-            if (const int rc = vd3d_raise_lds_limit((const void*)dcn_bf64_kernel<T, true>, kBfLds, lim_pk, "hipFuncSetAttribute(dcn_bf64)")) return rc;
-            hipLaunchKernelGGL((dcn_bf64_kernel<T, true>), grid, dim3(256), kBfLds, s, a, tiles_x);
-            return vd3d_check_launch("deform_conv(barrier-free)");
-        }
-    }
-    if (const int rc = vd3d_raise_lds_limit((const void*)dcn_bf64_kernel<T, false>, kBfLds, lim, "hipFuncSetAttribute(dcn_bf64)")) return rc;
-    hipLaunchKernelGGL((dcn_bf64_kernel<T, false>), grid, dim3(256), kBfLds, s, a, tiles_x);
-    return vd3d_check_launch("deform_conv(barrier-free)");
-}
-
-template <typename T>
-int launch_dcn_win64(const DcnArgs& a, hipStream_t s) {
-    static Vd3dLdsLimit lim;
-    if (const int rc = vd3d_raise_lds_limit((const void*)dcn_win64_kernel<T>, kWinLds, lim, "hipFuncSetAttribute(dcn_win64)")) return rc;
-    const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
-    const int64_t ntiles = (int64_t)a.B * tiles_x * tiles_y;
-    if (ntiles > 0x7fffffff) return VD3D_ERANGE;
-    const int cus = vd3d_device_cu_count();
-    if (cus < 8) return VD3D_ELAUNCH;
-    int64_t grid = (ntiles + 7) / 8 * 8;                       // a multiple of 8: one lane of workgroups per XCD
-    if (grid > cus / 8 * 8) grid = cus / 8 * 8;
-    hipLaunchKernelGGL(dcn_win64_kernel<T>, dim3((unsigned)grid), dim3(256), kWinLds, s, a, (int)ntiles, tiles_x, tiles_y);
-    return vd3d_check_launch("deform_conv(window)");
-}
-
-template <typename T>
-int launch_dcn_ks64(const DcnArgs& a, hipStream_t s) {
-    static Vd3dLdsLimit lim;
-    if (const int rc = vd3d_raise_lds_limit((const void*)dcn_ks64_kernel<T>, kKsLds, lim, "hipFuncSetAttribute(dcn_ks64)")) return rc;
-    const int tiles_x = (a.Wo + 7) / 8, tiles_y = (a.Ho + 7) / 8;
-    const int64_t ntiles = (int64_t)a.B * tiles_x * tiles_y;
-    if (ntiles > 0x7fffffff) return VD3D_ERANGE;
-    const int cus = vd3d_device_cu_count();
-    if (cus < 8) return VD3D_ELAUNCH;
-    int64_t grid = (ntiles + 7) / 8 * 8;
-    if (grid > cus / 8 * 8) grid = cus / 8 * 8;
-    hipLaunchKernelGGL(dcn_ks64_kernel<T>, dim3((unsigned)grid), dim3(512), kKsLds, s, a, (int)ntiles, tiles_x, tiles_y);
-    return vd3d_check_launch("deform_conv(k-split window)");
-}
-
 template <typename T>
 int dispatch_dcn_nhwc(const DcnArgs& a, hipStream_t s) {
-    if constexpr (sizeof(T) == 2) {
-        if (dcn_win64_shape_ok(a, 2) && vd3d_switch(VD3D_SW_DCN_KSPLIT)) return launch_dcn_ks64<T>(a, s);
-        if (dcn_win64_ok(a, 2)) return launch_dcn_win64<T>(a, s);
-        // C = O = 64, 3x3 / s1 / p1 (KM3D's full-resolution DLA-Up nodes), round-4 experiments, both OPT-IN (neither beats the gather kernel inside
-        // the model): VD3D_DCN_LWIN=1 = the gather kernel with its corners from an LDS window, VD3D_DCN_BF=1 = the barrier-free kernel
-        if (dcn_win64_shape_ok(a, 2) && a.H * a.in_sy * 2 < 0x7ffffff0ll && vd3d_switch(VD3D_SW_DCN_LWIN)) return launch_dcn_lw64<T>(a, s);   // opt-in
-        if (dcn_win64_shape_ok(a, 2) && a.H * a.in_sy * 2 < 0x7ffffff0ll && vd3d_switch(VD3D_SW_DCN_BF)) return launch_dcn_bf64<T>(a, s);       // opt-in
-    }
     if (a.O > 128) return launch_dcn_nhwc<T, 256>(a, s);
     if (a.O > 64) return launch_dcn_nhwc<T, 128>(a, s);
     return launch_dcn_nhwc<T, 64>(a, s);
@@ -2131,9 +880,6 @@ extern "C" int vd3d_dcn_pack_weight(const float* w_oihw, void* packed, int O, in
 }
 
 extern "C" int vd3d_deform_conv(const vd3d_dcn_params* p, void* stream) { return launch_dcn(p, (hipStream_t)stream); }
-#ifdef VD3D_STAMPS
-extern "C" int vd3d_debug_read_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 4 * 32); }
-#endif
 
 extern "C" int64_t vd3d_deform_conv_workspace_bytes(int O, int C, int groups, int kh, int kw) {
     const int Kg = kh * kw * (C / (groups > 0 ? groups : 1));
