@@ -243,7 +243,7 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
         d[2] += 1
     for r in records:                      # the DCN launches with few channels are gather / HBM-side kernels too (64 -> 64 at full resolution)
         if r[0] == 'dcn' and r[4] and ' 64->  64 ' in r[5]:
-            d = hbm.setdefault('dcn_geo64_kernel ' + r[5], [0.0, 0.0, 0])
+            d = hbm.setdefault('dcn_nhwc_kernel ' + r[5], [0.0, 0.0, 0])
             d[0] += r[4]
             d[1] += max(r[2].elapsed_time(r[3]), 0.0) * 1e-3
             d[2] += 1

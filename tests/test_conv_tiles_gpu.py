@@ -456,3 +456,4 @@ def test_two_way_split_on_the_288_strips(dtype):
     torch.cuda.synchronize()
     assert torch.equal(a, b)
     assert ((a - c).abs().max() / c.abs().max()).item() < 2e-5
+

@@ -223,9 +223,8 @@ def test_deform_columns_wave_kernel_matches_thread_per_vector_kernel(dtype):
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('B,H,W,sigma', [(2, 21, 37, 0.5), (1, 64, 120, 0.5), (2, 16, 24, 4.0), (1, 40, 56, 1.7), (3, 8, 8, 0.3), (2, 33, 50, 40.0)])
 def test_64_to_64_kernel_views_layouts_and_oracle(dtype, B, H, W, sigma):
-    """The 64 -> 64 launch shape of KM3D's full-resolution DLA-Up nodes: dcn_geo64_kernel (round 5: barrier-free K loop, corners from global memory;
-    the four alternative kernels of rounds 3 - 4 were removed from the library, see csrc/deform_conv.hip) BIT-IDENTICAL to the tap-by-tap
-    dcn_nhwc_kernel<T, 64> it replaces (same blend order, modulation fold and k order; `VD3D_DCN_NO_GEO64=1`): sigma = spread of the learned offsets in pixels (0.3 ... 4.0, one sample far
+    """The 64 -> 64 launch shape of KM3D's full-resolution DLA-Up nodes (dcn_nhwc_kernel<T, 64>; the alternative kernels of rounds 3 - 5 were
+    removed from the library, see csrc/deform_conv.hip and profiles/r05_dcn_geo64_experiment.txt): sigma = spread of the learned offsets in pixels (0.3 ... 4.0, one sample far
     outside the image); ragged pixel counts, image borders, bias + folded BN + ReLU epilogue; a channel-slice INPUT view and a channel-slice
     OUTPUT view give the same bits as dense tensors; the logits as one packed [pixel][32] tensor (what the offset conv writes: staged through LDS)
     and as separate 18- / 9-channel tensors (the generic loader) give the same bits; and the result against the oracle (pinned to the reference's
@@ -254,18 +253,12 @@ def test_64_to_64_kernel_views_layouts_and_oracle(dtype, B, H, W, sigma):
     xwide[..., 64:] = xd
     bs = run(xwide[..., 64:], torch.empty((B, H, W, O), dtype=dtype, device='cuda'))     # channel-slice input view (pixel stride 128 elements)
     bg = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'), logits[..., :18].contiguous(), logits[..., 18:27].contiguous())
-    with _lib.test_switch('VD3D_DCN_NO_GEO64'):                   # the tap-by-tap kernel (dcn_nhwc_kernel<T, 64>), both of its logit loaders
-        old = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'))
-        with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
-            bn = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'))
-        buf_o = torch.full((B, H, W, 128), 3.0, dtype=dtype, device='cuda')
-        ao = run(xwide[..., 64:], buf_o[..., 64:])
+    with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
+        bn = run(xd, torch.empty((B, H, W, O), dtype=dtype, device='cuda'))
     torch.cuda.synchronize()
     assert torch.equal(a, b) and bool((buf[..., :64] == 3.0).all()), 'channel-slice output view'
     assert torch.equal(bs, b), 'channel-slice input view'
-    assert torch.equal(bg, b), 'separate offset / mask tensors (the tap-by-tap kernel takes those) differ from the packed logits (dcn_geo64_kernel)'
-    assert torch.equal(old, b) and torch.equal(bn, b) and torch.equal(ao[..., :], b) and bool((buf_o[..., :64] == 3.0).all()), \
-        'dcn_geo64_kernel is not bit-identical to the tap-by-tap kernel: max diff %.3e at sigma %.1f' % ((old.float() - b.float()).abs().max().item(), sigma)
+    assert torch.equal(bg, b) and torch.equal(bn, b), 'logit layouts / loaders differ'
     rnd = lambda t: t.to(dtype).float()                             # noqa: E731
     y = dcn_ref.deform_conv_forward(rnd(x).permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), torch.sigmoid(msk).permute(0, 3, 1, 2), wt, bias,
                                     1, 1, 1, 1, 1, rnd=rnd)
@@ -327,9 +320,8 @@ def test_logit_staging_of_the_gather_kernel_is_bit_identical(dtype, C, O, B, H, 
     def run():
         return ops.deform_conv_general(x, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
 
-    with _lib.test_switch('VD3D_DCN_NO_GEO64'):               # (16-bit 64 -> 64 would otherwise run dcn_geo64_kernel, which has one loader only)
-        a = run()
-        with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
-            b = run()
+    a = run()
+    with _lib.test_switch('VD3D_DCN_NO_LSTAGE'):
+        b = run()
     torch.cuda.synchronize()
     assert torch.equal(a, b), 'max diff %.3e' % (a.float() - b.float()).abs().max().item()

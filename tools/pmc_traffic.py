@@ -12,7 +12,7 @@ from visualdet3d_amd import build as _build  # noqa: E402
 
 # the HBM-bound stages north_star names: FETCH / WRITE per launch next to the launch duration of the same pass
 HBM_KERNELS = ('stem_pool_kernel', 'psm_cosine', 'cost_volume_fused_kernel', 'dwconv3x3_kernel', 'head_select_kernel', 'head_nms_kernel',
-               'dcn_nhwc_kernel', 'dcn_geo64_kernel', 'dwconvT_phase_kernel', 'image_conv7_kernel', 'conv_pair_kernel', 'look_ground_kernel')
+               'dcn_nhwc_kernel', 'dwconvT_phase_kernel', 'image_conv7_kernel', 'conv_pair_kernel', 'look_ground_kernel')
 CONV = ('conv_igemm', 'conv_halo', 'conv_resident', 'conv_regw', 'conv_ksplit', 'conv_small', 'conv_pw', 'splitk_reduce')      # (the reduction launch of a split-K convolution is part of that convolution)
 
 

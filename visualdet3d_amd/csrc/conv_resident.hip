@@ -199,6 +199,17 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead DMAs must not land in a successor workgroup's LDS
 }
 
+template <int V> struct IntC { static constexpr int value = V; };
+// compile-time loop: the body is instantiated once per index (a `#pragma unroll` loop this large may be left rolled, and a rolled
+// loop would index the weight registers dynamically, i.e. put them in scratch memory)
+template <int... Is, class F> VD3D_DEV void static_for_impl(F&& f, IntC<0>, std::integer_sequence<int, Is...>) { (f(IntC<Is>{}), ...); }
+template <int N, class F> VD3D_DEV void static_for(F&& f) { static_for_impl(f, IntC<0>{}, std::make_integer_sequence<int, N>{}); }
+
+// (Round 5, built, measured, removed -- source and numbers: profiles/r05_resident64_two_workgroups_experiment.txt: this kernel as FOUR-wave
+// workgroups, two per CU, so that one workgroup's epilogue runs under the other's MFMAs.  Bit-identical; 589 / 633 against 626 / 629 TF/s on the
+// layer-1 shape, headline 3.799 / 3.833 against 3.799 / 3.833 ms: NOTHING.  The eight-wave kernel is not held back by its waves' lock step: at
+// 3.0 - 4.5 TB/s of halo + output + residual traffic it sits at the bandwidth a mixed read / write stream gets on this part.)
+
 // =====================================================================================================
 // v6 "register-resident weights" kernel for the mid-size 3x3 / stride 1 / pad 1 layers with 128 or 256 input channels (ResNet
 // layer2 / layer3, the 256 -> 256 cls conv, DLA levels): bf16.  The tile kernels above stream the weight panel through LDS
@@ -219,11 +230,6 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
 #ifdef VD3D_TUNING
 __device__ unsigned long long g_regw_dbg[64];
 #endif
-template <int V> struct IntC { static constexpr int value = V; };
-// compile-time loop: the body is instantiated once per index (a `#pragma unroll` loop this large may be left rolled, and a rolled
-// loop would index the weight registers dynamically, i.e. put them in scratch memory)
-template <int... Is, class F> VD3D_DEV void static_for_impl(F&& f, IntC<0>, std::integer_sequence<int, Is...>) { (f(IntC<Is>{}), ...); }
-template <int N, class F> VD3D_DEV void static_for(F&& f) { static_for_impl(f, IntC<0>{}, std::make_integer_sequence<int, N>{}); }
 constexpr int kRwImg = kResStageBytes;            // 23 KiB: one 64-channel halo image of an 8 x 16 tile
 
 // RWRING = pixel-fragment ring depth (ds_read_b128 issued that many MFMAs ahead); ABL != 0: timing ablations of the tuning

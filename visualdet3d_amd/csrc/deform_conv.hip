@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
 // before any geometry, address arithmetic or epilogue; every variant runs 73 - 78 wave-instructions per pixel at 40 - 75 % VALU utilisation.
 // The packed fp16 blend (dcn_blend8_pk above, OPT-IN, halves the blend) stays outside the 2-ulp bar the teacher-forced tests hold this path to.
 
-// Round 5, a fifth one, built and removed in the same round (commit "EXPERIMENT dcn_geo64" in the history): the barrier-free kernel WITHOUT the LDS
+// Round 5, a fifth one, built and removed in the same round (source as measured + numbers: profiles/r05_dcn_geo64_experiment.txt): the barrier-free kernel WITHOUT the LDS
 // window -- lane (pixel n, k-group g) gathers its own four corners straight from global memory and the blended vector is the MFMA B fragment; evenly
 // spread geometry phase, 63 wave-instructions per pixel (ISA count; the tap-by-tap kernel: 78), 51 KB of LDS and 137 - 165 registers: three workgroups per
 // CU; bit-identical.  MEASURED (16 x 128 x 440 fp16, one box): 698 / 720 / 646 us at offsets sigma 0.5 / 1.5 / 40 px against 358 / 375 / 385 us for

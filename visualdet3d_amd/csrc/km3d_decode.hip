@@ -272,6 +272,7 @@ __global__ void __launch_bounds__(256) km3d_decode_kernel(const KArgs p) {
     __shared__ unsigned char keep[kMaxK], alive[kMaxK], chunk_alive[64];
     __shared__ int pos[kMaxK], cidx[kMaxK], scratch[32], total;
     __shared__ f32x4 chunk_box[64];
+    __shared__ uint64_t chunk_mask[64];
     __shared__ float chunk_area[64];
 
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -421,7 +422,7 @@ __global__ void __launch_bounds__(256) km3d_decode_kernel(const KArgs p) {
         f32x4 r = {det[k][0], det[k][1], det[k][2], det[k][3]};
         return r;
     };
-    nms_sorted(box, Kc, p.nms_thr, alive, chunk_box, chunk_area, chunk_alive);
+    nms_sorted(box, Kc, p.nms_thr, alive, chunk_box, chunk_area, chunk_alive, chunk_mask);
     compact_positions(alive, Kc, pos, scratch, &total);
     const int kept = total;
     for (int j = tid; j < Kc; j += blockDim.x) {

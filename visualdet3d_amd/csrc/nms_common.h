@@ -40,49 +40,55 @@ VD3D_DEV bool iou_gt(const f32x4& a, float area_a, const f32x4& b, float area_b,
     return iou > thr;
 }
 
-// Greedy NMS over K boxes already in decreasing-score order.  box(i) -> f32x4.  alive[] in LDS (bytes).
-// 64-box chunks: wave 0 resolves a chunk wave-synchronously, then every thread tests later boxes against the
-// chunk's survivors.
+// Greedy NMS over K boxes already in decreasing-score order.  box(i) -> f32x4.  alive[] in LDS (bytes).  64-box chunks.
+// Round 5: a chunk is resolved in PARALLEL.  (Before: wave 0 walked the chunk's 64 boxes one after the other -- 64 dependent steps of five
+// shuffles + an IoU test -- while the other 15 waves waited at a barrier; with ~1 500 candidates per frame (config 3's workload) the stage
+// took 400 us, with 4 000 two milliseconds.)  Now: (a) wave 0 stages the chunk's boxes; (b) every wave takes rows of the chunk's 64 x 64
+// suppression matrix: lane j tests box j against row box i, one ballot = the row's 64-bit mask; (c) the greedy pass over the chunk is then 64
+// steps of `alive &= ~mask[i]` on one 64-bit word, run redundantly by every thread (no barrier to publish it); (d) every thread tests the
+// later boxes against the chunk's survivors, as before.  A chunk without a live box costs two barriers.  Same comparisons in the same
+// operand order as the sequential walk: the same survivors.
 template <typename BoxFn>
 __device__ void nms_sorted(BoxFn box, int K, float thr, unsigned char* alive, f32x4* chunk_box, float* chunk_area,
-                           unsigned char* chunk_alive) {
-    const int lane = threadIdx.x & 63;
+                           unsigned char* chunk_alive, uint64_t* chunk_mask) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int i = threadIdx.x; i < K; i += blockDim.x) alive[i] = 1;
-    __syncthreads();
     for (int c0 = 0; c0 < K; c0 += 64) {
+        __syncthreads();                                  // alive[] of this chunk is final; the chunk buffers are free
+        const int cn = min(64, K - c0);
         if (threadIdx.x < 64) {
             const int j = c0 + lane;
             const bool in = j < K;
             f32x4 bj = {0.f, 0.f, 0.f, 0.f};
             if (in) bj = box(j);
-            const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
-            bool a = in && alive[j];
-            const int cn = min(64, K - c0);
-            for (int i = 0; i < cn; ++i) {
-                const bool ai = __shfl((int)a, i) != 0;
-                if (!ai) continue;  // wave-uniform
-                f32x4 bi;
-                bi[0] = __shfl(bj[0], i); bi[1] = __shfl(bj[1], i); bi[2] = __shfl(bj[2], i); bi[3] = __shfl(bj[3], i);
-                const float areai = __shfl(aj, i);
-                if (lane > i && a && iou_gt(bi, areai, bj, aj, thr)) a = false;
-            }
-            if (in) alive[j] = a;
             chunk_box[lane] = bj;
-            chunk_area[lane] = aj;
-            chunk_alive[lane] = a;
+            chunk_area[lane] = (bj[2] - bj[0]) * (bj[3] - bj[1]);
+            chunk_alive[lane] = in && alive[j];
         }
         __syncthreads();
-        const int cn = min(64, K - c0);
+        uint64_t am = __builtin_amdgcn_ballot_w64(chunk_alive[lane] != 0);       // the same word in every wave
+        if (!am) continue;                                // block-uniform: nothing alive in this chunk
+        const f32x4 bl = chunk_box[lane];
+        const float al = chunk_area[lane];
+        for (int i = wave; i < cn; i += nw) {
+            if (!((am >> i) & 1ull)) continue;            // wave-uniform: a dead box suppresses nothing
+            const uint64_t row = __builtin_amdgcn_ballot_w64(lane > i && lane < cn && iou_gt(chunk_box[i], chunk_area[i], bl, al, thr));
+            if (lane == 0) chunk_mask[i] = row;
+        }
+        __syncthreads();
+        for (int i = 0; i < cn; ++i)
+            if ((am >> i) & 1ull) am &= ~chunk_mask[i];   // (LDS broadcast reads; every thread computes the same word)
+        if (threadIdx.x < cn) alive[c0 + threadIdx.x] = (am >> threadIdx.x) & 1ull;
         for (int j = c0 + 64 + threadIdx.x; j < K; j += blockDim.x) {
             if (!alive[j]) continue;
             const f32x4 bj = box(j);
             const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
             for (int i = 0; i < cn; ++i) {
-                if (chunk_alive[i] && iou_gt(chunk_box[i], chunk_area[i], bj, aj, thr)) { alive[j] = 0; break; }
+                if (((am >> i) & 1ull) && iou_gt(chunk_box[i], chunk_area[i], bj, aj, thr)) { alive[j] = 0; break; }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // block-wide order-preserving compaction positions: pos[i] = number of set flags before i; *total = count.

@@ -62,63 +62,83 @@ __global__ void zero_counts_kernel(int32_t* c, int n) {
     if (i < n) c[i] = 0;
 }
 
-// ---- stage 1: mask + sigmoid + threshold -> candidate list (unordered, atomics) ----------------------
-__global__ void __launch_bounds__(kSelThreads) head_select_kernel(const HeadArgs p) {
-    const int64_t total = (int64_t)p.B * p.N;
-    const int nc1 = p.n_cls + 1;
-    const int lane = threadIdx.x & 63;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    // every lane of a wave runs the same number of iterations (the bound is rounded up to whole waves), so the ballots below see all
-    // 64 lanes; lanes past the end simply never hit
-    const int64_t total_up = (total + 63) / 64 * 64;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total_up; i += stride) {
-        const bool in = i < total;
-        const int b = in ? (int)(i / p.N) : -1;
-        const int n = in ? (int)(i - (int64_t)b * p.N) : 0;
-        bool useful = in;
-        if (in && p.use_filter) {
-            // heads/anchors.py:99-111 -- both back-projections divide by fy
-            const int a = n % p.A;
-            const float* P = p.P2 + b * 12;
-            const float fy = P[5], cy = P[6], cx = P[2];
-            const f32x4 an = *(const f32x4*)(p.anchors + (int64_t)n * 4);
-            const float xc = (an[0] + an[2]) / 2.0f, yc = (an[1] + an[3]) / 2.0f;
-            useful = false;
-            for (int t = 0; t < p.n_types; ++t) {
-                const float z = p.prior[((a * p.n_types + t) * 6 + 0) * 2 + 0];
-                const float x3d = (xc * z - cx * z) / fy;
-                const float y3d = (yc * z - cy * z) / fy;
-                useful |= (y3d > p.y_min) && (y3d < p.y_max) && (fabsf(x3d) < p.x_max);
+// ---- stage 1: mask + sigmoid + threshold -> candidate list (unordered) ---------------------------------
+// A workgroup owns ONE chunk of ONE sample's anchors (grid = chunks x samples, <= 64 iterations of 256 anchors) and appends all of its
+// candidates with ONE atomic: pass 1 evaluates every anchor, counts the hits per wave (ballot + popcount) and remembers each lane's hits as
+// one bit per iteration; the wave counts meet in LDS, thread 0 reserves the workgroup's range of the sample's list; pass 2 walks the hit
+// bits again (a wave without hits in an iteration skips it) and writes (anchor, score) at base + rank.  History: one atomic per candidate
+// serialised on the sample's counter (277 us at 32 x 69 120 anchors with thousands of candidates per frame); one per (wave, sample) still did:
+// config 3's launch took 496 us for 26 MB of logits -- ~900 dependent atomics per counter; now 16 per counter.
+// (The list is unordered either way: stage 2 sorts it into anchor order.)
+VD3D_DEV bool head_anchor_hit(const HeadArgs& p, int b, int n, float& best) {
+    bool useful = true;
+    if (p.use_filter) {
+        // heads/anchors.py:99-111 -- both back-projections divide by fy
+        const int a = n % p.A;
+        const float* P = p.P2 + b * 12;
+        const float fy = P[5], cy = P[6], cx = P[2];
+        const f32x4 an = *(const f32x4*)(p.anchors + (int64_t)n * 4);
+        const float xc = (an[0] + an[2]) / 2.0f, yc = (an[1] + an[3]) / 2.0f;
+        useful = false;
+        for (int t = 0; t < p.n_types; ++t) {
+            const float z = p.prior[((a * p.n_types + t) * 6 + 0) * 2 + 0];
+            const float x3d = (xc * z - cx * z) / fy;
+            const float y3d = (yc * z - cy * z) / fy;
+            useful |= (y3d > p.y_min) && (y3d < p.y_max) && (fabsf(x3d) < p.x_max);
+        }
+    }
+    best = 0.f;
+    if (!useful) return false;
+    const float* c = p.cls + ((int64_t)b * p.N + n) * (p.n_cls + 1);
+    best = sigmoidf_(c[0]);
+    for (int k = 1; k < p.n_cls; ++k) best = fmaxf(best, sigmoidf_(c[k]));
+    return best > p.score_thr;
+}
+
+__global__ void __launch_bounds__(kSelThreads) head_select_kernel(const HeadArgs p, int chunk) {
+    __shared__ int wsum[kSelThreads / 64];
+    __shared__ int wg_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int n0 = blockIdx.x * chunk;
+    const int n1 = n0 + chunk < p.N ? n0 + chunk : p.N;
+    const int iters = (n1 - n0 + kSelThreads - 1) / kSelThreads;           // <= 64 (host)
+    uint64_t mine = 0;                                                      // bit `it`: this lane's anchor of iteration `it` is a candidate
+    int wcount = 0;
+    for (int it = 0; it < iters; ++it) {
+        const int n = n0 + it * kSelThreads + tid;
+        float best;
+        const bool hit = n < n1 && head_anchor_hit(p, b, n, best);
+        wcount += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+        if (hit) mine |= 1ull << it;
+    }
+    if (lane == 0) wsum[wave] = wcount;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < kSelThreads / 64; ++w) tot += wsum[w];
+        wg_base = tot ? atomicAdd(p.ws.count + b, tot) : 0;                 // ONE atomic per workgroup, none without candidates
+    }
+    __syncthreads();
+    int run = wg_base;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    if (wcount == 0) return;                                                // (wave-uniform)
+    for (int it = 0; it < iters; ++it) {
+        const bool hit = (mine >> it) & 1ull;
+        const uint64_t grp = __builtin_amdgcn_ballot_w64(hit);
+        if (!grp) continue;
+        if (hit) {
+            const int n = n0 + it * kSelThreads + tid;
+            float best;
+            head_anchor_hit(p, b, n, best);                                 // the same arithmetic again: the score of a hit (its bits are the list's)
+            const int pos = run + __builtin_popcountll(grp & ((1ull << lane) - 1ull));
+            if (pos < p.max_cand) {
+                p.ws.cand_idx[(int64_t)b * p.max_cand + pos] = n;
+                p.ws.cand_score[(int64_t)b * p.max_cand + pos] = best;
             }
         }
-        float best = 0.f;
-        bool hit = false;
-        if (useful) {
-            const float* c = p.cls + i * nc1;
-            best = sigmoidf_(c[0]);
-            for (int k = 1; k < p.n_cls; ++k) best = fmaxf(best, sigmoidf_(c[k]));
-            hit = best > p.score_thr;
-        }
-        // append the wave's candidates with ONE atomic per (wave, sample) instead of one per candidate: with thousands of candidates
-        // per frame (low threshold) the per-candidate atomics on the sample's single counter serialised -- 277 us at 32 x 69120 anchors.
-        // (The list is unordered either way: stage 2 sorts it into anchor order.)
-        uint64_t pending = __builtin_amdgcn_ballot_w64(hit);
-        while (pending) {
-            const int leader = __builtin_ctzll(pending);
-            const int bl = __shfl(b, leader);
-            const uint64_t grp = __builtin_amdgcn_ballot_w64(hit && b == bl);     // this sample's candidates of the wave (a wave spans <= 2 samples)
-            int base = 0;
-            if (lane == leader) base = atomicAdd(p.ws.count + bl, __builtin_popcountll(grp));
-            base = __shfl(base, leader);
-            if (hit && b == bl) {
-                const int pos = base + __builtin_popcountll(grp & ((1ull << lane) - 1ull));
-                if (pos < p.max_cand) {
-                    p.ws.cand_idx[(int64_t)b * p.max_cand + pos] = n;
-                    p.ws.cand_score[(int64_t)b * p.max_cand + pos] = best;
-                }
-            }
-            pending &= ~grp;
-        }
+        run += __builtin_popcountll(grp);
     }
 }
 
@@ -328,6 +348,8 @@ __global__ void __launch_bounds__(kNmsThreads) head_nms_kernel(const HeadArgs p)
     unsigned char* alive = flag + p.max_cand;                          // [max_cand]
     unsigned char* chunk_alive = alive + p.max_cand;                   // [64]
     int* total = (int*)(chunk_alive + 64);
+    uint64_t* chunk_mask = (uint64_t*)(((uintptr_t)(total + 4) + 15) & ~(uintptr_t)15);      // [64] rows of the chunk's suppression matrix
+    f32x4* sbox = p.max_cand <= 4096 ? (f32x4*)(chunk_mask + 64) : nullptr;   // [max_cand] 2-D boxes in NMS order (when they fit; else from global)
 
     const int64_t cb = (int64_t)b * p.max_cand;
     // 1. anchor order (boolean-mask indexing in the reference preserves anchor order)
@@ -371,7 +393,15 @@ __global__ void __launch_bounds__(kNmsThreads) head_nms_kernel(const HeadArgs p)
         f32x4 r = {o[0], o[1], o[2], o[3]};
         return r;
     };
-    nms_sorted(box, Kc, p.nms_thr, alive, chunk_box, chunk_area, chunk_alive);
+    if (sbox) {
+        // the boxes once, in NMS order, into LDS: the greedy pass reads every live box once per chunk -- through two indirections into
+        // global memory that was a dependent L2 round trip per chunk and thread
+        for (int j = threadIdx.x; j < Kc; j += blockDim.x) sbox[j] = box(j);
+        __syncthreads();
+        nms_sorted([&](int j) -> f32x4 { return sbox[j]; }, Kc, p.nms_thr, alive, chunk_box, chunk_area, chunk_alive, chunk_mask);
+    } else {
+        nms_sorted(box, Kc, p.nms_thr, alive, chunk_box, chunk_area, chunk_alive, chunk_mask);
+    }
     compact_positions(alive, Kc, pos, scratch, total);
     const int kept = *total;
     const int nout = min(kept, p.max_det);
@@ -402,12 +432,13 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(const float* __restric
     float* chunk_area = (float*)(chunk_box + 64);
     unsigned char* chunk_alive = (unsigned char*)(chunk_area + 64);
     int* total = (int*)(chunk_alive + 64);
+    uint64_t* chunk_mask = (uint64_t*)(((uintptr_t)(total + 4) + 15) & ~(uintptr_t)15);
     for (int i = threadIdx.x; i < P; i += blockDim.x)
         keys[i] = i < n ? (((uint64_t)orderable_desc(scores[i]) << 32) | (uint32_t)i) : ~0ull;
     __syncthreads();
     bitonic_sort(keys, P);
     auto box = [&](int j) -> f32x4 { return *(const f32x4*)(boxes + (int64_t)(uint32_t)keys[j] * 4); };
-    nms_sorted(box, n, thr, alive, chunk_box, chunk_area, chunk_alive);
+    nms_sorted(box, n, thr, alive, chunk_box, chunk_area, chunk_alive, chunk_mask);
     compact_positions(alive, n, pos, scratch, total);
     for (int j = threadIdx.x; j < n; j += blockDim.x)
         if (alive[j]) keep[pos[j]] = (int32_t)(uint32_t)keys[j];
@@ -415,14 +446,15 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(const float* __restric
 }
 
 inline int64_t head_nms_lds(int max_cand) {
-    const int64_t block_path = (int64_t)max_cand * 8 + (int64_t)max_cand * 8 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + max_cand * 2 + 64 + 16;
+    const int64_t block_path = (int64_t)max_cand * 8 + (int64_t)max_cand * 8 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + max_cand * 2 + 64 + 16 + 32 + 64 * 8 +
+                               (max_cand <= 4096 ? (int64_t)max_cand * 16 : 0);      // + chunk masks + (when they fit) the boxes in NMS order
     const int64_t wave_path = kWaveCand * (8 + 16 + 44 + 4 * 7 + 1) + 64;      // head_nms_wave's carve (24.3 KB)
     return block_path > wave_path ? block_path : wave_path;
 }
 inline int64_t nms_lds(int n) {
     int P = 1;
     while (P < n) P <<= 1;
-    return (int64_t)P * 8 + ((n + 15) / 16) * 16 + (int64_t)n * 4 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + 64 + 16;
+    return (int64_t)P * 8 + ((n + 15) / 16) * 16 + (int64_t)n * 4 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + 64 + 16 + 32 + 64 * 8;   // (+ chunk masks)
 }
 
 }  // namespace
@@ -458,10 +490,14 @@ extern "C" int vd3d_head_select(const vd3d_head_params* q, void* stream) {
     if (const int rc = head_args(q, a, true, false)) return rc;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(zero_counts_kernel, dim3((q->B + 63) / 64), dim3(64), 0, s, a.ws.count, q->B);
-    const int64_t total = (int64_t)q->B * q->N;
-    int64_t g = (total + kSelThreads - 1) / kSelThreads;
-    if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(head_select_kernel, dim3((unsigned)g), dim3(kSelThreads), 0, s, a);
+    // chunks x samples workgroups: ~512 in all (two per CU), a chunk a multiple of 256 anchors and at most 64 iterations of them
+    int cps = (512 + q->B - 1) / q->B;
+    const int max_cps = (q->N + kSelThreads - 1) / kSelThreads, min_cps = (q->N + 64 * kSelThreads - 1) / (64 * kSelThreads);
+    if (cps > max_cps) cps = max_cps;
+    if (cps < min_cps) cps = min_cps;
+    const int chunk = ((q->N + cps - 1) / cps + kSelThreads - 1) / kSelThreads * kSelThreads;
+    if (q->B > 65535) { vd3d_set_error("head_select: more than 65535 samples"); return VD3D_ERANGE; }
+    hipLaunchKernelGGL(head_select_kernel, dim3((unsigned)((q->N + chunk - 1) / chunk), (unsigned)q->B), dim3(kSelThreads), 0, s, a, chunk);
     return vd3d_check_launch("head_select");
 }
 
