@@ -29,18 +29,30 @@ _VERSION = attrgetter('_version')
 _MAX_GRAPHS = 8          # per model; each holds the activations of its shape in a private pool (least recently USED goes first)
 
 
+_SCALARS = (int, float, bool, str, type(None), torch.dtype)
+
+
 def _plain(v):
-    """a hashable, by-value form of a launch-time setting (tuples / lists / numpy scalars / tensors of the anchor filter)"""
+    """a hashable, by-value form of a launch-time setting (tuples / lists / numpy scalars / tensors of the anchor filter); the common cases
+    (python scalars, tuples of them) cost one type test -- this runs on every call"""
+    t = type(v)
+    if t in _SCALARS:
+        return v
+    if t is tuple:
+        for x in v:
+            if type(x) not in _SCALARS:
+                return tuple(_plain(y) for y in v)
+        return v
     if isinstance(v, torch.Tensor):
         return tuple(v.detach().reshape(-1).tolist())
     if isinstance(v, (list, tuple)):
         return tuple(_plain(x) for x in v)
-    if hasattr(v, 'item') and not isinstance(v, (int, float, bool)):
+    if hasattr(v, 'item'):
         try:
             return v.item()
         except Exception:                        # noqa: BLE001 -- not a scalar: its repr will do
             return repr(v)
-    return v
+    return v if getattr(v, '__hash__', None) else repr(v)
 
 
 class _Entry:
@@ -71,25 +83,41 @@ class GraphedForward:
         st = self._graph_state()
         st['entries'].clear()
         st['tensors'] = None
+        self.__dict__.pop('_vd3d_knob_plan', None)   # (sub-modules may have been replaced)
 
     def _apply(self, fn, *a, **k):
         self.drop_graphs()                       # storages are about to be replaced
         return super()._apply(fn, *a, **k)
 
+    _KNOBS = (('bbox_head', ('overlap_towers', 'overlap_select', 'max_candidates', 'max_peaks', 'TOPK')), ('core', ('overlap_neck',)),
+              ('bbox_head.anchors', ('filter_y_threshold_min_max', 'filter_x_threshold', 'readConfigFile')))
+
     def _graph_knobs(self):
-        head = getattr(self, 'bbox_head', None)
-        core = getattr(self, 'core', None)
-        tc = getattr(head, 'test_cfg', None)
-        knobs = [self.compute_dtype, self.training, _lib.hook_epoch()]
-        anchors = getattr(head, 'anchors', None)
-        for obj, names in ((head, ('overlap_towers', 'overlap_select', 'max_candidates', 'max_peaks', 'TOPK')), (core, ('overlap_neck',)),
-                           (anchors, ('filter_y_threshold_min_max', 'filter_x_threshold', 'is_filtering', 'readConfigFile'))):
-            knobs += [_plain(getattr(obj, n, None)) for n in names]
-        for cfg_name in ('loss_cfg',):           # filter_anchor of the loss config is the eval default (detection_3d_head._is_filtering)
-            knobs += [_plain(getattr(getattr(head, cfg_name, None), 'filter_anchor', None))]
-        if tc is not None:
-            knobs += [repr(sorted(tc.items())) if hasattr(tc, 'items') else repr(tc)]
-        return tuple(knobs)
+        """everything the launches read at call time besides inputs and weights, by value.  Runs on every call: which of the settings exist on
+        this model is found out once (a missing attribute of an nn.Module costs a raised AttributeError), afterwards it is attribute reads."""
+        plan = self.__dict__.get('_vd3d_knob_plan')
+        if plan is None:
+            plan = []
+            for path, names in self._KNOBS:
+                obj = self
+                for part in path.split('.'):
+                    obj = getattr(obj, part, None)
+                if obj is not None:
+                    plan += [(obj, n) for n in names if hasattr(obj, n)]
+            self.__dict__['_vd3d_knob_plan'] = plan
+        tc = getattr(self.bbox_head, 'test_cfg', None) if 'bbox_head' in self._modules else None
+        if isinstance(tc, dict):
+            try:
+                tcv = (len(tc),) + tuple(map(_plain, tc.values()))
+                hash(tcv)
+            except TypeError:
+                tcv = repr(sorted(tc.items()))
+        else:
+            tcv = repr(tc)
+        # filter_anchor of the loss config is the eval default (detection_3d_head._is_filtering); a dict lookup, present or not
+        lc = getattr(self.bbox_head, 'loss_cfg', None) if 'bbox_head' in self._modules else None
+        fa = _plain(lc.get('filter_anchor')) if isinstance(lc, dict) else None
+        return (self.compute_dtype, self.training, _lib.hook_epoch(), tcv, fa) + tuple(_plain(getattr(o, n)) for o, n in plan)
 
     def _graphed(self, *inputs):
         if not self.use_graph or torch.cuda.is_current_stream_capturing():
