@@ -27,6 +27,7 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('head 1408->256', 8, 24, 80, 1408, 256),
     ('cls 256->144', 8, 24, 80, 256, 144),
     ('cls 256->256', 8, 24, 80, 256, 256),
+    ('c3 dcn gemm 1x1 19584->2176', 32, 18, 80, 19584, 2176, 1),       # config 3's column GEMM (K = 9 x 2176 sampled columns)
 ]
 cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
 
@@ -40,12 +41,13 @@ import os
 if os.environ.get('VD3D_SHAPES'):
     SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ['VD3D_SHAPES'].split(','))]
 torch.manual_seed(0)
-for name, B, H, W, Cin, Cout in SHAPES:
+for name, B, H, W, Cin, Cout, *kk in SHAPES:
+    ks = kk[0] if kk else 3
     x = torch.randn(B, H, W, Cin, device='cuda').to(torch.bfloat16)
-    w = torch.randn(Cout, Cin, 3, 3, device='cuda') * (2.0 / (9 * Cin)) ** 0.5
-    pc = ops.pack_conv(w, None, None, torch.bfloat16, 1, 1, 1)
+    w = torch.randn(Cout, Cin, ks, ks, device='cuda') * (2.0 / (ks * ks * Cin)) ** 0.5
+    pc = ops.pack_conv(w, None, None, torch.bfloat16, 1, ks // 2, 1)
     res = torch.randn(B, H, W, Cout, device='cuda').to(torch.bfloat16)
-    flops = 2.0 * B * H * W * Cout * 9 * Cin
+    flops = 2.0 * B * H * W * Cout * ks * ks * Cin
     ref = None
     line = '%-18s' % name
     ok_cfgs, best = [], {}
