@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         for (int pi = 0; pi < NPIECE; ++pi) {
             if ((pi & 3) != g) continue;
             if (ABL == 6 && pi < A_PIECES) continue;      // timing ablations: 6 = no pixel DMA, 7 = no weight DMA
-            if (ABL == 7 && pi >= A_PIECES) continue;
+            if (ABL == 7 && pi >= A_PIECES) continue;      // (ABL >= 8: VALU injection, the DMA schedule stays complete)
             if (pi < A_PIECES) {
                 const int it = pi;
                 const bool v = kvalid && (unsigned)(a_iy[it] + ddy) < (unsigned)p.H && (unsigned)(a_ix[it] + ddx) < (unsigned)p.W;
@@ -804,6 +804,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         static_assert((NSUB * TN) % R == 0 && R <= TN, "fragment ring");
         constexpr int F0 = NSUB * TN - R;      // first fragment whose refill comes from the NEXT slice: the barrier sits here
         i32x4 fa[R], fb[2][TM];
+        [[maybe_unused]] float abl_v[4] = {1.f, 2.f, 3.f, 4.f}, abl_w = 0.5f;     // (ABL 8 - 10: operands of the injected VALU work)
 #pragma unroll
         for (int i = 0; i < R; ++i) fa[i] = ld_w(0, 0, i);
 #pragma unroll
@@ -821,14 +822,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                     // landed for everybody: after the barrier the stage is free for slice t+2 and the ring starts
                     // refilling from slice t+1.
                     // ABL != 0: timing ablations for tools/bench_conv.py (WRONG results): 1 = no barrier, 2 = no DMA wait, 3 = neither
-                    if constexpr (ABL == 0 || ABL == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if constexpr (ABL == 0 || ABL == 1 || ABL >= 8) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if constexpr (ABL == 0 || ABL == 2) __builtin_amdgcn_s_barrier();   // 4: MFMA only, 5: MFMA + ds_read
+                    if constexpr (ABL == 0 || ABL == 2 || ABL >= 8) __builtin_amdgcn_s_barrier();   // 4: MFMA only, 5: MFMA + ds_read
                     asm volatile("" ::: "memory");
                     // DMA of slice t+2: half of it here, the rest at the top of the next slice -- everything is in flight
                     // within the first tenth of a slice, i.e. has ~0.9 slice times to land before its barrier (PMC: with
                     // the pieces spread evenly over the slice a third of the wave cycles were spent parked at that barrier)
-                    if constexpr (ABL < 4) {
+                    if constexpr (ABL < 4 || ABL >= 8) {
                         if (!hiw) { issue_group(st, 0, more2); issue_group(st, 1, more2); }
                     }
                 }
@@ -843,7 +844,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                 }
                 if (i == 0 && ks == 0) {
                     if (!hiw) {
-                        if constexpr (ABL < 4) { issue_group(st ^ 1, 2, more1); issue_group(st ^ 1, 3, more1); }
+                        if constexpr (ABL < 4 || ABL >= 8) { issue_group(st ^ 1, 2, more1); issue_group(st ^ 1, 3, more1); }
                         advance_k();
                     }
                 }
@@ -859,6 +860,17 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
                 }
 #pragma unroll
                 for (int j = 0; j < TM; ++j) MmaShape<T, MS>::run(fa[f % R], fb[ks & 1][j], acc[i][j]);
+                if constexpr (ABL >= 8) {
+                    // timing experiment (tuning build only; results stay correct): INJECT the VALU issue load that blending the pixel operand inside this
+                    // loop would add (config 3's DCN sampling fused into the strip GEMM).  Four independent fma chains
+                    // (the blend has that much ILP), no memory traffic: 8 = 17 per fragment (~304 per 64-deep slice and wave on the 288 strip: the
+                    // bf16 blend of this wave's 32 x 64 share incl. unpack / pack), 9 = 9 (~160: an fp16 blend on v_fma_mix); 20 + n = n per fragment
+                    // (20 = none: only the empty volatile asm, i.e. its effect on the compiler's schedule)
+                    constexpr int NV = ABL == 8 ? 17 : (ABL == 9 ? 9 : ABL - 20);
+                    if constexpr (NV == 0) asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(abl_v[q & 3]) : "v"(abl_w));
+                }
                 const int nf = f + R, nks = nf / TN, ni = nf - nks * TN;
                 if constexpr (ABL != 4) fa[f % R] = ld_w(nks < NSUB ? st : st ^ 1, nks % NSUB, ni);
                 // pin the schedule (otherwise the scheduler sinks every ds_read to its use): MFMAs of this fragment, its
@@ -1517,6 +1529,20 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 33: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 5>(a, stream));
         case 38: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16, 0, 0, false, 6>(a, stream));      // 128 x 288 (1408 -> 576): 18 fragments, barrier at 16
         case 39: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16, 0, 0, false, 8>(a, stream));
+        // config 3's column GEMM with the blend's VALU load injected into the 288 strip (ring 6, one DMA schedule: what the grouped GEMM runs)
+        case 111: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 29>(a, stream));   // 9 per fragment (~160 per slice and wave: an fp16 blend)
+        case 112: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 37>(a, stream));   // 17 (~304: the bf16 blend incl. unpack / pack)
+        case 113: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 54>(a, stream));   // 34
+        case 101: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream));       // the same instantiation without injection
+        case 102: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 20>(a, stream));   // empty volatile asm per fragment
+        case 103: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 21>(a, stream));   // 1 VALU per fragment
+        case 104: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 23>(a, stream));   // 3
+        case 105: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 26>(a, stream));   // 6
+        case 106: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 32>(a, stream));   // 12
+        case 107: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 29, false, 5>(a, stream));   // the production 288 strip (STG 5) + 9 per fragment
+        case 108: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 29, false, 8>(a, stream));   // the production 352 strip (STG 8) + 9 per fragment
+        case 109: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 26, false, 8>(a, stream));   // ... + 6
+        case 110: VD3D_BF16_ONLY(launch<T, 256, 352, 4, 2, true, true, 16, 0, 20, false, 8>(a, stream));   // ... + empty asm
         case 74: VD3D_BF16_ONLY(launch<T, 64, 144, 2, 1, true, true, 16>(a, stream));
         case 75: VD3D_BF16_ONLY(launch<T, 128, 288, 2, 2, true, true, 16>(a, stream));
         case 71: VD3D_HALO_ONLY(launch_halo<T, 8, 16, 128, 4, 1, 2>(a, stream));
