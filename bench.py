@@ -578,6 +578,11 @@ def time_api_config(c, device, calls=100, warm=10):
 
 def main():
     args = parse()
+    # stdout carries the ONE JSON line and nothing else: keep a private handle on the real stdout and point fd 1 at stderr, so that whatever else
+    # writes to stdout -- RCCL prints its version banner through C stdio, flushed at exit, i.e. AFTER a Python print -- lands on stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -588,7 +593,8 @@ def main():
         port = cpu_baseline(cfg, sd, args)
         del os.environ['VD3D_BENCH_CPU_PORT']
         ref = cpu_baseline(cfg, sd, args)
-        print(json.dumps({'cpu_baseline_port': port, 'cpu_baseline': ref}))
+        json_out.write(json.dumps({'cpu_baseline_port': port, 'cpu_baseline': ref}) + '\n')
+        json_out.flush()
         return
     assert torch.cuda.is_available(), 'bench.py measures the MI355X HIP path; no GPU visible'
     torch.cuda.set_device(local_rank)              # before the process group: RCCL binds to the current device
@@ -796,7 +802,8 @@ def main():
             line['other_configs'] = others
         if not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg, sd, args)
-        print(json.dumps(line))
+        json_out.write(json.dumps(line) + '\n')
+        json_out.flush()
     if dist:
         td.barrier()
         td.destroy_process_group()
