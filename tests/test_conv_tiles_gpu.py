@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 76, 79, 73, 61, 68, 69, 58, 70}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 52, 76, 79, 73, 61, 68, 69, 58, 70}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64, 130: 64}       # tiles whose N extent bounds Cout in production (130: the split-K form of the 128 x 64 tile)
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130]   # 144 / 130: split-K (two launches)
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 52, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130]   # 144 / 130: split-K (two launches)
 
 
 class forced_tile:
@@ -236,7 +236,7 @@ BENCH_SHAPES = [
     ('ghost 384->384', 8, 24, 80, 384, 384, dict()),
     ('neck 288->288 + res', 8, 24, 80, 288, 288, dict(residual=True)),              # 128x144 16x16x32
     ('cls 256->256', 8, 24, 80, 256, 256, dict(bn=False)),                          # register-resident weights, 4 slices
-    ('r50 head 2176->2176', 16, 18, 80, 2176, 2176, dict(residual=True)),           # 256x272 16x16x32 strips
+    ('r50 head 2176->2176', 16, 18, 80, 2176, 2176, dict(residual=True)),           # 256x320 16x16x32 strips (6.8 of them)
 ]
 
 
@@ -417,7 +417,7 @@ def test_staggered_dma_schedule_of_the_strips_is_bit_identical(shape, dtype):
     res = torch.randn(B, H, W, Cout, generator=g).cuda().to(dtype)
     pc = ops.pack_conv(w, None, None, dtype, 1, 1, 1)
     outs = []
-    for tile in (50, 54):
+    for tile in (50, 54, 52):
         with forced_tile(tile):
             a = ops.conv2d(x, pc, residual=res, relu=True)
             with _lib.test_switch('VD3D_CONV_NO_STAGGER'):

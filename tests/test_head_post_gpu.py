@@ -55,6 +55,33 @@ def test_head_postprocess_matches_oracle(H, W, B, seed, std):
     assert total >= 5, 'test inputs produced too few detections to be meaningful'
 
 
+@pytest.mark.parametrize('max_cand', [256, 2048, 4096, 8192])
+def test_head_postprocess_every_nms_path_same_selection(max_cand):
+    """The three NMS routes of vd3d_head_postprocess -- one wave per frame (<= 256 candidates), the block path with its boxes in LDS
+    (capacity <= 4096) and the block path reading them from the workspace (8192) -- against the oracle on inputs sized for each:
+    ~60 candidates for the wave path, 1 300 - 1 500 (twenty-odd chunks of 64, most of them with survivors AND suppressions) for the others."""
+    H, W, B = (96, 320, 2) if max_cand == 256 else (192, 640, 2)
+    cfg, head, cls, reg, P2 = _setup(H, W, B, 11, logit_bias=-2.2 if max_cand == 256 else -0.8, logit_std=1.2)
+    head.max_candidates = max_cand
+    mean_npy, std_npy = orc.load_priors(cfg.head.preprocessed_path, cfg.obj_types)
+    anchors, means, mean_std = orc.anchors_for_image(H, W, cfg.head.anchors_cfg, mean_npy, std_npy)
+    mask = orc.anchor_mask(anchors, means, P2)
+    padded = head.get_bboxes_batched(cls.cuda(), reg.cuda(), P2.cuda(), (H, W))
+    torch.cuda.synchronize()
+    scores, boxes, labels, aidx, count = [t.cpu() for t in padded]
+    for b in range(B):
+        s, bx, l, idx = orc.get_bboxes(cls[b], reg[b], anchors, mean_std, mask[b], (H, W), 2, 0.6, 0.4)
+        ncand = int(((torch.sigmoid(cls[b][:, :2]).amax(dim=1) > 0.6) & mask[b]).sum())
+        if max_cand == 256:
+            assert 20 < ncand <= 256, ncand
+        else:
+            assert 1000 < ncand <= 2048, ncand
+        k = int(count[b])
+        assert k == len(s) and k >= 5, (b, k, len(s))
+        assert torch.equal(aidx[b, :k].long(), idx), 'sample %d: anchor selection / order differs' % b
+        assert torch.equal(labels[b, :k].long(), l)
+
+
 def test_head_candidate_overflow_is_reported():
     cfg, head, cls, reg, P2 = _setup(96, 320, 1, 3, logit_bias=3.0)
     head.max_candidates = 64
@@ -78,6 +105,50 @@ def test_nms_bit_exact(n, seed):
     want = nms_numpy(boxes, scores, 0.45)
     got = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), 0.45).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+def _nms_case(kind, n, rng):
+    if kind == 'identical':            # one survivor: box 0 suppresses every other box of every chunk
+        boxes = np.tile(np.array([[10, 10, 60, 50]], np.float32), (n, 1))
+    elif kind == 'disjoint':           # nothing suppresses anything: every chunk's 64 x 64 matrix is empty
+        i = np.arange(n, dtype=np.float32)
+        boxes = np.stack([20 * (i % 97), 20 * (i // 97), 20 * (i % 97) + 10, 20 * (i // 97) + 10], 1).astype(np.float32)
+    elif kind == 'chain':              # a sliding row in score order: i suppresses i+1 (IoU 0.82), i+1 is dead so i+2 (IoU 0.67) is tested
+        i = np.arange(n, dtype=np.float32)      # against i only, ... -- the greedy order INSIDE a chunk and across chunk borders decides
+        boxes = np.stack([i * 2.0, np.zeros(n, np.float32), i * 2.0 + 20, np.full(n, 10, np.float32)], 1).astype(np.float32)
+    elif kind == 'clusters':           # ~n/40 clusters of heavily overlapping boxes, scores interleaved across clusters
+        c = rng.integers(0, max(1, n // 40), n)
+        ctr = np.stack([60.0 * (c % 25), 60.0 * (c // 25)], 1) + rng.uniform(-6, 6, (n, 2))
+        wh = rng.uniform(30, 44, (n, 2))
+        boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+    else:
+        raise KeyError(kind)
+    if kind == 'chain':
+        scores = np.linspace(1.0, 0.1, n).astype(np.float32)       # score order = position order
+    else:
+        scores = rng.uniform(0, 1, n).astype(np.float32)
+    return boxes, scores
+
+
+@pytest.mark.parametrize('kind', ['identical', 'disjoint', 'chain', 'clusters'])
+@pytest.mark.parametrize('n', [63, 64, 65, 128, 129, 1025, 4096, 4097])
+def test_nms_structured_cases_bit_exact(kind, n):
+    """vd3d_nms against torchvision's algorithm (oracle/nms_ref.py) on inputs built to stress the chunked greedy pass: sizes on either side of the
+    64-box chunk and of the 4096-box capacity steps; a lone survivor, no suppression at all, a chain whose outcome depends on the greedy
+    order inside a chunk and across chunk borders, and dense clusters."""
+    from visualdet3d_amd import hip_ops as ops
+    rng = np.random.default_rng(n * 7 + len(kind))
+    boxes, scores = _nms_case(kind, n, rng)
+    for thr in (0.45, 0.7):
+        want = nms_numpy(boxes, scores, thr)
+        got = ops.nms(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), thr).cpu().numpy()
+        assert np.array_equal(got, want), (kind, n, thr, len(got), len(want))
+    if kind == 'identical':
+        assert len(want) == 1
+    if kind == 'disjoint':
+        assert len(want) == n
+    if kind == 'chain':
+        assert 1 < len(want) < n
 
 
 def test_get_bboxes_reference_signature_no_clip_and_cls_agnostic_flag():

@@ -22,11 +22,18 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('head 1408->1408', 8, 24, 80, 1408, 1408),
     ('head 1408->576', 8, 24, 80, 1408, 576),
     ('r50head 2176->2176', 16, 18, 80, 2176, 2176),
+    ('r50head32 2176->2176', 32, 18, 80, 2176, 2176),        # config 3's own batch: 180 pixel tiles
     ('r50 reg 2176->576', 32, 18, 80, 2176, 576),
     ('r50 cls 2176->256', 32, 18, 80, 2176, 256),
     ('head 1408->256', 8, 24, 80, 1408, 256),
     ('cls 256->144', 8, 24, 80, 256, 144),
     ('cls 256->256', 8, 24, 80, 256, 256),
+    ('r50 l1 down 1x1 256->64', 64, 72, 320, 256, 64, 1),            # config 3's bottleneck 1x1 convs (HBM-side: K is 1 - 16 slices)
+    ('r50 l2 down 1x1 512->128', 64, 36, 160, 512, 128, 1),
+    ('r50 l3 down 1x1 1024->256', 64, 18, 80, 1024, 256, 1),
+    ('r50 l1 up 1x1 64->256', 64, 72, 320, 64, 256, 1),
+    ('r50 l2 up 1x1 128->512', 64, 36, 160, 128, 512, 1),
+    ('r50 l3 up 1x1 256->1024', 64, 18, 80, 256, 1024, 1),
     ('c3 dcn gemm 1x1 19584->2176', 32, 18, 80, 19584, 2176, 1),       # config 3's column GEMM (K = 9 x 2176 sampled columns)
 ]
 cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]

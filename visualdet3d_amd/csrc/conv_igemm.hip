@@ -1388,6 +1388,20 @@ int launch_strip288(ConvArgs& a, hipStream_t stream) {
     if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER) || a.group_m > 0) return launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream);
     return launch<T, 256, 288, 4, 2, true, true, 16, 6, 0, false, 5>(a, stream);
 }
+// Round 5: a 320-wide strip for Cout = 2176 (config 3's R50 head: 2176 -> 2176 and the 19 584-deep DCN column GEMM).  On the 288 strip that width is
+// 7.56 strips (94.4 % of the columns computed are real) x 180 pixel tiles = 1 440 workgroups = 5.6 rounds of 256 CUs (93.8 %): 88.5 % useful; on 320
+// it is 6.8 strips (97.1 %) x 180 = 1 260 workgroups = 4.92 rounds (98.4 %): 95.6 %.  Same kernel: 4 x 2 waves of 64 x 160 on 16x16x32 MFMAs (TN = 10,
+// 20 fragments per slice, five weight pieces per wave and slice exactly), 150 KB of LDS.
+template <typename T>
+int launch_strip320(ConvArgs& a, hipStream_t stream) {
+    // MEASURED (tools/bench_conv.py, one box, round-robin; 288 strip -> this one): the column GEMM 19 584 -> 2176 at 32 x 18 x 80 1166 -> 1299 TF/s (+11 %),
+    // 2176 -> 2176 3x3 at the same size 1366 -> 1391 (+1.8 %); at 16 x 18 x 80 (90 pixel tiles: 630 workgroups = 2.46 rounds) it LOSES, 1391 -> 1327 -- the
+    // heuristic's round count keeps the 288 strip there.  Weight-fragment ring 2 / 4 / 5 / 10: 1391 / 1380 / 1377 / 692 (ten live fragments spill);
+    // upper-half issue point 5 / 6 / 7 / 8: flat (1359 - 1377).  Unlike the 288 strip, the staggered schedule also wins on the grouped column GEMM
+    // (1299 against 1226 without it).
+    if (vd3d_switch(VD3D_SW_CONV_NO_STAGGER)) return launch<T, 256, 320, 4, 2, true, true, 16, 2>(a, stream);
+    return launch<T, 256, 320, 4, 2, true, true, 16, 2, 0, false, 6>(a, stream);
+}
 
 // Tile override: 0 = heuristic, otherwise a config id (vd3d_test_force_conv_tile, csrc/test_hooks.h: a TEST hook, thread-local,
 // not declared in include/vd3d.h).  The PRODUCT build only knows the ids of the
@@ -1440,6 +1454,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 41: return launch<T, 256, 288, 8, 1, true, true>(a, stream);
         case 50: VD3D_BF16_ONLY(launch_strip352<T>(a, stream));
         case 54: VD3D_BF16_ONLY(launch_strip288<T>(a, stream));
+        case 52: VD3D_BF16_ONLY(launch_strip320<T>(a, stream));
         case 12: return launch<T, 128, 352, 4, 1, true>(a, stream);
         case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 76: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16>(a, stream));
@@ -1533,6 +1548,14 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 111: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 29>(a, stream));   // 9 per fragment (~160 per slice and wave: an fp16 blend)
         case 112: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 37>(a, stream));   // 17 (~304: the bf16 blend incl. unpack / pack)
         case 113: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 54>(a, stream));   // 34
+        // the 320 strip: ring / stagger sweep (production: ring 2, STG 6 = case 124)
+        case 120: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 5, 0, false, 5>(a, stream));
+        case 121: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 5, 0, false, 7>(a, stream));
+        case 122: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 5, 0, false, 8>(a, stream));
+        case 123: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 10, 0, false, 6>(a, stream));
+        case 124: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 2, 0, false, 6>(a, stream));
+        case 125: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 4, 0, false, 6>(a, stream));
+        case 126: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 2>(a, stream));
         case 101: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6>(a, stream));       // the same instantiation without injection
         case 102: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 20>(a, stream));   // empty volatile asm per fragment
         case 103: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 21>(a, stream));   // 1 VALU per fragment
@@ -1636,6 +1659,11 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         const double r = 1455.0 * util(256, 288, kSlots1);
         if (r > best) { best = r; pick = 3; }
     }
+    if (sizeof(T) == 2 && a.Cout > 1152 && a.Cout % 352 != 0 && a.Cout % 288 != 0) {
+        // 2176 = 6.8 x 320: 95.6 % of the chip-rounds useful against 88.5 % on the 288 strips (launch_strip320)
+        const double r = 1460.0 * util(256, 320, kSlots1);
+        if (r > best) { best = r; pick = 9; }
+    }
     if (a.Cout % 288 == 0) {
         // bf16: 8 waves of 32 x 144 on 16x16x32 MFMAs: 1109 vs 929 TF/s (128x192 tiles) on the 1408 -> 576 reg output conv
         // (only with >= 2 strips per pixel tile: on the 288 -> 288 neck convs the 120 tiles leave half the chip idle, 69 vs 55 us)
@@ -1659,6 +1687,9 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 3:
             if constexpr (sizeof(T) == 2) return launch_strip288<T>(a, stream);   // ring of 6: +4 % over 2
             else return launch<T, 256, 288, 8, 1, true, true>(a, stream);
+        case 9:
+            if constexpr (sizeof(T) == 2) return launch_strip320<T>(a, stream);
+            else return launch<T, 256, 256, 2, 4, true, true>(a, stream);
         case 4: return launch<T, 128, 352, 4, 1, true>(a, stream);
         case 5:     // bf16: 8 waves of 32 x 144 on 16x16x32 MFMAs (+20 % over 128x192 tiles on the 1408 -> 576 reg output conv)
             if constexpr (sizeof(T) == 2) return launch<T, 128, 288, 4, 2, true, true, 16>(a, stream);
@@ -1686,7 +1717,7 @@ extern "C" int vd3d_test_force_conv_tile(int cfg) {
 
 extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
     // keep in step with the "production tiles" block of dispatch()
-    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130};
+    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 52, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130};
     const int n = (int)(sizeof(kIds) / sizeof(kIds[0]));
     for (int i = 0; i < n && i < cap; ++i) ids[i] = kIds[i];
     return n;
