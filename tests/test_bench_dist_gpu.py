@@ -32,7 +32,8 @@ def test_bench_force_dist_gathers_the_detections_forward_device_returns(graph):
     cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'] + ([] if graph else ['--no-graph'])
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert len(r.stdout.strip().splitlines()) == 1, 'stdout must carry the ONE JSON line and nothing else (RCCL prints its banner through C stdio):\n' + r.stdout[-1500:]
+    line = json.loads(r.stdout.strip())
     assert line['n_gpus'] == 1 and line['config']['hip_graph'] == graph and line['value'] > 100
     assert '[bench] rank 0/1' in r.stderr                              # per-rank timing line (diagnosable SCALE runs)
     d = torch.load(dump)

@@ -17,13 +17,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF16_TILES = {50, 54, 52, 76, 79, 73, 61, 68, 69, 58, 70}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
+BF16_TILES = {50, 54, 52, 53, 76, 79, 73, 61, 68, 69, 58, 70}    # (16-bit-only tiles: bf16 and fp16, no fp32 variant)       # 16x16x32 bf16 MFMA tiles; 61 = register-resident weights (bf16, Cin 128 | 256)
 HALO_TILES = {21, 23, 27}                # 3x3 / s1 / p1, Cin % K-slice == 0
 NARROW = {87: 32, 30: 64, 130: 64}       # tiles whose N extent bounds Cout in production (130: the split-K form of the 128 x 64 tile)
 
 
 # = vd3d_conv2d_production_tiles() (tests/test_abi.py checks the two lists agree, on CPU)
-PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 52, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130]   # 144 / 130: split-K (two launches)
+PRODUCTION_TILES = [44, 42, 40, 41, 50, 54, 52, 53, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130]   # 144 / 130: split-K (two launches)
 
 
 class forced_tile:
@@ -228,7 +228,7 @@ BENCH_SHAPES = [
     ('reg out 1408->576 f32', 8, 24, 80, 1408, 576, dict(out_f32=True, bn=False, relu=False)),   # 128x192
     ('cls 1408->256', 8, 24, 80, 1408, 256, dict(bn=False)),                        # halo 8x16x128
     ('cls 256->144 f32', 8, 24, 80, 256, 144, dict(out_f32=True, bn=False, relu=False)),
-    ('layer3 256->256 + res', 16, 24, 80, 256, 256, dict(residual=True)),           # halo 8x16x256
+    ('layer3 256->256 + res', 16, 24, 80, 256, 256, dict(residual=True)),           # K-split resident weights (240 tiles of 256 x 128 would be ONE round: measured slower in the model)
     ('layer2 128->128 + res', 16, 48, 160, 128, 128, dict(residual=True)),          # halo 8x32x128
     ('layer1 64->64 + res', 16, 96, 320, 64, 64, dict(residual=True)),              # resident weights
     ('layer2.0 64->128 s2', 16, 96, 320, 64, 128, dict(stride=2)),                  # 128x128
@@ -236,6 +236,7 @@ BENCH_SHAPES = [
     ('ghost 384->384', 8, 24, 80, 384, 384, dict()),
     ('neck 288->288 + res', 8, 24, 80, 288, 288, dict(residual=True)),              # 128x144 16x16x32
     ('cls 256->256', 8, 24, 80, 256, 256, dict(bn=False)),                          # register-resident weights, 4 slices
+    ('r50 layer3 256->256 + res', 64, 18, 80, 256, 256, dict(residual=True)),      # 256 x 128 tiles, 2.81 rounds
     ('r50 head 2176->2176', 16, 18, 80, 2176, 2176, dict(residual=True)),           # 256x320 16x16x32 strips (6.8 of them)
 ]
 

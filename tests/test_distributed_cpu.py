@@ -17,6 +17,35 @@ def _free_port():
     return p
 
 
+def _run_world2(target, args_after_port, timeout):
+    """spawn two ranks of `target(rank, 2, port, *args_after_port, q)`, return what rank 0 put on the queue.  The rendezvous port is chosen by
+    binding port 0 and releasing it: another process can take it in between (seen once in ~50 runs of the suite) -- a failed rendezvous is
+    retried on a fresh port, a failure of the ranks' own assertions is not masked (it fails all three attempts the same way)."""
+    last = None
+    for attempt in range(3):
+        ctx = mp.get_context('spawn')
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, 2, port) + tuple(args_after_port) + (q,)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            out = q.get(timeout=timeout)
+            for p in procs:
+                p.join(timeout=timeout)
+            codes = [p.exitcode for p in procs]
+            if codes == [0, 0]:
+                return out
+            last = AssertionError('rank exit codes %s (attempt %d)' % (codes, attempt + 1))
+        except Exception as e:                       # noqa: BLE001 -- queue.Empty: a rank died before reporting
+            last = e
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+    raise last
+
+
 def _fake_padded(n_frames, K=16, seed=0):
     g = torch.Generator().manual_seed(seed)
     count = torch.randint(0, K + 1, (n_frames,), generator=g, dtype=torch.int32)
@@ -48,16 +77,7 @@ def _worker(rank, world, port, n_frames, q):
 
 def test_shard_and_gather_world2_matches_single_process():
     n = 6
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    allp, allc, p1, c1 = q.get(timeout=120)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    allp, allc, p1, c1 = _run_world2(_worker, (n,), 120)
     scores, boxes, labels, count = _fake_padded(n)
     want_p, want_c = vdist.pack_detections(scores, boxes, labels, count, k=16)
     assert torch.equal(allp, want_p) and torch.equal(allc, want_c)
@@ -126,16 +146,7 @@ def test_detector_output_through_the_gather_world2():
     g = load_golden('stereo3d_r34_96x320')
     n_frames = int(g['meta'][3])
     assert n_frames % 2 == 0
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_detector_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    pack, cnt = q.get(timeout=600)
-    for p in procs:
-        p.join(timeout=600)
-        assert p.exitcode == 0
+    pack, cnt = _run_world2(_detector_worker, (), 600)
     dets = vdist.unpack_detections(pack, cnt)
     assert len(dets) == n_frames and sum(int(c) for c in cnt) > 0
     for f, (s_, b_, l_) in enumerate(dets):

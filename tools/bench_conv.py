@@ -18,6 +18,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('layer2 128->128', 16, 48, 160, 128, 128),
     ('layer3 256->256', 16, 24, 80, 256, 256),
     ('probe3 256->256 w96', 14, 24, 96, 256, 256),
+    ('r50 l3 3x3 256->256', 64, 18, 80, 256, 256),
+    ('dla l3 3x3 256->256', 16, 32, 110, 256, 256),
     ('neck 1152->1152', 8, 24, 80, 1152, 1152),
     ('head 1408->1408', 8, 24, 80, 1408, 1408),
     ('head 1408->576', 8, 24, 80, 1408, 576),

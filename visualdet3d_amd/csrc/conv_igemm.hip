@@ -1412,10 +1412,23 @@ int launch_strip320(ConvArgs& a, hipStream_t stream) {
 // Which of the resident-weight / streaming kernels takes a 16-bit shape under natural dispatch (ROUTE_NONE: the tile kernels, possibly
 // split over K).  The ONE statement of that choice: dispatch() launches by it and vd3d_conv2d_workspace_bytes() sizes the split-K
 // scratch by it, so the two cannot drift apart.
-enum SpecialRoute { ROUTE_NONE = 0, ROUTE_REGW, ROUTE_KSPLIT, ROUTE_SMALL, ROUTE_NARROW, ROUTE_PW, ROUTE_RES64 };
+enum SpecialRoute { ROUTE_NONE = 0, ROUTE_REGW, ROUTE_KSPLIT, ROUTE_SMALL, ROUTE_NARROW, ROUTE_PW, ROUTE_RES64, ROUTE_TILE256x128 };
+// Round 5: the Cin 256 3x3 layers with SEVERAL well-filled rounds of 256-pixel x 128-channel tiles (config 3's ResNet-50 layer3 at 64 x 18 x 80: 360 x 2 = 720
+// tiles = 2.81 rounds of 256 CUs) run on THAT tile -- 8 waves of 64 x 64 on 16x16x32 MFMAs, weight-fragment ring 4, one workgroup per CU.
+// MEASURED (profiles/r05_tile256x128_ab.txt).  tools/bench_conv.py, back-to-back launches: 64 x 18 x 80 966 against 798 TF/s for the K-split resident kernel;
+// ResNet-34 layer3 at 16 x 24 x 80 (240 tiles, ONE round) 861 - 898 against 790 - 840 -- but inside the model the one-round case LOSES: same-box A/B of the
+// headline 3.510 - 3.512 against 3.500 - 3.508 ms per step, and the serial trace shows why (41 - 45 us per launch against 38.5 - 41 for the K-split kernel:
+// the micro-benchmark's dense random operands throttle the resident kernel more than the model's post-ReLU activations do); config 3, same box:
+// 17.36 / 17.29 -> 17.27 / 17.20 ms per step.  Hence: only with >= 2 rounds.  (The 256 -> 256 cls conv at 8 x 24 x 80, 120 tiles: 504 against 712.)
+static bool tile256x128_fills(const ConvArgs& a) {
+    if (a.Cout % 128 != 0 || a.out_f32) return false;
+    const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
+    const int64_t tm = (a.M + 255) / 256, tiles = tm * (a.Cout / 128), rounds = (tiles + cus - 1) / cus;
+    return rounds >= 2 && (int64_t)a.M * 100 >= tm * 256 * 95 && tiles * 100 >= rounds * cus * 90;
+}
 static SpecialRoute special_route(const ConvArgs& a) {
     if (a.Cin == 128 && regw_shape_ok(a)) return ROUTE_REGW;
-    if (ksplit_shape_ok(a)) return ROUTE_KSPLIT;
+    if (ksplit_shape_ok(a)) return tile256x128_fills(a) ? ROUTE_TILE256x128 : ROUTE_KSPLIT;
     if (small_shape_ok(a)) return ROUTE_SMALL;
     if (narrow_shape_ok(a) && !vd3d_switch(VD3D_SW_NO_NARROW)) return ROUTE_NARROW;
     if (pw_shape_ok(a)) return ROUTE_PW;
@@ -1455,6 +1468,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 50: VD3D_BF16_ONLY(launch_strip352<T>(a, stream));
         case 54: VD3D_BF16_ONLY(launch_strip288<T>(a, stream));
         case 52: VD3D_BF16_ONLY(launch_strip320<T>(a, stream));
+        case 53: VD3D_BF16_ONLY(launch<T, 256, 128, 4, 2, true, true, 16, 4>(a, stream));
         case 12: return launch<T, 128, 352, 4, 1, true>(a, stream);
         case 11: return launch<T, 128, 288, 4, 1, true>(a, stream);
         case 76: VD3D_BF16_ONLY(launch<T, 128, 288, 4, 2, true, true, 16>(a, stream));
@@ -1548,6 +1562,14 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         case 111: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 29>(a, stream));   // 9 per fragment (~160 per slice and wave: an fp16 blend)
         case 112: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 37>(a, stream));   // 17 (~304: the bf16 blend incl. unpack / pack)
         case 113: VD3D_BF16_ONLY(launch<T, 256, 288, 4, 2, true, true, 16, 6, 54>(a, stream));   // 34
+        // 256 pixels x 128 channels, one workgroup per CU (layer 3 at batch 8: 120 x 2 = 240 tiles for 256 CUs): does a third tile shape move the layer-3 plateau?
+        case 150: VD3D_BF16_ONLY(launch<T, 256, 128, 4, 2, true, true, 16>(a, stream));
+        case 151: return launch<T, 256, 128, 4, 2, true, true>(a, stream);
+        case 152: return launch<T, 256, 128, 8, 1, true, true>(a, stream);
+        case 153: VD3D_BF16_ONLY(launch<T, 256, 128, 4, 2, true, true, 16, 4>(a, stream));      // (production: forced id 53)
+        case 154: VD3D_BF16_ONLY(launch<T, 256, 128, 4, 2, true, true, 16, 4, 0, false, 2>(a, stream));   // + staggered DMA issue (upper half at fragment 2 of 8)
+        case 155: VD3D_BF16_ONLY(launch<T, 256, 128, 4, 2, true, true, 16, 2, 0, false, 3>(a, stream));
+        case 156: VD3D_BF16_ONLY(launch<T, 256, 128, 2, 4, true, true, 16>(a, stream));                   // 2 x 4 waves of 128 x 32
         // the 320 strip: ring / stagger sweep (production: ring 2, STG 6 = case 124)
         case 120: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 5, 0, false, 5>(a, stream));
         case 121: VD3D_BF16_ONLY(launch<T, 256, 320, 4, 2, true, true, 16, 5, 0, false, 7>(a, stream));
@@ -1584,6 +1606,9 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
             // Cin 256: the 8-wave K-split resident kernel (v7): +3.5 % over the 8x16x256 halo tiles on layer3 (781 vs 754 TF/s), +50 % on
             // the 256 -> 256 cls conv whose 120 halo tiles leave half the chip idle (690 vs 441; the 4-wave v6 kernel: 641 - 704)
             case ROUTE_KSPLIT: return launch_ksplit(a, stream, fmt);
+            case ROUTE_TILE256x128:
+                if constexpr (kBf16) return launch<T, 256, 128, 4, 2, true, true, 16, 4>(a, stream);
+                else break;
             // small-channel streaming kernel (DLA level 0 / 1, DCN offset convs): input staged once, HBM-bound instead of LDS-fill-bound
             case ROUTE_SMALL: return launch_small(a, stream, fmt);
             // the same tile walked over 64-channel chunks for the deep offset convs (Cin 128 ... 2176 -> 27): 2-4x over the 256 x 32 tiles
@@ -1717,7 +1742,7 @@ extern "C" int vd3d_test_force_conv_tile(int cfg) {
 
 extern "C" int vd3d_conv2d_production_tiles(int32_t* ids, int cap) {
     // keep in step with the "production tiles" block of dispatch()
-    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 52, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130};
+    static const int32_t kIds[] = {44, 42, 40, 41, 50, 54, 52, 53, 12, 11, 76, 43, 79, 73, 87, 30, 21, 23, 27, 61, 68, 69, 58, 70, 144, 130};
     const int n = (int)(sizeof(kIds) / sizeof(kIds[0]));
     for (int i = 0; i < n && i < cap; ++i) ids[i] = kIds[i];
     return n;
