@@ -458,3 +458,24 @@ def test_two_way_split_on_the_288_strips(dtype):
     assert torch.equal(a, b)
     assert ((a - c).abs().max() / c.abs().max()).item() < 2e-5
 
+
+def test_two_way_split_when_the_strips_fill_their_rounds_badly():
+    """Round 5, the second case of plan_splitk_strip: config 3's 2176 -> 576 reg-tower output conv at 32 x 18 x 80 (fp32 output) -- 180 x 2 = 360 strip tiles are
+    1.4 rounds of 256 CUs; with K (306 slices) split in two the same strips are 720 workgroups = 2.81 rounds.  The split path is what runs (workspace query),
+    the result meets the fp32-output bar against the oracle, equals the unsplit path to summation noise and is run-to-run bit-identical."""
+    from visualdet3d_amd import _lib, hip_ops as ops
+    torch.set_num_threads(min(64, torch.get_num_threads()))
+    ulp, rel = run_case(32, 18, 80, 2176, 576, dtype=torch.bfloat16, seed=5, cfg=0, out_f32=True, bn=False, relu=False)
+    assert rel <= 1e-4, rel
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(32, 18, 80, 2176, generator=g).cuda().to(torch.bfloat16)
+    pc = ops.pack_conv((torch.randn(576, 2176, 3, 3, generator=g) * (2.0 / (9 * 2176)) ** 0.5).cuda(), None, None, torch.bfloat16, 1, 1, 1)
+    a = ops.conv2d(x, pc, relu=False, out_f32=True)
+    assert pc.ws_need and max(pc.ws_need.values()) == 2 * 360 * 256 * 288 * 4, pc.ws_need          # the two-way split of the 360 strip tiles
+    b = ops.conv2d(x, pc, relu=False, out_f32=True)
+    with _lib.test_switch('VD3D_NO_STRIP_SPLIT'):
+        c = ops.conv2d(x, pc, relu=False, out_f32=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert ((a - c).abs().max() / c.abs().max()).item() < 2e-5
+

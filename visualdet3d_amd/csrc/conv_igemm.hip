@@ -1346,11 +1346,22 @@ static SplitPlan plan_splitk_strip(const ConvArgs& a) {
     const int tm = (a.M + 255) / 256, tn = (a.Cout + 287) / 288;
     const int64_t tiles = (int64_t)tm * tn;
     const int pad_n = tn * 288 - a.Cout, pad_m = tm * 256 - a.M;
-    if (a.Cout <= 288 || pad_n * 16 > a.Cout || pad_m * 12 > a.M || tiles * 2 > cus) return pl;
-    int sp = (int)(cus / tiles);
-    if (sp > a.nk / 16) sp = a.nk / 16;
-    if (sp > 16) sp = 16;
-    if (sp < 2 || tiles * sp * 100 < (int64_t)cus * 85) return pl;
+    if (a.Cout <= 288 || pad_n * 16 > a.Cout || pad_m * 12 > a.M) return pl;
+    int sp;
+    if (tiles * 2 > cus) {
+        // Round 5, (iii): SEVERAL rounds, the last one badly filled, and a K deep enough that the fp32 partials are noise -- config 3's 2176 -> 576 reg-tower
+        // output conv at 32 x 18 x 80: 180 x 2 = 360 strip tiles = 1.4 rounds (70 % of two); it ran on 128 x 288 tiles (720 = 2.81 rounds, but 1 001 TF/s: the
+        // half-height tile's LDS fill per KFLOP).  Two splits of the strips are the same 720 workgroups at the strips' efficiency; 2 x 106 MB of partials
+        // against a 306-slice K.  MEASURED: profiles/r05_strip_split_two_rounds.txt.
+        auto fill = [&](int64_t w) { const int64_t r = (w + cus - 1) / cus; return (double)w / (double)(r * cus); };
+        if (!(fill(tiles) < 0.8 && fill(2 * tiles) >= 0.9 && a.nk >= 160)) return pl;
+        sp = 2;
+    } else {
+        sp = (int)(cus / tiles);
+        if (sp > a.nk / 16) sp = a.nk / 16;
+        if (sp > 16) sp = 16;
+        if (sp < 2 || tiles * sp * 100 < (int64_t)cus * 85) return pl;
+    }
     const int per = (a.nk + sp - 1) / sp;
     pl.splits = (a.nk + per - 1) / per;               // every split is non-empty
     if (pl.splits < 2) { pl.splits = 1; return pl; }
