@@ -38,6 +38,10 @@ run pmc_c5_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WA
 run pmc_c5_valu --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d $OUT/pmc_c5_valu -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
 run pmc_c5_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_c5_fetch -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
 run pmc_c5_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_c5_write -- python $ROOT/tools/bench_configs.py --eager "fp16 (as BASELINE"
+# config 3's own SQ / traffic passes (the 2176-channel strips, the column GEMM, the columns kernel, the point-wise streaming kernels), eager launches
+run pmc_c3_sq --kernel-trace --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $OUT/pmc_c3_sq -- python $ROOT/tools/bench_configs.py --eager "C3 Stereo3D R50 +"
+run pmc_c3_fetch --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_c3_fetch -- python $ROOT/tools/bench_configs.py --eager "C3 Stereo3D R50 +"
+run pmc_c3_write --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_c3_write -- python $ROOT/tools/bench_configs.py --eager "C3 Stereo3D R50 +"
 cd $ROOT
 db() { find $OUT/$1 -name "*.db" | sort | tail -1; }
 python tools/rocpd_stats.py $(db trace_overlap) > $OUT/${TAG}_kernel_stats.csv
@@ -54,6 +58,9 @@ python tools/rocpd_pmc_table.py $OUT/pmc_sq_nostg conv_ > $OUT/${TAG}_sq_pmc_no_
   echo "## instruction mix"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_valu conv_pair_kernel | tail -n +2;
   echo "## FETCH_SIZE (x2 for bytes on gfx950: 32-byte units reported as 64)"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_fetch conv_pair_kernel | tail -n +2;
   echo "## WRITE_SIZE"; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write dcn_; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write km3d_head_kernel | tail -n +2; python tools/rocpd_pmc_table.py $OUT/pmc_c5_write conv_pair_kernel | tail -n +2; } > $OUT/${TAG}_c5_pmc.txt 2>&1
+{ echo "# BASELINE config 3 (Stereo3D R50 + base DCNv2 head, bf16, 32 x 288 x 1280), eager launches: conv families, DCN columns kernel"; echo "## SQ pass"; python tools/rocpd_pmc_table.py $OUT/pmc_c3_sq conv_; python tools/rocpd_pmc_table.py $OUT/pmc_c3_sq dcn_ | tail -n +2;
+  echo "## FETCH_SIZE (x2 for bytes on gfx950: 32-byte units reported as 64)"; python tools/rocpd_pmc_table.py $OUT/pmc_c3_fetch conv_; python tools/rocpd_pmc_table.py $OUT/pmc_c3_fetch dcn_ | tail -n +2;
+  echo "## WRITE_SIZE"; python tools/rocpd_pmc_table.py $OUT/pmc_c3_write conv_; python tools/rocpd_pmc_table.py $OUT/pmc_c3_write dcn_ | tail -n +2; } > $OUT/${TAG}_c3_pmc.txt
 python tools/serial_roofline_check.py $OUT/${TAG}_serial_kernel_stats.csv $OUT/${TAG}_serial_bench.json > $OUT/${TAG}_serial_roofline_check.txt
 cat $OUT/${TAG}_serial_roofline_check.txt
 python tools/rocpd_timeline.py $(db trace_b1_mono) > $OUT/${TAG}_b1_mono_timeline.txt
@@ -73,5 +80,5 @@ python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench_line.err; tail -1 $O
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 VD3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-other-configs 2> $OUT/bench_force_dist.err | grep '^{' | tail -1 > $OUT/${TAG}_bench_force_dist.json; tail -1 $OUT/bench_force_dist.err
 python bench.py --feed host --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_feed_host.json 2> $OUT/bench_feed_host.err; tail -1 $OUT/bench_feed_host.err
 # the rocpd databases stay on the box (too big); only the summaries travel back
-rm -rf $OUT/pmc_sq_nostg $OUT/trace_b1_mono $OUT/trace_b1_stereo $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5 $OUT/pmc_c5_sq $OUT/pmc_c5_valu $OUT/pmc_c5_fetch $OUT/pmc_c5_write
+rm -rf $OUT/pmc_sq_nostg $OUT/trace_b1_mono $OUT/trace_b1_stereo $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5 $OUT/pmc_c5_sq $OUT/pmc_c5_valu $OUT/pmc_c5_fetch $OUT/pmc_c5_write $OUT/pmc_c3_sq $OUT/pmc_c3_fetch $OUT/pmc_c3_write
 ls -la $OUT
