@@ -72,6 +72,32 @@ def main():
         print('%-7s B=1 384x1280 bf16 %s: %.3f ms per module([...]) call = %.1f img/s, %.1f %% of 2.5 PF whole path; %d detections%s  %s'
               % (kind, 'eager' if not m.use_graph else 'hipGraph cache', dt * 1e3, 1 / dt, GF[kind] / dt / 25e3, out[0].numel(),
                  '; replay alone %.3f ms' % (dev * 1e3) if dev else '', m.graph_stats), flush=True)
+        if '--breakdown' in sys.argv and m.use_graph:
+            # where the host's time of one call goes: stamps around the graph cache (_graphed) and the host sync (read_counts)
+            import visualdet3d_amd.networks.lib.graphed as G
+            import visualdet3d_amd.networks.heads.detection_3d_head as H  # noqa: F401
+            st = []
+            g0, r0 = m._graphed, G.read_counts
+
+            def g1(*a):
+                st.append(time.perf_counter()); o = g0(*a); st.append(time.perf_counter()); return o
+
+            def r1(c):
+                st.append(time.perf_counter()); o = r0(c); st.append(time.perf_counter()); return o
+            m._graphed, G.read_counts = g1, r1
+            acc = [0.0] * 5
+            with torch.no_grad():
+                for _ in range(calls):
+                    del st[:]
+                    ta = time.perf_counter()
+                    m(x)
+                    tb = time.perf_counter()
+                    if len(st) == 4:
+                        for i, d in enumerate((st[0] - ta, st[1] - st[0], st[2] - st[1], st[3] - st[2], tb - st[3])):
+                            acc[i] += d
+            m._graphed, G.read_counts = g0, r0
+            print('  host breakdown per call (us): before the graph cache %.1f | key + input copies + replay enqueue %.1f | result copies enqueue %.1f | '
+                  'wait for the counts (GPU time + wake-up) %.1f | slicing + return %.1f' % tuple(a / calls * 1e6 for a in acc), flush=True)
         if '--layers' in sys.argv:
             import bench
             os.environ['VD3D_BENCH_LAYERS'] = '1'

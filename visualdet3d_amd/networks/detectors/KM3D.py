@@ -5,7 +5,7 @@ import torch.nn as nn
 
 from ..heads.km3d_head import KM3DHead
 from ..lib import fused
-from ..lib.graphed import GraphedForward, clone_results
+from ..lib.graphed import GraphedForward
 from ..utils.registry import DETECTOR_DICT
 from .KM3D_core import KM3DCore
 
@@ -45,7 +45,7 @@ class KM3D(GraphedForward, nn.Module):
         # the calibration in kernel form (contiguous fp32 on the device) BEFORE the graph cache: the graph's static input is then what the
         # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
         P2 = torch.as_tensor(P2).to(device=img_batch.device, dtype=torch.float32).contiguous()
-        return clone_results(self.bbox_head.unpad(self._graphed(img_batch, P2)))      # hipGraph cache, lib/graphed.py
+        return self.bbox_head.unpad(self._graphed(img_batch, P2), own=True)      # hipGraph cache, lib/graphed.py
 
     @torch.no_grad()
     def test_forward(self, img_batch, P2):

@@ -10,7 +10,7 @@ from ... import hip_ops as ops
 from ..heads.detection_3d_head import AnchorBasedDetection3DHead, _conv_pack
 from ..lib import fused
 from ..lib.blocks import AnchorFlatten
-from ..lib.graphed import GraphedForward, clone_results
+from ..lib.graphed import GraphedForward
 from ..lib.look_ground import LookGround
 from ..utils.registry import DETECTOR_DICT
 from .yolomono3d_core import YoloMono3DCore
@@ -84,7 +84,7 @@ class Yolo3D(GraphedForward, nn.Module):
         # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
         P2 = torch.as_tensor(P2).to(device=img_batch.device, dtype=torch.float32).contiguous()
         # through the hipGraph cache (lib/graphed.py); post_optimization runs inside get_bboxes_batched, i.e. inside the graph
-        return clone_results(self.bbox_head.unpad(self._graphed(img_batch, P2)))
+        return self.bbox_head.unpad(self._graphed(img_batch, P2), own=True)
 
     @torch.no_grad()
     def test_forward(self, img_batch, P2):

@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from ..heads.detection_3d_head import AnchorBasedDetection3DHead, StereoHead
 from ..lib import fused
-from ..lib.graphed import GraphedForward, clone_results
+from ..lib.graphed import GraphedForward
 from ..utils.registry import DETECTOR_DICT
 from .yolostereo3d_core import YoloStereo3DCore
 
@@ -54,7 +54,7 @@ class Stereo3D(GraphedForward, nn.Module):
         # the calibration in kernel form (contiguous fp32 on the device) BEFORE the graph cache: the graph's static input is then what the
         # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
         P2 = torch.as_tensor(P2).to(device=left_images.device, dtype=torch.float32).contiguous()
-        return clone_results(self.bbox_head.unpad(self._graphed(left_images, right_images, P2)))
+        return self.bbox_head.unpad(self._graphed(left_images, right_images, P2), own=True)
 
     @torch.no_grad()
     def test_forward(self, left_images, right_images, P2, P3):

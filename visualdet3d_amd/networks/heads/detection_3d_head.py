@@ -253,16 +253,30 @@ class AnchorBasedDetection3DHead(nn.Module):
         return self._select_key(cls_preds, args, kw)
 
     @staticmethod
-    def unpad(padded):
-        """One host sync: slice the padded batch results into per-sample (scores, boxes, labels int64) tuples."""
+    def unpad(padded, own=False):
+        """One host sync: slice the padded batch results into per-sample (scores, boxes, labels int64) tuples.
+        ``own=True`` (the detectors' ``test_forward``: the padded tensors are a hipGraph's static outputs, overwritten by the next replay): the
+        results are views of PRIVATE copies of the padded arrays, made BEFORE the sync -- three launches per call that the host issues while the
+        GPU still works on the forward, instead of three per SAMPLE after the sync (slices, ``.long()``, clones)."""
         scores, boxes, labels, aidx, count = padded
-        counts = count.tolist()
+        from ..lib.graphed import COPY_AFTER_SYNC, read_counts
+        early = own and not COPY_AFTER_SYNC
+        if early:
+            scores, boxes, labels = scores.clone(), boxes.clone(), labels.long()
+            rows = list(zip(scores.unbind(0), boxes.unbind(0), labels.unbind(0)))      # per-sample rows, still before the sync
+        counts = read_counts(count)
         outs = []
         for b, k in enumerate(counts):
             if k < 0:
                 raise RuntimeError('sample %d: more candidates than max_candidates (or detections than max_det); '
                                    'raise AnchorBasedDetection3DHead.max_candidates' % b)
-            outs.append((scores[b, :k], boxes[b, :k], labels[b, :k].long()))
+            if early:                            # after the sync: three slices per sample, nothing else (this is the call's critical path)
+                s, bx, l = rows[b]
+                outs.append((s[:k], bx[:k], l[:k]))
+            else:
+                outs.append((scores[b, :k], boxes[b, :k], labels[b, :k].long()))
+        if own and not early:
+            outs = [(s.clone(), bx.clone(), l) for s, bx, l in outs]
         return outs
 
     def get_bboxes(self, cls_scores, reg_preds, anchors, P2s, img_batch=None):

@@ -149,13 +149,25 @@ class KM3DHead(nn.Module):
         return scores, boxes, cls, count
 
     @staticmethod
-    def unpad(padded):
+    def unpad(padded, own=False):
+        """``own=True``: views of private copies made BEFORE the host sync (see AnchorBasedDetection3DHead.unpad)"""
         scores, boxes, cls, count = padded
         outs = []
-        for b, k in enumerate(count.tolist()):
+        from ..lib.graphed import COPY_AFTER_SYNC, read_counts
+        early = own and not COPY_AFTER_SYNC
+        if early:
+            scores, boxes, cls = scores.clone(), boxes.clone(), cls.long().unsqueeze(-1)
+            rows = list(zip(scores.unbind(0), boxes.unbind(0), cls.unbind(0)))
+        for b, k in enumerate(read_counts(count)):
             if k < 0:
                 raise RuntimeError('sample %d: more heat-map peaks than KM3DHead.max_peaks' % b)
-            outs.append((scores[b, :k], boxes[b, :k], cls[b, :k].long().unsqueeze(1)))
+            if early:
+                s, bx, c = rows[b]
+                outs.append((s[:k], bx[:k], c[:k]))
+            else:
+                outs.append((scores[b, :k], boxes[b, :k], cls[b, :k].long().unsqueeze(1)))
+        if own and not early:
+            outs = [(s.clone(), bx.clone(), l) for s, bx, l in outs]
         return outs
 
     def get_bboxes(self, output: dict, P2, img_batch=None):

@@ -5,8 +5,8 @@ The reference's contract is one frame per call (``networks/detectors/yolostereo3
 the host's launch path, not the GPU, sets the frame time.  Here the first call for a given (input shapes, compute dtype, head
 settings, weights) runs ``forward_device`` eagerly (packs weights, builds the anchor tables, raises LDS limits, warms the allocator),
 captures it once into a hipGraph over STATIC input buffers, and every later call is: three device copies into the static inputs, one
-graph launch, one device->host read of the detection counts, and clones of the (tiny) result slices -- what ``bench.py`` measures is
-what a caller of ``module([left, right, P2, P3])`` gets.
+graph launch, private copies of the (tiny) padded result arrays queued right behind it, one device->host read of the detection counts through a
+pinned buffer (``read_counts``), and views of those copies -- what ``bench.py`` measures is what a caller of ``module([left, right, P2, P3])`` gets.
 
 Invalidation (the same facts ``lib/fused.PackCache`` keys the packed weights on):
   * every parameter's / buffer's ``_version`` (``load_state_dict`` and any in-place update bump it) -- checked on every call;
@@ -17,6 +17,7 @@ Swapping a parameter's storage by hand (``p.data = other``) is the one thing not
 
 ``VD3D_NO_GRAPH=1`` in the environment or ``model.use_graph = False`` selects the eager path (same kernels, same results)."""
 import os
+import threading
 import warnings
 from collections import OrderedDict
 from operator import attrgetter
@@ -26,6 +27,9 @@ import torch
 from ... import _lib
 
 _VERSION = attrgetter('_version')
+_PAGEABLE_COUNTS = bool(os.environ.get('VD3D_PAGEABLE_COUNTS'))
+_CHECK_FIRST = bool(os.environ.get('VD3D_GRAPH_CHECK_FIRST'))
+COPY_AFTER_SYNC = bool(os.environ.get('VD3D_COPY_AFTER_SYNC'))   # A/B: the callers' result copies per sample AFTER the host sync (until round 5)
 _MAX_GRAPHS = 8          # per model; each holds the activations of its shape in a private pool (least recently USED goes first)
 
 
@@ -126,13 +130,26 @@ class GraphedForward:
         st = self._graph_state()
         if st['tensors'] is None:
             st['tensors'] = list(self.parameters()) + list(self.buffers())
-        versions = tuple(map(_VERSION, st['tensors']))
         key = (tuple((tuple(t.shape), t.dtype, t.device) for t in inputs), self._graph_knobs())
         ent = st['entries'].get(key)
+        if ent is not None and ent.graph is not None and not _CHECK_FIRST:
+            # the common case, OPTIMISTIC (VD3D_GRAPH_CHECK_FIRST=1: versions first, the order until round 5 -- A/B): enqueue the input copies and the replay first, compare the ~200 parameter versions while the GPU
+            # already works (~10 us of host time off the critical path of a 0.5 ms batch-1 call).  A mismatch (weights changed in place since
+            # the capture -- rare) drops the replay's results: it wrote nothing but its own static buffers, which the re-capture below rewrites
+            for dst, src in zip(ent.static_in, inputs):
+                dst.copy_(src, non_blocking=True)
+            ent.graph.replay()
+            if ent.versions == tuple(map(_VERSION, st['tensors'])):
+                st['entries'].move_to_end(key)   # LRU: a hit makes the shape the most recently used
+                st['replays'] += 1
+                return ent.static_out
+            torch.cuda.current_stream().synchronize()    # (the stale replay is done before its graph is dropped)
+            ent = None
+        versions = tuple(map(_VERSION, st['tensors']))
         if ent is not None and ent.versions != versions:
-            ent = None                           # weights changed in place since the capture
+            ent = None                           # (an eager entry) weights changed in place since it was made
         if ent is not None:
-            st['entries'].move_to_end(key)       # LRU: a hit makes the shape the most recently used
+            st['entries'].move_to_end(key)
         if ent is None:
             ent = self._capture(inputs, versions)
             st['entries'][key] = ent
@@ -175,7 +192,21 @@ class GraphedForward:
         return ent
 
 
-def clone_results(per_sample):
-    """The graph's result tensors are overwritten by the next replay: hand the caller its own copies (a few hundred bytes each).
-    ``unpad`` already made the int64 labels a fresh tensor."""
-    return [(s.clone(), b.clone(), l) for s, b, l in per_sample]
+_host_counts = threading.local()
+
+
+def read_counts(count):
+    """Device detection counts [B] -> python list: THE host sync of a ``test_forward`` call.  ``count.tolist()`` is a pageable device->host
+    copy: the runtime first waits for the stream, THEN issues the staged copy -- ~10 us of serial latency behind the last kernel of a 0.5 ms
+    batch-1 forward.  Here the copy goes into a (per-thread, per-shape) pinned buffer and is queued behind the producing launches at once;
+    the host only waits for the stream.  ``VD3D_PAGEABLE_COUNTS=1``: the old path (A/B)."""
+    if not count.is_cuda or _PAGEABLE_COUNTS:
+        return count.tolist()
+    bufs = _host_counts.__dict__.setdefault('bufs', {})
+    key = (tuple(count.shape), count.dtype)
+    buf = bufs.get(key)
+    if buf is None:
+        buf = bufs[key] = torch.empty(count.shape, dtype=count.dtype).pin_memory()
+    buf.copy_(count, non_blocking=True)
+    torch.cuda.current_stream(count.device).synchronize()
+    return buf.tolist()
