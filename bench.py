@@ -57,7 +57,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--feed', default='resident', choices=['resident', 'host'],
                     help="resident (default, the headline): synthetic network inputs already in HBM.  host: every step uploads 2 x batch "
-                         "uint8 KITTI-sized frames (375 x 1242 x 3) from pinned host memory into a double-buffered device ring on a "
+                         "uint8 camera frames of the network's size (384 x 1280 x 3) from pinned host memory into a double-buffered device ring on a "
                          "copy stream and runs vd3d_preprocess_image (crop / resize / normalise) inside the captured step -- the "
                          "PCIe-inclusive rate, the one thing that differs between 1 and 8 ranks of a node")
     ap.add_argument('--no-other-configs', action='store_true',
@@ -412,16 +412,19 @@ class Stepper:
 
 
 class HostFeed:
-    """--feed host: 2 x B uint8 KITTI-sized frames per step travel from pinned host memory into a double-buffered device ring on a
+    """--feed host: 2 x B uint8 camera frames per step travel from pinned host memory into a double-buffered device ring on a
     copy stream; the step itself (captured in the hipGraph) starts with vd3d_preprocess_image on a STATIC device frame buffer
     (crop / cv2-style resize / pad / normalise -> the fp32 NCHW network input), which the main stream refreshes from ring slot
     (i & 1) right before the replay.  Upload i + 1 overlaps step i."""
-    HS, WS = 375, 1242          # KITTI frame
-
     def __init__(self, B, H, W, device, L, R, seed=0):
         from visualdet3d_amd import hip_ops
-        g = torch.Generator().manual_seed(seed)
-        self.host = [torch.randint(0, 256, (2 * B, self.HS, self.WS, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(2)]
+        # The frames are the resident workload's own images as uint8 camera frames of the NETWORK's size (de-normalised, rounded to bytes): the
+        # preprocessed input then equals the resident one up to the byte rounding (0.02 sigma) and the timed decode / NMS see the same ~100
+        # detections.  (Until round 5: uniform random bytes at KITTI's 375 x 1242 -- NO detections; the resident images resampled to 375 x 1242 and
+        # back lose their high frequencies: 3 detections.  384 x 1280 frames are 5 % more bytes per upload than a KITTI frame; the resize still
+        # runs, at scale 1.)  The second ring slot holds the same frames in another batch order.
+        self.HS, self.WS = H, W
+        self.host = [f.pin_memory() for f in self.slot_frames(L, R)]
         self.ring = [torch.empty((2 * B, self.HS, self.WS, 3), dtype=torch.uint8, device=device) for _ in range(2)]
         self.frames = torch.empty((2 * B, self.HS, self.WS, 3), dtype=torch.uint8, device=device)       # the graph's static source
         self.copy_stream = torch.cuda.Stream()
@@ -432,6 +435,17 @@ class HostFeed:
         self.bytes_per_step = self.host[0].numel()
         self.hip_ops = hip_ops
         self.frames.copy_(self.host[0])
+
+    @staticmethod
+    def slot_frames(L, R):
+        """the two ring slots' uint8 frames [2 B, H, W, 3] (left frames, then right frames) of the normalised images L, R [B, 3, H, W]"""
+        mean_t = torch.tensor((0.485, 0.456, 0.406)).view(1, 3, 1, 1)
+        std_t = torch.tensor((0.229, 0.224, 0.225)).view(1, 3, 1, 1)
+
+        def frames_of(x):
+            img = x.detach().float().cpu() * std_t + mean_t
+            return (img.clamp(0, 1) * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        return [torch.cat([frames_of(L), frames_of(R)], 0), torch.cat([frames_of(L).roll(1, 0), frames_of(R).roll(1, 0)], 0)]
 
     preprocess = None               # set by main(): the 2 x B vd3d_preprocess_image launches that open the captured step
 

@@ -71,7 +71,7 @@ def test_pack_detections_kernel_matches_host_pack():
 
 
 def test_bench_feed_host_uploads_frames_and_preprocesses_inside_the_step():
-    """``bench.py --feed host`` (world = 1): every step uploads 2 x B uint8 KITTI-sized frames from pinned host memory into the
+    """``bench.py --feed host`` (world = 1): every step uploads 2 x B uint8 camera frames (the resident workload's images as bytes) from pinned host memory into the
     device ring on the copy stream and runs vd3d_preprocess_image inside the captured step.  The network inputs the step produced
     equal the oracle's preprocessing (oracle/preprocess_ref.py, pinned to the reference's augmentation classes) of the frames of
     the LAST step's ring slot, and the detections that reached the host are the ones forward_device returns for those inputs."""
@@ -88,9 +88,14 @@ def test_bench_feed_host_uploads_frames_and_preprocesses_inside_the_step():
     assert line['config']['feed'].startswith('host:') and 'other_configs' not in line and line['value'] > 50
     d = torch.load(dump)
     L, R = d['inputs']
-    g = torch.Generator().manual_seed(0)                       # HostFeed(seed = rank 0): slot 0 then slot 1
-    slots = [torch.randint(0, 256, (2 * B, 375, 1242, 3), dtype=torch.uint8, generator=g) for _ in range(2)]
+    sys.path.insert(0, REPO)
+    import bench
+    from visualdet3d_amd.utils import synthetic as syn
+    slots = bench.HostFeed.slot_frames(*syn.stereo_pair(B, 384, 1280, seed=100))      # (bench.py: VD3D_BENCH_SEED 100 + rank 0) slot 0 then slot 1
     frames = slots[(steps - 1) & 1]
+    assert frames.shape == (2 * B, 384, 1280, 3) and frames.dtype == torch.uint8
+    import re
+    assert int(re.search(r'\((\d+) detections in the last step', r.stderr).group(1)) >= 1, 'the host-fed workload must not time decode / NMS on an empty candidate list'
     mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
     for b, dst in ((0, L[0]), (B - 1, L[B - 1]), (B, R[0]), (2 * B - 1, R[B - 1])):
         want = preprocess_ref.preprocess(frames[b].numpy(), 0, (384, 1280), mean, std)
