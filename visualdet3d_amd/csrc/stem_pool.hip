@@ -10,6 +10,8 @@
 // int16, and -0 loses) and writes 16 bytes per lane.  HBM traffic: packed image once + pooled map once.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kTPX = 16;                           // pooled tile width
@@ -43,6 +45,7 @@ struct StemArgs {
     int B, Hp, Wp, Ho, Wo, Hq, Wq, Kpad, out_pix_stride;
     uint32_t in_bytes;
     int ntiles;
+    int plain_walk;    // A/B: VD3D_STEM_PLAIN_WALK
 };
 
 // F32IN: the patch comes straight from the fp32 NCHW image (the reference's network input) -- converted to the NHWC4 16-bit LDS image
@@ -64,6 +67,19 @@ __global__ void __launch_bounds__(NW * 64) stem_pool_kernel(const StemArgs p) {
     const int wn = wave & 1, wmi = wave >> 1;
     const int lr = lane & 31, half = lane >> 5;
     const int tiles_x = p.Wq / kTPX, tiles_y = p.Hq / kTPY, tiles_img = tiles_x * tiles_y;
+    // XCD-aware walk (round 5): workgroups b, b + 8, ... share an XCD (round-robin dispatch) and with it an L2.  Each XCD owns a CONTIGUOUS
+    // run of the row-major tile list and its workgroups take consecutive tiles of it in every round, so the patch columns neighbouring tiles
+    // share (39 x 72 pixels fetched per 32 x 64 of new ones: 1.37 x) and the rows the next round shares are served by THAT L2 -- with the
+    // plain walk t = b, b + grid, ... neighbours sat on different XCDs and every overlap was fetched twice from beyond L2 (FETCH_SIZE 222 MB
+    // for a 94 MB image).  A grid that is not a multiple of 8 keeps the plain walk.
+    int t_first = blockIdx.x, t_end = p.ntiles, nwg = gridDim.x;
+    if ((gridDim.x & 7) == 0 && !p.plain_walk) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, q = p.ntiles >> 3, r = p.ntiles & 7;
+        const int start = xcd * q + (xcd < r ? xcd : r);
+        t_first = start + j;
+        t_end = start + q + (xcd < r ? 1 : 0);
+        nwg = gridDim.x >> 3;
+    }
 
     if (tid < 64) {
         ss[tid] = p.scale ? p.scale[tid] : 1.f;
@@ -93,7 +109,7 @@ __global__ void __launch_bounds__(NW * 64) stem_pool_kernel(const StemArgs p) {
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.packed, 0, p.in_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto issue_patch = [&](int t, int stage) {
-        const bool tv = t < p.ntiles;
+        const bool tv = t < t_end;
         const int tt = tv ? t : 0;
         const int b = tt / tiles_img, trem = tt - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -111,7 +127,7 @@ __global__ void __launch_bounds__(NW * 64) stem_pool_kernel(const StemArgs p) {
     float pre[HP][6];
     typedef f32x2 __attribute__((aligned(4))) f32x2_u;       // a pixel pair starts at an odd x: 4-byte aligned 8-byte loads
     auto load_patch = [&](int t) {
-        const bool tv = t < p.ntiles;
+        const bool tv = t < t_end;
         const int tt = tv ? t : 0;
         const int b = tt / tiles_img, trem = tt - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -169,8 +185,7 @@ __global__ void __launch_bounds__(NW * 64) stem_pool_kernel(const StemArgs p) {
         fbase[i] = ((2 * cy) * kCPR + cx + half) * 16;
     }
 
-    const int nwg = gridDim.x;
-    int t = blockIdx.x;
+    int t = t_first;
     if constexpr (F32IN) {
         load_patch(t);
         store_patch(0);
@@ -179,7 +194,7 @@ __global__ void __launch_bounds__(NW * 64) stem_pool_kernel(const StemArgs p) {
         issue_patch(t + nwg, 1);
     }
     int stage = 0;
-    for (; t < p.ntiles; t += nwg) {
+    for (; t < t_end; t += nwg) {
         if constexpr (F32IN) {
             // patch(k) was written to its stage by every wave at the end of tile k-1 (or in the prologue); pool phase k-1 is done
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -267,6 +282,8 @@ template <bool F32IN, int TPY, int NW>
 static int launch_stem_t(StemArgs& a, int wg_per_cu, hipStream_t stream) {
     constexpr int LDS = stem_lds_bytes<TPY, F32IN>();
     a.ntiles = a.B * (a.Hq / TPY) * (a.Wq / kTPX);
+    static const bool plain_walk = getenv("VD3D_STEM_PLAIN_WALK") != nullptr;      // A/B of the XCD-aware tile walk (same tiles, same arithmetic: bit-identical)
+    a.plain_walk = plain_walk ? 1 : 0;
     const int num_cu = vd3d_device_cu_count();
     if (num_cu <= 0) return VD3D_ELAUNCH;
     const int slots = num_cu * wg_per_cu;
