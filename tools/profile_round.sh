@@ -78,6 +78,8 @@ python tools/bench_configs.py 2>/dev/null | grep 'img/s' > $OUT/${TAG}_bench_con
 cp $OUT/${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # (the bench line below stamps its `roofline.traffic` from THIS pass)
 python bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench_line.err; tail -1 $OUT/bench_line.err
 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 VD3D_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-other-configs 2> $OUT/bench_force_dist.err | grep '^{' | tail -1 > $OUT/${TAG}_bench_force_dist.json; tail -1 $OUT/bench_force_dist.err
+# the driver's own N > 1 command line at N = 1 (through torch.distributed.run), RCCL path forced on: stdout must be the one JSON line
+VD3D_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_torchrun_nproc1.json 2> $OUT/bench_torchrun.err; tail -1 $OUT/bench_torchrun.err
 python bench.py --feed host --no-cpu-baseline --no-other-configs > $OUT/${TAG}_bench_feed_host.json 2> $OUT/bench_feed_host.err; tail -1 $OUT/bench_feed_host.err
 # the rocpd databases stay on the box (too big); only the summaries travel back
 rm -rf $OUT/pmc_sq_nostg $OUT/trace_b1_mono $OUT/trace_b1_stereo $OUT/trace_overlap $OUT/trace_serial $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/trace_c3 $OUT/trace_c5 $OUT/pmc_c5_sq $OUT/pmc_c5_valu $OUT/pmc_c5_fetch $OUT/pmc_c5_write $OUT/pmc_c3_sq $OUT/pmc_c3_fetch $OUT/pmc_c3_write
