@@ -3,6 +3,8 @@
 // kernels of conv_igemm.hip (which dispatches here); replaces the same reference layers (backbones/resnet.py:23-52 BasicBlock
 // convs of layer1 / layer2, heads/detection_3d_head.py:54-68 cls tower, backbones/dla.py tree blocks).
 #include "conv_common.h"
+
+#include <cstdlib>
 #include <stdio.h>
 
 using namespace vd3d_conv;
@@ -25,8 +27,29 @@ constexpr int kResStageBytes = kResPiecesTot * 1024;
 constexpr int kResLds = kResStages * kResStageBytes + 512;   // + scale[64], shift[64] (fp32): epilogue reads them through
                                                              // lgkmcnt, a global load per tile would drain the DMA queue (vmcnt)
 
+// XCD-aware walk of a row-major tile list by a persistent grid (round 5): workgroups b, b + 8, ... share an XCD and its L2.  Each XCD owns a CONTIGUOUS run of
+// the list and its workgroups take consecutive tiles of it in every round, so the halo rows / columns neighbouring tiles share are L2 hits -- with the plain
+// walk t = b, b + grid, ... neighbours sit on different XCDs and every overlap is fetched from beyond L2 twice.  -> first tile, end of the run, stride.
+// A grid that is not a multiple of 8 keeps the plain walk.  Same tiles, same arithmetic: bit-identical (VD3D_PLAIN_TILE_WALK=1 for A/B).
+struct TileWalk { int first, end, stride; };
+VD3D_DEV TileWalk xcd_tile_walk(int ntiles, int plain_walk) {
+    TileWalk w = {(int)blockIdx.x, ntiles, (int)gridDim.x};
+    if ((gridDim.x & 7) == 0 && !plain_walk) {
+        const int xcd = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
+        const int start = xcd * q + (xcd < r ? xcd : r);
+        w.first = start + (int)(blockIdx.x >> 3);
+        w.end = start + q + (xcd < r ? 1 : 0);
+        w.stride = (int)(gridDim.x >> 3);
+    }
+    return w;
+}
+inline int plain_tile_walk() {
+    static const int v = getenv("VD3D_PLAIN_TILE_WALK") != nullptr ? 1 : 0;
+    return v;
+}
+
 template <typename T, bool RES>
-__global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, int ntiles) {
+__global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, int ntiles, int plain_walk) {
     constexpr int NW = 8, HP = 3;                     // waves; halo pieces per wave (23 = 7 waves x 3 + 1 wave x 2)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -72,8 +95,13 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
     }
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // XCD-aware tile walk (xcd_tile_walk above): 10 x 18 pixels are staged per 8 x 16 computed (1.41 x) -- with the plain walk FETCH_SIZE read 1.38 x the
+    // input of a kernel that runs at the bandwidth of a mixed read / write stream
+    const TileWalk walk = xcd_tile_walk(ntiles, plain_walk);
+    int t = walk.first;
+    const int t_end = walk.end, nwg = walk.stride;
     auto issue_halo = [&](int t, int stage) {
-        const bool tv = t < ntiles;
+        const bool tv = t < t_end;
         const int tt = tv ? t : 0;
         const int b = tt / tiles_img, trem = tt - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -107,8 +135,6 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
         ss[tid] = p.scale ? p.scale[tid] : 1.f;
         ss[64 + tid] = p.shift ? p.shift[tid] : 0.f;
     }
-    const int nwg = gridDim.x;
-    int t = blockIdx.x;
 #pragma unroll
     for (int s0 = 0; s0 < kResStages; ++s0) issue_halo(t + s0 * nwg, s0);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kResStages - 1) * HP) : "memory");   // the first halo has landed (per wave) ...
@@ -125,7 +151,7 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
     // retires loads and stores in issue order.
     constexpr int kYounger = 2 * HP + (RES ? 4 : 0);     // RES: the 4 residual loads of this tile are younger too
     int stage = 0;
-    for (; t < ntiles; t += nwg) {
+    for (; t < t_end; t += nwg) {
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -513,7 +539,7 @@ __global__ void __launch_bounds__(256) conv_regw_kernel(const ConvArgs p, int nt
 // k-step; the MFMA's 32 output-channel rows are padded with zero filters) and one barrier.  Input read once (+ halo overlap),
 // output written once.  Epilogue: scale / shift (+ReLU), 16-bit (Cout % 16 == 0) or fp32 (Cout % 4 == 0) 16-byte stores.
 template <typename T, int CIN, int S, bool OUTF32>
-__global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int ntiles) {
+__global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int ntiles, int plain_walk) {
     constexpr int TH = 8, TW = 32;
     constexpr int HH = (TH - 1) * S + 3, HWD = (TW - 1) * S + 3;       // input halo of one output tile
     constexpr int PITCH = CIN * 2;                                    // bytes per halo pixel in LDS
@@ -556,8 +582,10 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int n
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x80000000u, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int in_bs = (int)p.in_batch_stride;
+    const TileWalk walk = xcd_tile_walk(ntiles, plain_walk);       // (the halo overlaps of neighbouring tiles become L2 hits)
+    const int t_end = walk.end, nwg = walk.stride;
     auto issue_halo = [&](int t, int stage) {
-        const bool tv = t < ntiles;
+        const bool tv = t < t_end;
         const int tt = tv ? t : 0;
         const int b = tt / tiles_img, trem = tt - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -593,8 +621,7 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int n
         ss[tid] = (p.scale && tid < p.Cout) ? p.scale[tid] : 1.f;
         ss[32 + tid] = (p.shift && tid < p.Cout) ? p.shift[tid] : 0.f;
     }
-    const int nwg = gridDim.x;
-    int t = blockIdx.x;
+    int t = walk.first;
 #pragma unroll
     for (int s0 = 0; s0 < NST; ++s0) issue_halo(t + s0 * nwg, s0);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NST - 1) * P) : "memory");
@@ -608,7 +635,7 @@ __global__ void __launch_bounds__(512) conv_small_kernel(const ConvArgs p, int n
     // (issued at tile k + 1 - NST's barrier) must have landed: younger than it are (NST - 2) D's and (NST - 1) S's.
     constexpr int kYounger = (NST - 2) * P + (NST - 1) * NS;
     int stage = 0, k = 0;
-    for (; t < ntiles; t += nwg, ++k) {
+    for (; t < t_end; t += nwg, ++k) {
         f32x16 acc;
         const int b = t / tiles_img, trem = t - b * tiles_img;
         const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -1077,8 +1104,9 @@ static int launch_resident64_t(ConvArgs& a, hipStream_t stream) {
     if (num_cu <= 0) return VD3D_ELAUNCH;
     const int ntiles = a.B * ((a.H + kResTH - 1) / kResTH) * ((a.W + kResTW - 1) / kResTW);
     const int grid = ntiles < num_cu ? ntiles : num_cu;
-    if (a.residual) hipLaunchKernelGGL((conv_resident64_kernel<T, true>), dim3(grid), dim3(512), kResLds, stream, a, ntiles);
-    else hipLaunchKernelGGL((conv_resident64_kernel<T, false>), dim3(grid), dim3(512), kResLds, stream, a, ntiles);
+    const int plain_walk = plain_tile_walk();
+    if (a.residual) hipLaunchKernelGGL((conv_resident64_kernel<T, true>), dim3(grid), dim3(512), kResLds, stream, a, ntiles, plain_walk);
+    else hipLaunchKernelGGL((conv_resident64_kernel<T, false>), dim3(grid), dim3(512), kResLds, stream, a, ntiles, plain_walk);
     return vd3d_check_launch("conv_resident64");
 }
 
@@ -1109,7 +1137,7 @@ static int launch_small_t(ConvArgs& a, hipStream_t stream) {
     // small halo stages leave room for two workgroups per CU (16 waves hide the DMA latency of these short tiles better)
     const int per_cu = LDS <= 72 * 1024 ? 2 : 1;
     const int grid = ntiles < num_cu * per_cu ? ntiles : num_cu * per_cu;
-    hipLaunchKernelGGL((conv_small_kernel<T, CIN, S, OUTF32>), dim3(grid), dim3(512), LDS, stream, a, ntiles);
+    hipLaunchKernelGGL((conv_small_kernel<T, CIN, S, OUTF32>), dim3(grid), dim3(512), LDS, stream, a, ntiles, plain_tile_walk());
     return vd3d_check_launch("conv_small");
 }
 

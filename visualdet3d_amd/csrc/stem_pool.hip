@@ -45,7 +45,7 @@ struct StemArgs {
     int B, Hp, Wp, Ho, Wo, Hq, Wq, Kpad, out_pix_stride;
     uint32_t in_bytes;
     int ntiles;
-    int plain_walk;    // A/B: VD3D_STEM_PLAIN_WALK
+    int plain_walk;    // A/B: VD3D_PLAIN_TILE_WALK
 };
 
 // F32IN: the patch comes straight from the fp32 NCHW image (the reference's network input) -- converted to the NHWC4 16-bit LDS image
@@ -282,7 +282,7 @@ template <bool F32IN, int TPY, int NW>
 static int launch_stem_t(StemArgs& a, int wg_per_cu, hipStream_t stream) {
     constexpr int LDS = stem_lds_bytes<TPY, F32IN>();
     a.ntiles = a.B * (a.Hq / TPY) * (a.Wq / kTPX);
-    static const bool plain_walk = getenv("VD3D_STEM_PLAIN_WALK") != nullptr;      // A/B of the XCD-aware tile walk (same tiles, same arithmetic: bit-identical)
+    static const bool plain_walk = getenv("VD3D_PLAIN_TILE_WALK") != nullptr;      // A/B of the XCD-aware tile walk (same tiles, same arithmetic: bit-identical)
     a.plain_walk = plain_walk ? 1 : 0;
     const int num_cu = vd3d_device_cu_count();
     if (num_cu <= 0) return VD3D_ELAUNCH;
