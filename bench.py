@@ -208,46 +208,56 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
     # of this very command (`bench.py --no-overlap`, tools/profile_round.sh -> profiles/*_serial_roofline_check.txt): the raw
     # event sums read the family 0.1-4 % LONGER than the profiler (an empty event pair reads 5-6 us, of which 0-3 us end up inside
     # a reading; subtracting a calibrated overhead over-corrected by 3.5-8 %), so the line stays on the conservative side.
+    # One reading per launch: the MEDIAN of its `reps` passes (the passes launch the same sequence, so launch i of pass r is record i + r * per).
+    # A mean lets ONE stalled pass -- seen under rocprofv3: the host falls behind, an event pair then brackets dispatch latency -- move the whole
+    # family by 20 % (profiles/r05: a serial profiled run read 836 instead of ~1 040 TF/s); the three timed regions of the line use the median too.
+    def med(vals):
+        return sorted(vals)[len(vals) // 2]
     per = len(records) // reps
+    launch_s = [med([max(records[i + r * per][2].elapsed_time(records[i + r * per][3]), 0.0) for r in range(reps)]) * 1e-3 for i in range(per)]
     if os.environ.get(verbose_env):
         for i in range(per):
-            fl = records[i][1]
-            t = sum(records[i + r * per][2].elapsed_time(records[i + r * per][3]) for r in range(reps)) / reps
-            print('  %-16s %2d  %-40s %8.2f GF  %8.1f us  %7.1f TF/s' % (records[i][0], i, records[i][5], fl / 1e9, t * 1e3, fl / (t * 1e-3) / 1e12), file=sys.stderr)
+            fl, t = records[i][1], launch_s[i]
+            print('  %-16s %2d  %-40s %8.2f GF  %8.1f us  %7.1f TF/s' % (records[i][0], i, records[i][5], fl / 1e9, t * 1e6, fl / t / 1e12), file=sys.stderr)
     fam = {}
-    for r in records:
+    for i in range(per):
+        r = records[i]
         d = fam.setdefault(r[0], dict(flops=0.0, secs=0.0, launches=0, bytes=0.0))
-        d['flops'] += r[1] / reps
-        d['secs'] += max(r[2].elapsed_time(r[3]), 0.0) * 1e-3 / reps
-        d['launches'] += 1.0 / reps
-        d['bytes'] += r[4] / reps
+        d['flops'] += r[1]
+        d['secs'] += launch_s[i]
+        d['launches'] += 1.0
+        d['bytes'] += r[4]
     # the single most expensive layer shape over all families (its launches all run the same kernel)
     by_shape = {}
-    for r in records:
+    for i in range(per):
+        r = records[i]
         d = by_shape.setdefault((r[0], r[5]), [0.0, 0.0, 0])
         d[0] += r[1]
-        d[1] += max(r[2].elapsed_time(r[3]), 0.0) * 1e-3
+        d[1] += launch_s[i]
         d[2] += 1
     total_secs = sum(d['secs'] for d in fam.values())
     dominant = {}
     for family in fam:
         (f_, name), (fl, tt, n) = max(((k, v) for k, v in by_shape.items() if k[0] == family), key=lambda kv: kv[1][1])
-        dominant[family] = dict(layer=name, launches_per_step=n // reps, share_of_family_time=round(tt / (fam[family]['secs'] * reps), 4),
+        dominant[family] = dict(layer=name, launches_per_step=n, share_of_family_time=round(tt / fam[family]['secs'], 4),
                                 avg_launch_us=round(tt / n * 1e6, 1), achieved=round(fl / tt / 1e12, 1) if tt > 0 else 0.0)
-    # HBM-bound kernels: per distinct launch shape, algorithmic bytes / mean duration against the HBM roof
+    # HBM-bound kernels: per distinct launch shape, algorithmic bytes / duration (median over the passes per launch) against the HBM roof
     hbm = {}
-    for label, nb, s0, e0 in hbm_records:
+    hper = len(hbm_records) // reps
+    for i in range(hper):
+        label, nb = hbm_records[i][0], hbm_records[i][1]
         d = hbm.setdefault(label, [0.0, 0.0, 0])
         d[0] += nb
-        d[1] += max(s0.elapsed_time(e0), 0.0) * 1e-3
+        d[1] += med([max(hbm_records[i + r * hper][2].elapsed_time(hbm_records[i + r * hper][3]), 0.0) for r in range(reps)]) * 1e-3
         d[2] += 1
-    for r in records:                      # the DCN launches with few channels are gather / HBM-side kernels too (64 -> 64 at full resolution)
+    for i in range(per):                   # the DCN launches with few channels are gather / HBM-side kernels too (64 -> 64 at full resolution)
+        r = records[i]
         if r[0] == 'dcn' and r[4] and ' 64->  64 ' in r[5]:
             d = hbm.setdefault('dcn_nhwc_kernel ' + r[5], [0.0, 0.0, 0])
             d[0] += r[4]
-            d[1] += max(r[2].elapsed_time(r[3]), 0.0) * 1e-3
+            d[1] += launch_s[i]
             d[2] += 1
-    hbm_kernels = [dict(kernel=k, launches_per_step=v[2] // reps, algorithmic_bytes_per_launch=int(v[0] / v[2]), avg_launch_us=round(v[1] / v[2] * 1e6, 1),
+    hbm_kernels = [dict(kernel=k, launches_per_step=v[2], algorithmic_bytes_per_launch=int(v[0] / v[2]), avg_launch_us=round(v[1] / v[2] * 1e6, 1),
                         achieved_gbps=round(v[0] / v[1] / 1e9, 1) if v[1] > 0 else None,
                         frac_of_peak=round(v[0] / v[1] / 1e9 / PEAK_HBM_GBPS, 4) if v[1] > 0 else None,
                         frac_of_achievable=round(v[0] / v[1] / 1e9 / ACHIEVABLE_HBM_GBPS, 4) if v[1] > 0 else None)
@@ -499,7 +509,7 @@ def time_other_config(c, device, steps, warmup):
         inputs = (syn.mono_image(B, H, W, seed=3).to(device), P2.to(device))
     st = Stepper(m, inputs, B, device)
     elapsed, all_s, counts = st.timed(steps, warmup)
-    fam, dominant, _ = profile_ops(m, inputs, reps=2, verbose_env='VD3D_BENCH_LAYERS_OTHER')
+    fam, dominant, _ = profile_ops(m, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS_OTHER')
     value = B * steps / elapsed
     # the single (family, layer shape) that costs the step most
     dom_family = max(dominant, key=lambda k: dominant[k]['avg_launch_us'] * dominant[k]['launches_per_step'])
@@ -794,7 +804,8 @@ def main():
                          'whole_path_frac': round(value / world * GFLOP_PER_PAIR * (args.height * args.width) / (384 * 1280) / 1e3 / peak, 4),
                          # the HBM-bound stages of the step (north_star: "rocprof HBM GB/s"): algorithmic bytes / HIP-event duration per launch
                          # against the HBM roof; the counter side (FETCH / WRITE) is profiles/r*_pmc_traffic.json `hbm_kernels`
-                         'hbm_kernels': hbm_kernels, 'hbm_peak_gbps': PEAK_HBM_GBPS, 'hbm_achievable_gbps': ACHIEVABLE_HBM_GBPS},
+                         'hbm_kernels': hbm_kernels, 'hbm_peak_gbps': PEAK_HBM_GBPS, 'hbm_achievable_gbps': ACHIEVABLE_HBM_GBPS,
+                         'launch_time_statistic': 'per launch: the median of 3 serial HIP-event passes; a family = the sum over its launches'},
         }
         if gather_us is not None:
             line['config']['all_gather_us_per_step_rank0'] = round(gather_us, 1)
