@@ -174,3 +174,74 @@ def test_grouped_tile_order_is_a_bijection():
         assert all(0 <= m < tiles_m and 0 <= n < tiles_n for m, n in seen)
         first = seen[:gm * tiles_n] if tiles_m >= gm else seen
         assert {n for _, n in first} == set(range(tiles_n)) and len({m for m, _ in first}) == min(gm, tiles_m)
+
+
+def test_xcd_tile_walk_is_a_partition():
+    """The XCD-aware walk of the persistent stem / layer-1 / small-channel kernels (csrc/conv_resident.hip xcd_tile_walk, csrc/stem_pool.hip) restated in
+    Python: over all workgroups every tile is visited exactly once, an XCD's workgroups (b, b + 8, ...) cover ONE contiguous run of the tile list,
+    and in every round they take consecutive tiles of it; a grid that is not a multiple of 8 keeps the plain walk."""
+    def walk(b, grid, ntiles):
+        if grid % 8:
+            return list(range(b, ntiles, grid))
+        xcd, q, r = b & 7, ntiles >> 3, ntiles & 7
+        start = xcd * q + min(xcd, r)
+        end = start + q + (1 if xcd < r else 0)
+        return list(range(start + (b >> 3), end, grid >> 3))
+
+    for grid, ntiles in [(256, 3840), (256, 3841), (240, 240), (256, 487), (8, 3), (64, 10), (250, 1000), (256, 255)]:
+        per_wg = [walk(b, grid, ntiles) for b in range(grid)]
+        seen = sorted(t for w in per_wg for t in w)
+        assert seen == list(range(ntiles)), (grid, ntiles)
+        if grid % 8 == 0:
+            for xcd in range(8):
+                mine = sorted(t for b in range(xcd, grid, 8) for t in per_wg[b])
+                assert mine == list(range(mine[0], mine[0] + len(mine))) if mine else True          # one contiguous run per XCD
+                rounds = max((len(per_wg[b]) for b in range(xcd, grid, 8)), default=0)
+                for k in range(rounds):                                                              # round k: consecutive tiles
+                    row = [per_wg[b][k] for b in range(xcd, grid, 8) if len(per_wg[b]) > k]
+                    assert row == list(range(row[0], row[0] + len(row)))
+
+
+def test_unpad_own_copies_equal_the_plain_slices():
+    """`unpad(..., own=True)` (what the detectors' test_forward returns: views of private copies made before the host sync) against the plain
+    per-sample slices: same values, dtypes, shapes, contiguous -- both heads; counts through `lib/graphed.read_counts` (CPU tensors: .tolist())."""
+    from visualdet3d_amd.networks.heads.detection_3d_head import AnchorBasedDetection3DHead as H
+    from visualdet3d_amd.networks.heads.km3d_head import KM3DHead as K
+    from visualdet3d_amd.networks.lib.graphed import read_counts
+    g = torch.Generator().manual_seed(0)
+    B, M = 3, 8
+    sc, bx = torch.rand(B, M, generator=g), torch.rand(B, M, 11, generator=g)
+    lb = torch.randint(0, 3, (B, M), generator=g, dtype=torch.int32)
+    cnt = torch.tensor([2, 0, 5], dtype=torch.int32)
+    assert read_counts(cnt) == [2, 0, 5]
+    for plain, own in ((H.unpad((sc, bx, lb, None, cnt)), H.unpad((sc, bx, lb, None, cnt), own=True)),
+                       (K.unpad((sc, bx, lb, cnt)), K.unpad((sc, bx, lb, cnt), own=True))):
+        assert len(plain) == len(own) == B
+        for x, y in zip(plain, own):
+            for p_, q_ in zip(x, y):
+                assert torch.equal(p_, q_) and p_.dtype == q_.dtype and p_.shape == q_.shape and q_.is_contiguous()
+        assert own[2][2].dtype == torch.int64
+        own[2][0].zero_()                                   # the caller's copy is private
+        assert float(sc[2, :5].abs().sum()) > 0
+    with pytest.raises(RuntimeError):
+        H.unpad((sc, bx, lb, None, torch.tensor([1, -1, 0], dtype=torch.int32)), own=True)
+
+
+def test_host_feed_frames_are_the_resident_images_as_bytes():
+    """bench.py --feed host: the uploaded frames are the resident workload's images de-normalised and rounded to bytes (so that the host-fed step also
+    decodes detections); slot 1 = slot 0 in another batch order."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from visualdet3d_amd.utils import synthetic as syn
+    L, R = syn.stereo_pair(2, 32, 64, seed=5)
+    f0, f1 = bench.HostFeed.slot_frames(L, R)
+    assert f0.shape == (4, 32, 64, 3) and f0.dtype == torch.uint8 and f1.shape == f0.shape
+    assert torch.equal(f1[1], f0[0]) and torch.equal(f1[0], f0[1]) and torch.equal(f1[3], f0[2])
+    mean, std = torch.tensor((0.485, 0.456, 0.406)), torch.tensor((0.229, 0.224, 0.225))
+    back = (f0[:2].float() / 255 - mean) / std               # [2, H, W, 3]
+    want = L.permute(0, 2, 3, 1)
+    inside = ((want * std + mean) >= 0) & ((want * std + mean) <= 1)
+    assert float(((back - want).abs() * inside).max()) <= 0.5 / 255 / float(std.min()) + 1e-6
+    assert float(inside.float().mean()) > 0.9
