@@ -204,8 +204,10 @@ int vd3d_conv3d_3x3x3(const void* in, const float* weight, const float* scale, c
  * Outputs (padded to max_det per sample, decreasing score == torchvision nms order):
  *   out_scores [B][max_det], out_boxes [B][max_det][11], out_labels [B][max_det] int32,
  *   out_anchor [B][max_det] int32 (flat anchor index), out_count [B] int32
- * workspace: see vd3d_head_workspace_bytes.  If more than max_cand anchors pass the score threshold in a
- * sample, out_count[b] = -1 (caller must raise). */
+ * workspace: see vd3d_head_workspace_bytes.  max_cand: a power of two.  If more than max_cand anchors pass the score threshold in a
+ * sample, out_count[b] = -1 (more than max_det survivors: -2) and the caller repeats the call for that sample with a larger capacity -- the
+ * reference's candidate list has no cap (detection_3d_head.py:341-400).  Capacities <= 8192 keep the per-frame lists in LDS; larger ones
+ * (up to every anchor of the frame) run the same steps on lists in `workspace`, one workgroup per frame: correct at any count, not fast. */
 typedef struct vd3d_head_params {
     const float* cls;
     const float* reg;

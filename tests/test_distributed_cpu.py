@@ -18,7 +18,11 @@ def _free_port():
 
 
 def _run_world2(target, args_after_port, timeout):
-    """spawn two ranks of `target(rank, 2, port, *args_after_port, q)`, return what rank 0 put on the queue.  The rendezvous port is chosen by
+    return _run_world(2, target, args_after_port, timeout)
+
+
+def _run_world(world, target, args_after_port, timeout):
+    """spawn `world` ranks of `target(rank, world, port, *args_after_port, q)`, return what rank 0 put on the queue.  The rendezvous port is chosen by
     binding port 0 and releasing it: another process can take it in between (seen once in ~50 runs of the suite) -- a failed rendezvous is
     retried on a fresh port, a failure of the ranks' own assertions is not masked (it fails all three attempts the same way)."""
     last = None
@@ -26,7 +30,7 @@ def _run_world2(target, args_after_port, timeout):
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=target, args=(r, 2, port) + tuple(args_after_port) + (q,)) for r in range(2)]
+        procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args_after_port) + (q,)) for r in range(world)]
         for p in procs:
             p.start()
         try:
@@ -34,7 +38,7 @@ def _run_world2(target, args_after_port, timeout):
             for p in procs:
                 p.join(timeout=timeout)
             codes = [p.exitcode for p in procs]
-            if codes == [0, 0]:
+            if codes == [0] * world:
                 return out
             last = AssertionError('rank exit codes %s (attempt %d)' % (codes, attempt + 1))
         except Exception as e:                       # noqa: BLE001 -- queue.Empty: a rank died before reporting
@@ -152,3 +156,114 @@ def test_detector_output_through_the_gather_world2():
     for f, (s_, b_, l_) in enumerate(dets):
         assert_detections_close((s_, b_, l_), (g['f%d_scores' % f], g['f%d_boxes' % f], g['f%d_labels' % f]), rtol=1e-4,
                                 what='gathered frame %d' % f)
+
+
+# ---- world 8: BASELINE config 4's partition (64 frames -> 8 x 8), per-rank data, one collective per step ---------------------------
+def _worker8(rank, world, port, n_frames, steps, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    lo, hi = vdist.shard_range(n_frames, rank, world)
+    B = hi - lo
+    gathers = [vdist.DetectionGather(B, 32, 'cpu') for _ in range(2)]          # double buffered like bench.py's comm stream
+    last = None
+    for i in range(steps):
+        # every rank produces ITS frames of step i from its own seed (bench.py: stereo_pair(seed = 100 + rank)); frame f of the job is rank f // B's
+        scores, boxes, labels, count = _fake_padded(B, K=40, seed=1000 * i + rank)
+        g = gathers[i & 1]
+        g(scores, boxes, labels, count)
+        last = g.detections()
+    if rank == 0:
+        q.put((last[0].clone(), last[1].clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_gather_of_64_frames_equals_the_single_process_result():
+    """64 frames on 8 ranks (8 each, contiguous shards, per-rank seeds): what rank 0 holds after the step's ONE collective is exactly what a single
+    process computes for all 64 frames, in frame order -- for the last of three double-buffered steps."""
+    world, n, steps = 8, 64, 3
+    pack, cnt = _run_world(world, _worker8, (n, steps), 300)
+    want_p, want_c = [], []
+    for r in range(world):
+        lo, hi = vdist.shard_range(n, r, world)
+        assert (lo, hi) == (8 * r, 8 * r + 8)
+        scores, boxes, labels, count = _fake_padded(hi - lo, K=40, seed=1000 * (steps - 1) + r)
+        p, c = vdist.pack_detections(scores, boxes, labels, count, k=32)
+        want_p.append(p)
+        want_c.append(c)
+    assert torch.equal(pack, torch.cat(want_p)) and torch.equal(cnt, torch.cat(want_c))
+    assert len(vdist.unpack_detections(pack, cnt)) == n
+
+
+# ---- host placement: eight ranks of one node never share a core ---------------------------------------------------------------------
+def _fake_sysfs(root, gpu_nodes, node_cpus):
+    for i, node in enumerate(gpu_nodes):
+        d = os.path.join(root, 'bus/pci/devices/0000:%02x:00.0' % (0x10 + i))
+        os.makedirs(d)
+        open(os.path.join(d, 'numa_node'), 'w').write('%d\n' % node)
+    for node, cpus in node_cpus.items():
+        d = os.path.join(root, 'devices/system/node/node%d' % node)
+        os.makedirs(d)
+        open(os.path.join(d, 'cpulist'), 'w').write(cpus + '\n')
+    return ['0000:%02x:00.0' % (0x10 + i) for i in range(len(gpu_nodes))]
+
+
+def test_rank_cpu_sets_partition_each_numa_node_among_its_gpus(tmp_path):
+    # an MI355X node: 8 GPUs, 4 per socket; 2 x 64 cores with SMT siblings numbered 128+
+    bdfs = _fake_sysfs(str(tmp_path), [0, 0, 0, 0, 1, 1, 1, 1], {0: '0-63,128-191', 1: '64-127,192-255'})
+    sets = vdist.rank_cpu_sets(bdfs, sysfs=str(tmp_path))
+    assert all(len(s) == 32 for s in sets)
+    for a in range(8):
+        node_cpus = vdist._parse_cpulist('0-63,128-191' if a < 4 else '64-127,192-255')
+        assert sets[a] <= node_cpus, 'rank %d left its GPU\'s NUMA node' % a
+        for b in range(a + 1, 8):
+            assert not (sets[a] & sets[b]), 'ranks %d and %d share cores' % (a, b)
+    # restricted by the cgroup: only the allowed CPUs are divided; a GPU without a node is not pinned
+    sets = vdist.rank_cpu_sets(bdfs, sysfs=str(tmp_path), allowed=range(0, 8))
+    assert [sorted(s) for s in sets[:4]] == [[0, 1], [2, 3], [4, 5], [6, 7]] and sets[4:] == [None] * 4
+    bdfs2 = _fake_sysfs(str(tmp_path / 'b'), [-1, 0], {0: '0-3'})
+    assert vdist.rank_cpu_sets(bdfs2, sysfs=str(tmp_path / 'b')) == [None, {0, 1, 2, 3}]
+
+
+def _producer(rank, sysfs, bdfs, q):
+    """one --feed host producer: pin like bench.py does, then make the ring's uint8 frames (HostFeed.slot_frames) and report where it ran"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cpus = vdist.rank_cpu_sets(bdfs, sysfs=sysfs, allowed=os.sched_getaffinity(0))[rank]
+    os.sched_setaffinity(0, cpus)
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(rank)
+    L, R = torch.randn(1, 3, 32, 64, generator=g), torch.randn(1, 3, 32, 64, generator=g)
+    frames = bench.HostFeed.slot_frames(L, R)
+    q.put((rank, sorted(os.sched_getaffinity(0)), int(frames[0].shape[0]), str(frames[0].dtype)))
+
+
+def test_eight_concurrent_host_feed_producers_run_on_disjoint_cores(tmp_path):
+    """Eight producer processes (one per rank of a node), pinned by the rule bench.py applies (`pin_to_gpu_numa_node` -> `rank_cpu_sets`), on a fake
+    topology laid over THIS machine's CPUs (two 'NUMA nodes' = the two halves of the allowed CPUs, four 'GPUs' each): every process ends up on its
+    own core(s), inside its GPU's node."""
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 8:
+        import pytest
+        pytest.skip('needs 8 CPUs')
+    half = len(allowed) // 2
+    lists = {0: ','.join(map(str, allowed[:half])), 1: ','.join(map(str, allowed[half:]))}
+    bdfs = _fake_sysfs(str(tmp_path), [0, 0, 0, 0, 1, 1, 1, 1], lists)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_producer, args=(r, str(tmp_path), bdfs, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(8))
+    for p in procs:
+        p.join(timeout=60)
+    assert [p.exitcode for p in procs] == [0] * 8
+    seen = set()
+    for rank, cpus, n, dt in got:
+        assert cpus and not (set(cpus) & seen), 'rank %d shares a core with another producer' % rank
+        seen |= set(cpus)
+        assert set(cpus) <= set(allowed[:half] if rank < 4 else allowed[half:])
+        assert n == 2 and dt == 'torch.uint8'

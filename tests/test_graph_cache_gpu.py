@@ -206,3 +206,31 @@ def test_cache_is_lru_and_keyed_on_the_anchor_filter():
     m.use_graph = False
     m.bbox_head.anchors.filter_x_threshold = 20.0
     assert _same(r1, m(x))
+
+
+def test_candidate_overflow_inside_a_replayed_graph_is_rerun_off_graph():
+    """More candidates than the captured capacity (here: `max_candidates` lowered to 16 so that the golden workload overflows) must not be an
+    error: the frame is re-run eagerly on the graph's own logits with a capacity that fits (detectors `_overflow_retry`), in the first (capturing)
+    call, in a replay, and for one frame of a batched call -- results equal the uncapped ones bit for bit (same kernels, same arithmetic);
+    and the test_cfg fingerprint of the graph key sees a key swapped for another of equal value."""
+    m, cfg, (L, R, P2, P3), _ = _stereo()
+    x = [L[:1], R[:1], P2[:1], P3[:1]]
+    want = m(x)
+    want_b = m.test_forward_batched(L, R, P2, P3)
+    assert want[0].numel() > 16
+    m.bbox_head.max_candidates = 16
+    got = m(x)                                  # captures a new graph (the capacity is part of the key) whose count is -1, then retries
+    assert _same(got, want)
+    got = m(x)                                  # replay + retry
+    assert _same(got, want) and m.graph_stats['replays'] >= 2
+    got_b = m.test_forward_batched(L, R, P2, P3)
+    assert all(_same(a, b) for a, b in zip(got_b, want_b))
+    m.use_graph = False
+    assert _same(m(x), want)
+    m.use_graph = True
+    caps = m.graph_stats['captures']
+    tc = m.bbox_head.test_cfg
+    v = tc.pop('nms_iou_thr')
+    tc['nms_iou_thr_renamed'] = v               # same values, other keys: the head now reads its default 0.5
+    m(x)
+    assert m.graph_stats['captures'] == caps + 1, 'a test_cfg key swapped for another of equal value replayed the stale graph'

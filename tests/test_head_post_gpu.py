@@ -87,7 +87,41 @@ def test_head_candidate_overflow_is_reported():
     head.max_candidates = 64
     padded = head.get_bboxes_batched(cls.cuda(), reg.cuda(), P2.cuda(), (96, 320))
     with pytest.raises(RuntimeError):
-        head.unpad(padded)
+        head.unpad(padded)                     # the bare padded arrays carry no logits to retry with: the overflow is an error HERE ...
+    assert int(padded[4][0]) == -1
+
+
+@pytest.mark.parametrize('H,W,bias,std,lo,hi', [(192, 640, 0.9, 1.0, 4096, 8192),        # one doubling: 8192, still the LDS path
+                                                (384, 1280, 0.0, 1.0, 8192, 16384),      # config 2's frame size; capacity 16 384: the global-memory path
+                                                (384, 1280, 1.5, 1.0, 16384, 32768)])    # nearly every anchor the ground filter lets through
+def test_more_candidates_than_the_captured_capacity_equal_the_oracle(H, W, bias, std, lo, hi):
+    """The reference's candidate list has no cap (detection_3d_head.py:341-400: boolean indexing, then nms).  A frame with more candidates than
+    `max_candidates` (4096, the capacity of the captured launch) is re-run with doubled capacities (get_bboxes_unbounded; beyond 8192 the lists are
+    sorted in global memory): same selection, same order, same labels as the oracle -- through the reference-signature `get_bboxes` and through `unpad(retry=)`."""
+    B = 2
+    cfg, head, cls, reg, P2 = _setup(H, W, B, 21, logit_bias=bias, logit_std=std)
+    cls[1] -= bias + 1.0                             # frame 1: the ordinary path in the same call (_setup's default level)
+    mean_npy, std_npy = orc.load_priors(cfg.head.preprocessed_path, cfg.obj_types)
+    anchors, means, mean_std = orc.anchors_for_image(H, W, cfg.head.anchors_cfg, mean_npy, std_npy)
+    mask = orc.anchor_mask(anchors, means, P2)
+    ncand = int(((torch.sigmoid(cls[0][:, :2]).amax(dim=1) > 0.6) & mask[0]).sum())
+    assert lo < ncand <= hi, ncand
+    clsd, regd, P2d = cls.cuda(), reg.cuda(), P2.cuda()
+    padded = head.get_bboxes_batched(clsd, regd, P2d, (H, W))
+    assert padded[4].tolist()[0] == -1 and padded[4].tolist()[1] >= 0
+    outs = head.unpad(padded, retry=lambda b: head.get_bboxes_unbounded(clsd[b:b + 1], regd[b:b + 1], P2d[b:b + 1], (H, W)))
+    img = torch.zeros(1, 3, H, W)
+    head.get_anchor(img.cuda(), P2d[0:1])
+    ref_sig = head.get_bboxes(clsd[0:1], regd[0:1], None, P2d[0:1], img.cuda())
+    for b in range(B):
+        s, bx, l, idx = orc.get_bboxes(cls[b], reg[b], anchors, mean_std, mask[b], (H, W), 2, 0.6, 0.4)
+        for got in ([outs[b]] + ([ref_sig] if b == 0 else [])):
+            gs, gb, gl = [t.cpu() for t in got]
+            assert len(gs) == len(s) and len(s) >= 1, (b, len(gs), len(s))
+            assert torch.equal(gl, l)
+            assert torch.equal(gs, s) or torch.allclose(gs, s, rtol=1e-5, atol=1e-6)
+            sc = bx.abs().amax(dim=0).clamp_min(1.0)
+            assert ((gb - bx).abs() / sc).max().item() < 1e-5
 
 
 @pytest.mark.parametrize('n,seed', [(0, 0), (1, 1), (37, 2), (64, 3), (65, 4), (1000, 5), (5000, 6)])

@@ -245,3 +245,32 @@ def test_host_feed_frames_are_the_resident_images_as_bytes():
     inside = ((want * std + mean) >= 0) & ((want * std + mean) <= 1)
     assert float(((back - want).abs() * inside).max()) <= 0.5 / 255 / float(std.min()) + 1e-6
     assert float(inside.float().mean()) > 0.9
+
+
+def test_bench_gpus_flag_is_honoured(tmp_path):
+    """`bench.py --gpus N`: under a launcher N must equal WORLD_SIZE; without one and N > 1 the script re-executes itself under
+    torch.distributed.run with N ranks; it never prints an `n_gpus: 1` line for a `--gpus 8` command."""
+    import os
+    import subprocess
+    import sys
+
+    import pytest
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    assert bench.resolve_world(None, {}, ['bench.py']) == ('run', 1)
+    assert bench.resolve_world(1, {}, ['bench.py']) == ('run', 1)
+    assert bench.resolve_world(None, {'WORLD_SIZE': '4'}, ['bench.py']) == ('run', 4)
+    assert bench.resolve_world(8, {'WORLD_SIZE': '8'}, ['bench.py']) == ('run', 8)
+    with pytest.raises(ValueError):
+        bench.resolve_world(8, {'WORLD_SIZE': '1'}, ['bench.py'])
+    with pytest.raises(ValueError):
+        bench.resolve_world(2, {'WORLD_SIZE': '4'}, ['bench.py'])
+    how, cmd = bench.resolve_world(8, {}, ['bench.py', '--gpus', '8', '--steps', '3'], executable='python')
+    assert how == 'exec' and cmd[:3] == ['python', '-m', 'torch.distributed.run']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-5:] == ['bench.py', '--gpus', '8', '--steps', '3']
+    # the script itself: a mismatch exits non-zero before anything touches the GPU, and nothing is printed on stdout
+    env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8'], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == '' and 'disagree' in r.stderr

@@ -43,10 +43,7 @@ VD3D_DEV TileWalk xcd_tile_walk(int ntiles, int plain_walk) {
     }
     return w;
 }
-inline int plain_tile_walk() {
-    static const int v = getenv("VD3D_PLAIN_TILE_WALK") != nullptr ? 1 : 0;
-    return v;
-}
+inline int plain_tile_walk() { return vd3d_switch(VD3D_SW_PLAIN_TILE_WALK) ? 1 : 0; }
 
 template <typename T, bool RES>
 __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, int ntiles, int plain_walk) {

@@ -16,7 +16,7 @@
 namespace {
 
 constexpr int kSelThreads = 256;
-constexpr int kMaxSort = 8192;  // LDS bitonic sort capacity (64 KiB of keys)
+constexpr int kMaxSort = 8192;  // LDS bitonic sort capacity (64 KiB of keys); candidate capacities beyond it sort in global memory (the overflow path)
 
 VD3D_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -28,9 +28,16 @@ struct Workspace {  // per-sample slices of one flat buffer
     float* scores;        // [B][max_cand]
     int32_t* labels;      // [B][max_cand]
     int32_t* anchor;      // [B][max_cand]
+    char* big;            // max_cand > kMaxSort only: [B][big_bytes(max_cand)] -- the sort keys / positions / flags that otherwise live in LDS
 };
+// The reference's get_bboxes has NO cap on the candidate list (heads/detection_3d_head.py:341-400: boolean indexing, then nms).  Capacities up to
+// kMaxSort keep the per-frame lists in LDS (the production path); a larger capacity -- the caller's retry after an overflow, up to every anchor of the
+// frame -- runs the very same steps with those lists in global memory, one workgroup per frame.
+__host__ __device__ inline int64_t big_bytes(int max_cand) {
+    return max_cand > kMaxSort ? ((int64_t)max_cand * (8 + 4 + 4 + 1 + 1) + 255) / 256 * 256 : 0;
+}
 __host__ __device__ inline int64_t ws_bytes(int B, int max_cand) {
-    return 256 + (int64_t)B * 4 + (int64_t)B * max_cand * (4 + 4 + 44 + 4 + 4 + 4) + 256;
+    return 256 + (int64_t)B * 4 + (int64_t)B * max_cand * (4 + 4 + 44 + 4 + 4 + 4) + 256 + 256 + (int64_t)B * big_bytes(max_cand);
 }
 __host__ __device__ inline Workspace carve(void* base, int B, int max_cand) {
     Workspace w;
@@ -42,7 +49,8 @@ __host__ __device__ inline Workspace carve(void* base, int B, int max_cand) {
     w.boxes = (float*)p; p += n * 44;
     w.scores = (float*)p; p += n * 4;
     w.labels = (int32_t*)p; p += n * 4;
-    w.anchor = (int32_t*)p;
+    w.anchor = (int32_t*)p; p += n * 4;
+    w.big = max_cand > kMaxSort ? (char*)(((uintptr_t)p + 255) & ~(uintptr_t)255) : nullptr;
     return w;
 }
 
@@ -337,16 +345,20 @@ __global__ void __launch_bounds__(kNmsThreads) head_nms_kernel(const HeadArgs p)
     }
     int P = 1;
     while (P < K) P <<= 1;
-    // LDS carve
-    uint64_t* keys = (uint64_t*)smem;                                  // [max_cand]
-    int* pos = (int*)(keys + p.max_cand);                              // [max_cand]
+    // LDS carve (capacities beyond kMaxSort: the per-candidate lists live in the frame's slice of the global workspace instead; __syncthreads
+    // orders a workgroup's global accesses like its LDS accesses, so every step below is unchanged)
+    const bool big = p.max_cand > kMaxSort;
+    const int lcap = big ? 0 : p.max_cand;                             // list entries carved from LDS
+    char* gbase = big ? p.ws.big + (int64_t)b * big_bytes(p.max_cand) : nullptr;
+    uint64_t* keys = big ? (uint64_t*)gbase : (uint64_t*)smem;         // [max_cand]
+    int* pos = big ? (int*)(gbase + (int64_t)p.max_cand * 8) : (int*)(keys + p.max_cand);               // [max_cand]
     int* cidx = pos + p.max_cand;                                      // [max_cand] filtered position q -> anchor-order p
-    int* scratch = cidx + p.max_cand;                                  // [kNmsThreads]
+    int* scratch = big ? (int*)smem : cidx + p.max_cand;               // [kNmsThreads]
     f32x4* chunk_box = (f32x4*)(scratch + kNmsThreads);                // [64]
     float* chunk_area = (float*)(chunk_box + 64);                      // [64]
-    unsigned char* flag = (unsigned char*)(chunk_area + 64);           // [max_cand]
+    unsigned char* flag = big ? (unsigned char*)(cidx + p.max_cand) : (unsigned char*)(chunk_area + 64);   // [max_cand]
     unsigned char* alive = flag + p.max_cand;                          // [max_cand]
-    unsigned char* chunk_alive = alive + p.max_cand;                   // [64]
+    unsigned char* chunk_alive = big ? (unsigned char*)(chunk_area + 64) : alive + lcap;                // [64]
     int* total = (int*)(chunk_alive + 64);
     uint64_t* chunk_mask = (uint64_t*)(((uintptr_t)(total + 4) + 15) & ~(uintptr_t)15);      // [64] rows of the chunk's suppression matrix
     f32x4* sbox = p.max_cand <= 4096 ? (f32x4*)(chunk_mask + 64) : nullptr;   // [max_cand] 2-D boxes in NMS order (when they fit; else from global)
@@ -446,6 +458,7 @@ __global__ void __launch_bounds__(kNmsThreads) nms_kernel(const float* __restric
 }
 
 inline int64_t head_nms_lds(int max_cand) {
+    if (max_cand > kMaxSort) max_cand = 0;        // the overflow path keeps its per-candidate lists in global memory: scratch + chunk buffers only
     const int64_t block_path = (int64_t)max_cand * 8 + (int64_t)max_cand * 8 + kNmsThreads * 4 + 64 * 16 + 64 * 4 + max_cand * 2 + 64 + 16 + 32 + 64 * 8 +
                                (max_cand <= 4096 ? (int64_t)max_cand * 16 : 0);      // + chunk masks + (when they fit) the boxes in NMS order
     const int64_t wave_path = kWaveCand * (8 + 16 + 44 + 4 * 7 + 1) + 64;      // head_nms_wave's carve (24.3 KB)
@@ -469,9 +482,9 @@ static int head_args(const vd3d_head_params* q, HeadArgs& a, bool need_select, b
     }
     (void)need_select;
     if (q->B <= 0 || q->N <= 0 || q->A <= 0 || q->N % q->A || q->n_cls < 1 || q->n_types < q->n_cls ||
-        q->max_cand < 1 || q->max_cand > kMaxSort || (q->max_cand & (q->max_cand - 1)) || q->max_det < 1 ||
+        q->max_cand < 1 || q->max_cand > (1 << 24) || (q->max_cand & (q->max_cand - 1)) || q->max_det < 1 ||
         ((uintptr_t)q->anchors & 15)) {
-        vd3d_set_error("head_postprocess: bad sizes (max_cand must be a power of two <= 8192)");
+        vd3d_set_error("head_postprocess: bad sizes (max_cand must be a power of two <= 2^24)");
         return VD3D_EINVAL;
     }
     a.cls = q->cls; a.reg = q->reg; a.anchors = q->anchors; a.prior = q->prior_mean_std; a.P2 = q->P2;
@@ -489,6 +502,7 @@ extern "C" int vd3d_head_select(const vd3d_head_params* q, void* stream) {
     HeadArgs a;
     if (const int rc = head_args(q, a, true, false)) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (q->B > 65535) { vd3d_set_error("head_select: more than 65535 samples"); return VD3D_ERANGE; }      // (before anything is launched)
     hipLaunchKernelGGL(zero_counts_kernel, dim3((q->B + 63) / 64), dim3(64), 0, s, a.ws.count, q->B);
     // chunks x samples workgroups: ~512 in all (two per CU), a chunk a multiple of 256 anchors and at most 64 iterations of them
     int cps = (512 + q->B - 1) / q->B;
@@ -496,7 +510,6 @@ extern "C" int vd3d_head_select(const vd3d_head_params* q, void* stream) {
     if (cps > max_cps) cps = max_cps;
     if (cps < min_cps) cps = min_cps;
     const int chunk = ((q->N + cps - 1) / cps + kSelThreads - 1) / kSelThreads * kSelThreads;
-    if (q->B > 65535) { vd3d_set_error("head_select: more than 65535 samples"); return VD3D_ERANGE; }
     hipLaunchKernelGGL(head_select_kernel, dim3((unsigned)((q->N + chunk - 1) / chunk), (unsigned)q->B), dim3(kSelThreads), 0, s, a, chunk);
     return vd3d_check_launch("head_select");
 }

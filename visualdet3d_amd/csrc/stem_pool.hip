@@ -282,8 +282,7 @@ template <bool F32IN, int TPY, int NW>
 static int launch_stem_t(StemArgs& a, int wg_per_cu, hipStream_t stream) {
     constexpr int LDS = stem_lds_bytes<TPY, F32IN>();
     a.ntiles = a.B * (a.Hq / TPY) * (a.Wq / kTPX);
-    static const bool plain_walk = getenv("VD3D_PLAIN_TILE_WALK") != nullptr;      // A/B of the XCD-aware tile walk (same tiles, same arithmetic: bit-identical)
-    a.plain_walk = plain_walk ? 1 : 0;
+    a.plain_walk = vd3d_switch(VD3D_SW_PLAIN_TILE_WALK) ? 1 : 0;      // A/B of the XCD-aware tile walk (same tiles, same arithmetic: bit-identical)
     const int num_cu = vd3d_device_cu_count();
     if (num_cu <= 0) return VD3D_ELAUNCH;
     const int slots = num_cu * wg_per_cu;

@@ -2,8 +2,49 @@
 shards, one process per GPU (weights replicated), no data-path collective.  The only communication is the final gather
 of the fixed-size padded detection tensors (a few tens of KB per rank: one direct all_gather over RCCL/xGMI -- latency
 bound, nothing to tune).  Backend-agnostic: the same code runs over ``gloo`` on CPU tensors in the tests."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+# ---- host-side placement of the ranks of one node ---------------------------------------------------------------------------------
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if part:
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(bdf, sysfs='/sys'):
+    """NUMA node of the PCI device ``bdf`` ('0000:c1:00.0'), -1 when the platform reports none."""
+    return int(open(os.path.join(sysfs, 'bus/pci/devices', bdf, 'numa_node')).read().strip())
+
+
+def rank_cpu_sets(bdfs, sysfs='/sys', allowed=None):
+    """CPU affinity of every local rank, rank r driving the GPU ``bdfs[r]``: the CPUs of the GPU's NUMA node (pinned-memory copies and the
+    launch thread stay local to the GPU's root complex), DIVIDED among the ranks whose GPUs share that node -- 8 ranks on a two-socket host are
+    4 + 4, each with its own quarter of a socket, so that eight concurrent host-feed producers never compete for a core.  ``allowed``: the CPUs
+    this process may use at all (cgroup / taskset); a rank whose slice would be empty keeps the node's whole allowed set; a GPU without a NUMA node
+    -> None (not pinned)."""
+    nodes = [gpu_numa_node(b, sysfs) for b in bdfs]
+    out = []
+    for r, node in enumerate(nodes):
+        if node < 0:
+            out.append(None)
+            continue
+        cpus = _parse_cpulist(open(os.path.join(sysfs, 'devices/system/node/node%d/cpulist' % node)).read())
+        if allowed is not None:
+            cpus &= set(allowed)
+        peers = [i for i, n in enumerate(nodes) if n == node]
+        order = sorted(cpus)
+        per = len(order) // len(peers)
+        slot = peers.index(r)
+        mine = set(order[slot * per:(slot + 1) * per]) if per >= 1 else set()
+        out.append(mine or cpus or None)
+    return out
 
 
 def shard_range(n, rank, world):

@@ -186,10 +186,11 @@ def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
     p.weight_frag = pc.w_frag.data_ptr() if pc.w_frag is not None else None
     # split-K scratch for low-parallelism shapes (batch-1 calls): the library says how much it wants (0 for everything the batched
     # configurations launch).  The answer depends only on the launch geometry (shape, strides, alignments, epilogue form) and the
-    # library's test-hook state, so it is asked ONCE per (packed conv, geometry) and remembered on the packed conv; the scratch itself is
+    # library's test-hook state (+ whether a register image of the weights is attached, the activation type and the device: the routes that
+    # split need `weight_frag`, the plan reads the device's CU count), so it is asked ONCE per (packed conv, geometry) and remembered on the packed conv; the scratch itself is
     # a fresh stream-ordered allocation per call -- inside a hipGraph capture it lives in the graph's pool
     wkey = (B, H, W, ips, irs, ibs, p.out_pix_stride, p.out & 127, p.residual and (p.res_pix_stride, p.residual & 15), p.out_f32,
-            (p.scale or 0) & 15, (p.shift or 0) & 15, _lib.hook_epoch())
+            (p.scale or 0) & 15, (p.shift or 0) & 15, _lib.hook_epoch(), pc.w_frag is not None, x.dtype, x.device.index)
     need = pc.ws_need.get(wkey)
     if need is None:
         need = _lib.lib().vd3d_conv2d_workspace_bytes(C.byref(p))

@@ -76,6 +76,12 @@ class Yolo3D(GraphedForward, nn.Module):
         self._last_raw = (cls_preds, reg_preds)
         return self.bbox_head.get_bboxes_batched(cls_preds, reg_preds, P2, img_batch.shape[2:])
 
+    def _overflow_retry(self, b, P2, img_hw):
+        """sample b of the last forward had more candidates than the captured capacity: its logits (the forward's static outputs, still intact) once
+        more through the post-processing, eagerly, with a capacity that fits (bbox_head.get_bboxes_unbounded)"""
+        cls_preds, reg_preds = self._last_raw
+        return self.bbox_head.get_bboxes_unbounded(cls_preds[b:b + 1], reg_preds[b:b + 1], P2[b:b + 1], img_hw)
+
     @torch.no_grad()
     def test_forward_batched(self, img_batch, P2):
         if not img_batch.is_cuda:
@@ -84,7 +90,7 @@ class Yolo3D(GraphedForward, nn.Module):
         # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
         P2 = torch.as_tensor(P2).to(device=img_batch.device, dtype=torch.float32).contiguous()
         # through the hipGraph cache (lib/graphed.py); post_optimization runs inside get_bboxes_batched, i.e. inside the graph
-        return self.bbox_head.unpad(self._graphed(img_batch, P2), own=True)
+        return self.bbox_head.unpad(self._graphed(img_batch, P2), own=True, retry=lambda b: self._overflow_retry(b, P2, img_batch.shape[2:]))
 
     @torch.no_grad()
     def test_forward(self, img_batch, P2):

@@ -45,6 +45,12 @@ class Stereo3D(GraphedForward, nn.Module):
         self._last_raw = (cls_preds, reg_preds)
         return self.bbox_head.get_bboxes_batched(cls_preds, reg_preds, P2, left_images.shape[2:])
 
+    def _overflow_retry(self, b, P2, img_hw):
+        """sample b of the last forward had more candidates than the captured capacity: its logits (the forward's static outputs, still intact) once
+        more through the post-processing, eagerly, with a capacity that fits (bbox_head.get_bboxes_unbounded)"""
+        cls_preds, reg_preds = self._last_raw
+        return self.bbox_head.get_bboxes_unbounded(cls_preds[b:b + 1], reg_preds[b:b + 1], P2[b:b + 1], img_hw)
+
     @torch.no_grad()
     def test_forward_batched(self, left_images, right_images, P2, P3=None):
         """B >= 1.  Returns a list of per-sample ``(scores[N], bboxes[N,11], cls_indexes[N] int64)``.  Runs through the hipGraph
@@ -54,7 +60,8 @@ class Stereo3D(GraphedForward, nn.Module):
         # the calibration in kernel form (contiguous fp32 on the device) BEFORE the graph cache: the graph's static input is then what the
         # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
         P2 = torch.as_tensor(P2).to(device=left_images.device, dtype=torch.float32).contiguous()
-        return self.bbox_head.unpad(self._graphed(left_images, right_images, P2), own=True)
+        return self.bbox_head.unpad(self._graphed(left_images, right_images, P2), own=True,
+                                    retry=lambda b: self._overflow_retry(b, P2, left_images.shape[2:]))
 
     @torch.no_grad()
     def test_forward(self, left_images, right_images, P2, P3):

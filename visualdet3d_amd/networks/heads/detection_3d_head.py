@@ -60,7 +60,10 @@ class AnchorBasedDetection3DHead(nn.Module):
         self._cache = fused.PackCache()
         self._side_streams = {}
         self.overlap_towers = True   # False: run the towers back to back on one stream (per-kernel profiling)
-        self.max_candidates = 4096   # per-sample capacity of the device candidate list (power of two <= 8192)
+        # per-sample capacity of the device candidate list INSIDE the captured forward (a power of two; <= 8192 keeps the lists in LDS).  Not a
+        # limit of the head: a frame with more candidates is re-run off-graph with a doubled capacity (get_bboxes_unbounded) -- the reference's
+        # list has no cap (detection_3d_head.py:341-400)
+        self.max_candidates = 4096
         self._workspaces = {}        # candidate scratch per (batch size, capacity, device): never reallocated (hipGraphs bake its address)
         self._workspace = None       # the one the last call used
         self.overlap_select = True   # candidate selection (needs only the cls logits) on the cls tower's side stream, under the reg tower
@@ -252,12 +255,44 @@ class AnchorBasedDetection3DHead(nn.Module):
         ops.head_select(cls_preds, *args, **kw)
         return self._select_key(cls_preds, args, kw)
 
+    def get_bboxes_unbounded(self, cls_preds, reg_preds, P2s, img_hw, clip=True):
+        """ONE frame ([1, N, ...] logits) whose candidate list (or detection list) did not fit ``max_candidates``: the same two kernels, launched
+        eagerly with a doubled capacity until the frame fits -- at most every anchor of the frame (capacities beyond 8192 sort in global memory,
+        csrc/postprocess.hip).  The reference has no cap (boolean indexing, then nms: detection_3d_head.py:341-400), so neither has this head;
+        the capacity only bounds what a captured hipGraph handles without this detour.  -> (scores [n], boxes [n, 11], labels [n] int64), private."""
+        assert cls_preds.shape[0] == 1
+        N = int(cls_preds.shape[1])
+        dev = cls_preds.device
+        anchors, prior, A = self.anchors.device_tables(img_hw, dev)
+        lo, hi = self.anchors.filter_y_threshold_min_max
+        P2s = P2s.to(device=dev, dtype=torch.float32).contiguous()
+        limit = 1 << max(N - 1, 1).bit_length()
+        cap = int(self.max_candidates)
+        while True:
+            cap = min(cap * 2, limit)
+            padded = ops.head_postprocess(cls_preds.float().contiguous(), reg_preds.float().contiguous(), anchors, prior, P2s, A, self.num_classes,
+                                          len(self.anchors.obj_types), tuple(int(v) for v in img_hw) if clip else (0, 0),
+                                          getattr(self.test_cfg, 'score_thr', 0.5), getattr(self.test_cfg, 'nms_iou_thr', 0.5),
+                                          use_filter=bool(self._is_filtering() and self.anchors.readConfigFile), y_min_max=(lo, hi),
+                                          x_max=self.anchors.filter_x_threshold, max_cand=cap, workspace=None)
+            if getattr(self.test_cfg, 'post_optimization', False):
+                from ..lib.fast_utils.hill_climbing import post_opt_batch
+                post_opt_batch(padded[1], padded[2], P2s, counts=padded[4])
+            k = int(padded[4].item())
+            if k >= 0:
+                return padded[0][0, :k].clone(), padded[1][0, :k].clone(), padded[2][0, :k].long()
+            assert cap < limit, 'a capacity of every anchor of the frame cannot overflow'
+
     @staticmethod
-    def unpad(padded, own=False):
+    def unpad(padded, own=False, retry=None):
         """One host sync: slice the padded batch results into per-sample (scores, boxes, labels int64) tuples.
         ``own=True`` (the detectors' ``test_forward``: the padded tensors are a hipGraph's static outputs, overwritten by the next replay): the
         results are views of PRIVATE copies of the padded arrays, made BEFORE the sync -- three launches per call that the host issues while the
-        GPU still works on the forward, instead of three per SAMPLE after the sync (slices, ``.long()``, clones)."""
+        GPU still works on the forward, instead of three per SAMPLE after the sync (slices, ``.long()``, clones).  NB: the per-sample results of
+        one call are then VIEWS of one batch-wide copy (``[B, max_det, ...]``): holding one sample keeps the batch's copy alive, and
+        ``untyped_storage()`` of a sample is the whole batch -- ``.clone()`` a sample that outlives the call or crosses a process boundary.
+        ``retry(b)``: called for a sample whose candidate list overflowed the captured capacity (count < 0); returns that sample's tuple
+        (``get_bboxes_unbounded``).  Without it an overflow raises."""
         scores, boxes, labels, aidx, count = padded
         from ..lib.graphed import COPY_AFTER_SYNC, read_counts
         early = own and not COPY_AFTER_SYNC
@@ -268,8 +303,11 @@ class AnchorBasedDetection3DHead(nn.Module):
         outs = []
         for b, k in enumerate(counts):
             if k < 0:
-                raise RuntimeError('sample %d: more candidates than max_candidates (or detections than max_det); '
-                                   'raise AnchorBasedDetection3DHead.max_candidates' % b)
+                if retry is None:
+                    raise RuntimeError('sample %d: more candidates than max_candidates (or detections than max_det); '
+                                       'raise AnchorBasedDetection3DHead.max_candidates' % b)
+                outs.append(retry(b))
+                continue
             if early:                            # after the sync: three slices per sample, nothing else (this is the call's critical path)
                 s, bx, l = rows[b]
                 outs.append((s[:k], bx[:k], l[:k]))
@@ -296,9 +334,9 @@ class AnchorBasedDetection3DHead(nn.Module):
             if img_hw is None:
                 raise RuntimeError('get_bboxes(img_batch=None): image shape unknown -- call get_anchor(img_batch, P2) first '
                                    '(the reference flow, yolostereo3d_detector.py:90-93)')
-        padded = self.get_bboxes_batched(cls_scores.float().contiguous(), reg_preds.float().contiguous(), P2s, img_hw,
-                                         clip=img_batch is not None)
-        return self.unpad(padded)[0]
+        cls_scores, reg_preds = cls_scores.float().contiguous(), reg_preds.float().contiguous()
+        padded = self.get_bboxes_batched(cls_scores, reg_preds, P2s, img_hw, clip=img_batch is not None)
+        return self.unpad(padded, retry=lambda b: self.get_bboxes_unbounded(cls_scores, reg_preds, P2s, img_hw, clip=img_batch is not None))[0]
 
     def _post_process(self, scores, bboxes, labels, P2s):
         """heads/detection_3d_head.py:294-308: hill-climb the yaw of every label-0 box deeper than 3 m so that its

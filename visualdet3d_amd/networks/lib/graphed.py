@@ -60,10 +60,11 @@ def _plain(v):
 
 
 class _Entry:
-    __slots__ = ('graph', 'static_in', 'static_out', 'versions', 'eager')
+    __slots__ = ('graph', 'static_in', 'static_out', 'versions', 'eager', 'raw')
 
     def __init__(self):
         self.graph, self.static_in, self.static_out, self.versions, self.eager = None, None, None, None, False
+        self.raw = None          # the captured forward's `_last_raw` (head logits / maps among the graph's static tensors): restored on every replay
 
 
 class GraphedForward:
@@ -96,32 +97,42 @@ class GraphedForward:
     _KNOBS = (('bbox_head', ('overlap_towers', 'overlap_select', 'max_candidates', 'max_peaks', 'TOPK')), ('core', ('overlap_neck',)),
               ('bbox_head.anchors', ('filter_y_threshold_min_max', 'filter_x_threshold', 'readConfigFile')))
 
+    def _knob_objects(self):
+        objs = []
+        for path, _ in self._KNOBS:
+            obj = self
+            for part in path.split('.'):
+                obj = getattr(obj, part, None)
+            objs.append(obj)
+        return objs
+
     def _graph_knobs(self):
         """everything the launches read at call time besides inputs and weights, by value.  Runs on every call: which of the settings exist on
-        this model is found out once (a missing attribute of an nn.Module costs a raised AttributeError), afterwards it is attribute reads."""
+        this model is found out once per set of sub-module OBJECTS (a missing attribute of an nn.Module costs a raised AttributeError); the plan is
+        re-made when ``bbox_head`` / ``core`` / ``bbox_head.anchors`` is replaced (validated by identity), afterwards it is attribute reads."""
+        objs = self._knob_objects()
+        ids = tuple(map(id, objs))
         plan = self.__dict__.get('_vd3d_knob_plan')
-        if plan is None:
-            plan = []
-            for path, names in self._KNOBS:
-                obj = self
-                for part in path.split('.'):
-                    obj = getattr(obj, part, None)
+        if plan is None or plan[0] != ids:
+            pairs = []
+            for obj, (_, names) in zip(objs, self._KNOBS):
                 if obj is not None:
-                    plan += [(obj, n) for n in names if hasattr(obj, n)]
-            self.__dict__['_vd3d_knob_plan'] = plan
-        tc = getattr(self.bbox_head, 'test_cfg', None) if 'bbox_head' in self._modules else None
+                    pairs += [(obj, n) for n in names if hasattr(obj, n)]
+            plan = self.__dict__['_vd3d_knob_plan'] = (ids, pairs)
+        head = objs[0]
+        tc = getattr(head, 'test_cfg', None) if head is not None else None
         if isinstance(tc, dict):
             try:
-                tcv = (len(tc),) + tuple(map(_plain, tc.values()))
+                tcv = tuple((k, _plain(v)) for k, v in tc.items())      # keys AND values: swapping one key for another of equal value is a new key
                 hash(tcv)
             except TypeError:
                 tcv = repr(sorted(tc.items()))
         else:
             tcv = repr(tc)
-        # filter_anchor of the loss config is the eval default (detection_3d_head._is_filtering); a dict lookup, present or not
-        lc = getattr(self.bbox_head, 'loss_cfg', None) if 'bbox_head' in self._modules else None
-        fa = _plain(lc.get('filter_anchor')) if isinstance(lc, dict) else None
-        return (self.compute_dtype, self.training, _lib.hook_epoch(), tcv, fa) + tuple(_plain(getattr(o, n)) for o, n in plan)
+        # filter_anchor of the loss config is the eval default; read the way detection_3d_head._is_filtering reads it (getattr: EasyDict or namespace)
+        lc = getattr(head, 'loss_cfg', None) if head is not None else None
+        fa = _plain(getattr(lc, 'filter_anchor', None)) if lc is not None else None
+        return (self.compute_dtype, self.training, _lib.hook_epoch(), tcv, fa) + tuple(_plain(getattr(o, n)) for o, n in plan[1])
 
     def _graphed(self, *inputs):
         if not self.use_graph or torch.cuda.is_current_stream_capturing():
@@ -142,6 +153,7 @@ class GraphedForward:
             if ent.versions == tuple(map(_VERSION, st['tensors'])):
                 st['entries'].move_to_end(key)   # LRU: a hit makes the shape the most recently used
                 st['replays'] += 1
+                self._last_raw = ent.raw         # (several shapes may be cached: the raw outputs of THIS graph)
                 return ent.static_out
             torch.cuda.current_stream().synchronize()    # (the stale replay is done before its graph is dropped)
             ent = None
@@ -163,6 +175,7 @@ class GraphedForward:
             dst.copy_(src, non_blocking=True)
         ent.graph.replay()
         st['replays'] += 1
+        self._last_raw = ent.raw
         return ent.static_out
 
     def _capture(self, inputs, versions):
@@ -184,6 +197,7 @@ class GraphedForward:
                 with torch.cuda.graph(g):
                     ent.static_out = self.forward_device(*ent.static_in)
                 ent.graph = g
+                ent.raw = self.__dict__.get('_last_raw')
                 st['captures'] += 1
             except Exception as e:               # noqa: BLE001 -- the eager launches are the same kernels; say so once and carry on
                 warnings.warn('hipGraph capture of %s.forward_device failed (%s: %s); this shape runs eagerly' % (type(self).__name__, type(e).__name__, e))
