@@ -209,7 +209,7 @@ def test_cache_is_lru_and_keyed_on_the_anchor_filter():
 
 
 def test_candidate_overflow_inside_a_replayed_graph_is_rerun_off_graph():
-    """More candidates than the captured capacity (here: `max_candidates` lowered to 16 so that the golden workload overflows) must not be an
+    """More candidates than the captured capacity (here: `max_candidates` lowered to 1 so that the golden workload overflows) must not be an
     error: the frame is re-run eagerly on the graph's own logits with a capacity that fits (detectors `_overflow_retry`), in the first (capturing)
     call, in a replay, and for one frame of a batched call -- results equal the uncapped ones bit for bit (same kernels, same arithmetic);
     and the test_cfg fingerprint of the graph key sees a key swapped for another of equal value."""
@@ -217,8 +217,8 @@ def test_candidate_overflow_inside_a_replayed_graph_is_rerun_off_graph():
     x = [L[:1], R[:1], P2[:1], P3[:1]]
     want = m(x)
     want_b = m.test_forward_batched(L, R, P2, P3)
-    assert want[0].numel() > 16
-    m.bbox_head.max_candidates = 16
+    assert want[0].numel() >= 2                 # >= 2 detections => >= 2 candidates: a capacity of ONE must overflow
+    m.bbox_head.max_candidates = 1
     got = m(x)                                  # captures a new graph (the capacity is part of the key) whose count is -1, then retries
     assert _same(got, want)
     got = m(x)                                  # replay + retry
