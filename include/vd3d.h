@@ -341,6 +341,16 @@ int vd3d_kitti_postpath(const float* boxes, const int32_t* counts, const float* 
 int vd3d_conv2d_pair(const vd3d_conv_params* a, const vd3d_conv_params* b, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * ABI >= 6.  A whole ResNet Bottleneck of the 64-wide stage in one launch (backbones/resnet.py:55-91 `Bottleneck.forward`: conv1 1x1 + bn1 + relu ->
+ * conv2 3x3 + bn2 + relu -> conv3 1x1 + bn3, + identity | downsample(x), relu; ResNet-50 / 101 / 152 layer1).  c1 / c2 / c3 / ds are the
+ * vd3d_conv2d_igemm parameter blocks of the three convolutions and of the stage's first block's 1x1 downsample conv (NULL for an identity block,
+ * whose c3->residual must be c1->in): 16-bit formats, conv1 256 | 64 -> 64, conv2 64 -> 64, conv3 (and ds) 64 -> 256, stride 1.  c1->in is the
+ * block's input, c3->out its output; every other in / out pointer is ignored -- both 64-channel intermediates live in LDS only (rounded to the storage
+ * type exactly where the separate launches round them).  Other shapes: VD3D_EINVAL (the caller launches the convolutions separately). */
+int vd3d_conv2d_bottleneck(const vd3d_conv_params* c1, const vd3d_conv_params* c2, const vd3d_conv_params* c3, const vd3d_conv_params* ds,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * KM3D head, fused (heads/km3d_head.py:132-153,353-357: nine branches conv3x3(64 -> 256) + ReLU + conv1x1(256 -> n_h)).  The nine
  * 3x3 convs run as ONE implicit GEMM with Cout = 256 x heads (`p`: the vd3d_conv2d_igemm parameters of that conv, bf16,
  * shift = the concatenated first-conv biases, relu implied, `p->out` ignored); each 256-pixel x 256-channel tile applies bias +

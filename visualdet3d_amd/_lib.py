@@ -25,7 +25,7 @@ if _NAME != 'libvd3d_hip.so':
 VD3D_BF16 = 0
 VD3D_F32 = 1
 VD3D_F16 = 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -128,6 +128,7 @@ SIGNATURES = {
     'vd3d_preprocess_image': (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'vd3d_rotate_iou_eval': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     'vd3d_conv2d_pair': (c_int, [C.POINTER(ConvParams), C.POINTER(ConvParams), c_void_p]),
+    'vd3d_conv2d_bottleneck': (c_int, [C.POINTER(ConvParams), C.POINTER(ConvParams), C.POINTER(ConvParams), C.POINTER(ConvParams), c_void_p]),
     'vd3d_km3d_head_fused': (c_int, [C.POINTER(ConvParams), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'vd3d_post_opt': (c_int, [c_void_p] * 4 + [c_int, c_int] + [c_float] * 3 + [c_int, c_void_p]),
 }

@@ -83,7 +83,7 @@ int vd3d_raise_lds_limit(const void* kern, int bytes, Vd3dLdsLimit& state, const
     return VD3D_OK;
 }
 
-extern "C" int vd3d_abi_version(void) { return 5; }
+extern "C" int vd3d_abi_version(void) { return 6; }
 extern "C" const char* vd3d_last_error(void) { return g_err; }
 #ifndef VD3D_SRC_HASH
 #define VD3D_SRC_HASH "unstamped"

@@ -58,6 +58,10 @@ bool narrow_shape_ok(const ConvArgs& a);                               // 3x3 / 
 int launch_narrow(ConvArgs& a, hipStream_t stream, int fmt);          // narrow-output streaming kernel (chunked small-channel kernel)
 bool pair_shape_ok(const ConvArgs& a, const ConvArgs& b);               // conv A 3x3 / s1 16 -> 16, conv B 3x3 / s2 16 -> <= 32, 16-bit
 int launch_pair(ConvArgs& a, ConvArgs& b, hipStream_t stream, int fmt);   // DLA level0 + level1 in one launch
+// a whole ResNet Bottleneck of the 64-wide stage in one launch (conv_bottleneck.hip): c1 1x1 (256 | 64 -> 64), c2 3x3 (64 -> 64), c3 1x1 (64 -> 256),
+// cd = the 1x1 downsample conv (64 -> 256) of the stage's first block or nullptr (identity block: c3.residual == c1.in)
+bool bottleneck_shape_ok(const ConvArgs& c1, const ConvArgs& c2, const ConvArgs& c3, const ConvArgs* cd);
+int launch_bottleneck(ConvArgs& c1, ConvArgs& c2, ConvArgs& c3, ConvArgs* cd, hipStream_t stream, int fmt);
 bool km3d_head_shape_ok(const ConvArgs& a);                            // 3x3 / s1 / p1, Cin % 64 == 0, Cout = 256 x branches (h_* fields set)
 int launch_km3d_head(ConvArgs& a, hipStream_t stream, int fmt);       // persistent fused KM3D head (km3d_head_conv.hip)
 bool pw_shape_ok(const ConvArgs& a);                                   // 1x1 / stride 1, Cin 64 | 128 | 256, Cout % 256 == 0, weight_frag given

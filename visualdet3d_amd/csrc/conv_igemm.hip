@@ -1863,6 +1863,34 @@ extern "C" int vd3d_conv2d_pair(const vd3d_conv_params* pa, const vd3d_conv_para
     return launch_pair(a, b, (hipStream_t)stream, pa->dtype);
 }
 
+extern "C" int vd3d_conv2d_bottleneck(const vd3d_conv_params* p1, const vd3d_conv_params* p2, const vd3d_conv_params* p3, const vd3d_conv_params* pd,
+                                      void* stream) {
+    if (!p1 || !p2 || !p3) { vd3d_set_error("conv2d_bottleneck: null pointer"); return VD3D_EINVAL; }
+    if ((p1->dtype != VD3D_BF16 && p1->dtype != VD3D_F16) || p2->dtype != p1->dtype || p3->dtype != p1->dtype || (pd && pd->dtype != p1->dtype)) {
+        vd3d_set_error("conv2d_bottleneck: every conv in the same 16-bit format");
+        return VD3D_EINVAL;
+    }
+    // the intermediates exist in LDS only: conv1.out / conv2.in / conv2.out / conv3.in (and the downsample conv's out) are ignored
+    vd3d_conv_params q1 = *p1, q2 = *p2, q3 = *p3, qd = pd ? *pd : *p3;
+    const int64_t mid_bytes = (int64_t)p2->B * p2->H * p2->W * p2->Cin * 2;
+    q1.out = p3->out; q1.out_pix_stride = p1->Cout;
+    q2.in = p1->in; q2.in_pix_stride = p2->Cin; q2.in_row_stride = p2->W * p2->Cin; q2.in_batch_stride = (int64_t)p2->H * p2->W * p2->Cin; q2.in_bytes = mid_bytes;
+    q2.out = p3->out; q2.out_pix_stride = p2->Cout;
+    q3.in = p1->in; q3.in_pix_stride = p3->Cin; q3.in_row_stride = p3->W * p3->Cin; q3.in_batch_stride = (int64_t)p3->H * p3->W * p3->Cin; q3.in_bytes = mid_bytes;
+    if (pd) { qd.out = p3->out; qd.out_pix_stride = pd->Cout; }
+    ConvArgs a1, a2, a3, ad;
+    if (const int rc = fill_conv_args(&q1, a1)) return rc;
+    if (const int rc = fill_conv_args(&q2, a2)) return rc;
+    if (const int rc = fill_conv_args(&q3, a3)) return rc;
+    if (pd) { if (const int rc = fill_conv_args(&qd, ad)) return rc; }
+    if (!bottleneck_shape_ok(a1, a2, a3, pd ? &ad : nullptr)) {
+        vd3d_set_error("conv2d_bottleneck: needs conv1 1x1 256 | 64 -> 64 + relu, conv2 3x3/s1/p1 64 -> 64 + relu, conv3 1x1 64 -> 256 with residual = conv1's "
+                       "(dense) input, or with the 1x1 64 -> 256 downsample conv of the same input; 16-bit");
+        return VD3D_EINVAL;
+    }
+    return launch_bottleneck(a1, a2, a3, pd ? &ad : nullptr, (hipStream_t)stream, p1->dtype);
+}
+
 extern "C" int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_packed, const float* b2, void* const* outs,
                                     const int32_t* n_out, int n_heads, void* stream) {
     if (!p || !w2_packed || !b2 || !outs || !n_out) { vd3d_set_error("km3d_head_fused: null pointer"); return VD3D_EINVAL; }

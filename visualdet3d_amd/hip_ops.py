@@ -240,6 +240,51 @@ def conv2d_pair(x, pc_a, pc_b, relu_a=True, relu_b=True):
     return out
 
 
+def conv2d_bottleneck_supported(x, pc1, pc2, pc3, pc_ds=None):
+    """shapes vd3d_conv2d_bottleneck takes: the 64-wide Bottleneck (ResNet-50 / 101 / 152 layer1) on a dense 16-bit NHWC input."""
+    k = lambda pc: (pc.kh, pc.kw, pc.stride, pc.pad, pc.dil)
+    cin = 64 if pc_ds is not None else 256
+    return (is16(x.dtype) and x.is_contiguous() and x.shape[3] == cin and pc1.dtype == pc2.dtype == pc3.dtype == x.dtype and
+            k(pc1) == (1, 1, 1, 0, 1) and k(pc2) == (3, 3, 1, 1, 1) and k(pc3) == (1, 1, 1, 0, 1) and
+            (pc1.Cin, pc1.Cout, pc2.Cin, pc2.Cout, pc3.Cin, pc3.Cout) == (cin, 64, 64, 64, 64, 256) and
+            (pc_ds is None or (k(pc_ds) == (1, 1, 1, 0, 1) and (pc_ds.Cin, pc_ds.Cout) == (64, 256) and pc_ds.dtype == x.dtype)) and
+            x.numel() * x.element_size() <= _MAX_IN_BYTES and x.shape[0] * x.shape[1] * x.shape[2] * 256 * 2 <= _MAX_IN_BYTES)
+
+
+def conv2d_bottleneck(x, pc1, pc2, pc3, pc_ds=None, out=None):
+    """A whole ResNet Bottleneck in ONE launch (vd3d_conv2d_bottleneck): relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + identity), identity = x
+    (``pc_ds`` None) or bn(downsample 1x1 (x)).  Both 64-channel intermediates stay in LDS; rounding points are those of the separate launches."""
+    _require_cuda(x, pc1.w, pc2.w, pc3.w, out)
+    B, H, W, Cx = x.shape
+    assert conv2d_bottleneck_supported(x, pc1, pc2, pc3, pc_ds)
+    if out is None:
+        out = torch.empty((B, H, W, 256), dtype=x.dtype, device=x.device)
+    assert out.shape == (B, H, W, 256) and out.dtype == x.dtype and _dense_pixels(out)
+
+    def params(pc, relu, residual=None):
+        p = ConvParams()
+        p.in_, p.weight, p.out = x.data_ptr(), pc.w.data_ptr(), out.data_ptr()
+        p.scale = pc.scale.data_ptr() if pc.scale is not None else None
+        p.shift = pc.shift.data_ptr() if pc.shift is not None else None
+        p.B, p.H, p.W, p.Cin = B, H, W, pc.Cin
+        p.in_pix_stride, p.in_row_stride, p.in_batch_stride = Cx, W * Cx, H * W * Cx
+        p.in_bytes = x.numel() * x.element_size()
+        p.Ho, p.Wo, p.Cout = H, W, pc.Cout
+        p.out_pix_stride = out.stride(2)
+        p.kh, p.kw, p.stride, p.pad, p.dil = pc.kh, pc.kw, pc.stride, pc.pad, pc.dil
+        p.Kpad, p.CoutPad, p.relu = pc.Kpad, pc.CoutPad, int(relu)
+        p.dtype, p.out_f32 = dtype_code(x.dtype), 0
+        if residual is not None:
+            p.residual, p.res_pix_stride = residual.data_ptr(), residual.stride(2)
+        return p
+
+    p1, p2, p3 = params(pc1, True), params(pc2, True), params(pc3, True, None if pc_ds is not None else x)
+    pd = params(pc_ds, False) if pc_ds is not None else None
+    check(_lib.lib().vd3d_conv2d_bottleneck(C.byref(p1), C.byref(p2), C.byref(p3), C.byref(pd) if pd is not None else None, _stream()),
+          'vd3d_conv2d_bottleneck')
+    return out
+
+
 def conv2d_pair_supported(pc_a, pc_b):
     k = lambda pc: (pc.kh, pc.kw, pc.pad, pc.dil)
     return (is16(pc_a.dtype) and pc_a.dtype == pc_b.dtype and k(pc_a) == k(pc_b) == (3, 3, 1, 1) and pc_a.stride == 1 and pc_b.stride == 2 and

@@ -6,6 +6,8 @@ names (backbones/resnet.py:95-198,255-270), executed as fused implicit-GEMM HIP 
   7x7/s2 stem                             -> NHWC4 image pack + implicit GEMM over (7 rows x 32 elements)
 
 Inference only (eval-mode BN); the reference's freeze_stages / norm_eval only affect ``train()`` there."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -67,14 +69,23 @@ class Bottleneck(nn.Module):
         self.stride = stride
         self._cache = fused.PackCache()
 
+    fuse_block = not os.environ.get('VD3D_NO_BLOCK_FUSION')    # the 64-wide stage (layer1) as ONE launch per block (vd3d_conv2d_bottleneck); False: the separate launches (A/B, tests)
+
     def forward_nhwc(self, x, out=None):
         dt = x.dtype
-        y = ops.conv2d(x, _conv_bn(self._cache, 'c1', self.conv1, self.bn1, dt), relu=True)
-        y = ops.conv2d(y, _conv_bn(self._cache, 'c2', self.conv2, self.bn2, dt), relu=True)
+        pc1 = _conv_bn(self._cache, 'c1', self.conv1, self.bn1, dt)
+        pc2 = _conv_bn(self._cache, 'c2', self.conv2, self.bn2, dt)
+        pc3 = _conv_bn(self._cache, 'c3', self.conv3, self.bn3, dt)
+        pcd = _conv_bn(self._cache, 'ds', self.downsample[0], self.downsample[1], dt) if self.downsample is not None else None
+        if self.fuse_block and ops.conv2d_bottleneck_supported(x, pc1, pc2, pc3, pcd):
+            # x read once (+ halo), the output written once, both 64-channel intermediates in LDS (csrc/conv_bottleneck.hip)
+            return ops.conv2d_bottleneck(x, pc1, pc2, pc3, pcd, out=out)
+        y = ops.conv2d(x, pc1, relu=True)
+        y = ops.conv2d(y, pc2, relu=True)
         res = x
-        if self.downsample is not None:
-            res = ops.conv2d(x, _conv_bn(self._cache, 'ds', self.downsample[0], self.downsample[1], dt), relu=False)
-        return ops.conv2d(y, _conv_bn(self._cache, 'c3', self.conv3, self.bn3, dt), out=out, residual=res, relu=True)
+        if pcd is not None:
+            res = ops.conv2d(x, pcd, relu=False)
+        return ops.conv2d(y, pc3, out=out, residual=res, relu=True)
 
     def forward(self, x):
         return fused.to_nchw(self.forward_nhwc(fused.to_nhwc(x)))
