@@ -238,38 +238,39 @@ __global__ void __launch_bounds__(256, 2) bottleneck64_kernel(const ConvArgs c1,
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // ---- conv3 (+ downsample conv) per pixel block, epilogue: bn3 + residual + relu -> 2 x 16-byte stores per lane ----------------------
+        // operands of row y + 1 (t2 fragments, residual / x fragments) are requested before row y's epilogue
         BN_OPAQUE();
-#pragma unroll 1
-        for (int y = 0; y < 8; ++y) {
-            const int oy = ty * kBnTH + y, ox = tx * kBnTW + pxv;
-            const bool pin = oy < H && ox < W;
-            const int64_t m = pin ? ((int64_t)b * H + oy) * W + ox : 0;
-            i32x4 rr[2];
-            if constexpr (!DS) {
-                const char* rp = c3.residual + (m * c3.res_pix_stride + 64 * wave + 8 * gv) * 2;
-                rr[0] = *(const i32x4*)rp;
-                rr[1] = *(const i32x4*)(rp + 64);
-            }
-            f32x4 a3[4], ad[4];
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) a3[cb] = ad[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-            {
-                const i32x4 b0 = frag(kBnT1, 16 * y + pxv, 0), b1 = frag(kBnT1, 16 * y + pxv, 1);
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    Fmt16<T>::mfma16(w3[2 * cb], b0, a3[cb]);
-                    Fmt16<T>::mfma16(w3[2 * cb + 1], b1, a3[cb]);
-                }
-            }
+        const int64_t m00 = ((int64_t)b * H + ty * kBnTH) * W + tx * kBnTW + pxv;       // the lane's pixel of tile row 0
+        const bool xin = tx * kBnTW + pxv < W;
+        i32x4 bq[2][2], xq[2][2];
+        auto ld3 = [&](int y, i32x4* b2, i32x4* x2) {
+            b2[0] = frag(kBnT1, 16 * y + pxv, 0);
+            b2[1] = frag(kBnT1, 16 * y + pxv, 1);
             if constexpr (DS) {
                 const int row = (y + 1) * kBnHW + 1 + pxv;
-                const i32x4 b0 = frag(par * kBnImg, row, 0), b1 = frag(par * kBnImg, row, 1);
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    Fmt16<T>::mfma16(wd[2 * cb], b0, ad[cb]);
-                    Fmt16<T>::mfma16(wd[2 * cb + 1], b1, ad[cb]);
-                }
+                x2[0] = frag(par * kBnImg, row, 0);
+                x2[1] = frag(par * kBnImg, row, 1);
+            } else {
+                const bool pin = xin && ty * kBnTH + y < H;
+                const char* rp = c3.residual + ((pin ? m00 + (int64_t)y * W : 0) * c3.res_pix_stride + 64 * wave + 8 * gv) * 2;
+                x2[0] = *(const i32x4*)rp;
+                x2[1] = *(const i32x4*)(rp + 64);
             }
+        };
+        auto row3 = [&](int y, const i32x4* b2, const i32x4* x2) {
+            const bool pin = xin && ty * kBnTH + y < H;
+            f32x4 a3[4], ad[4];
+            auto mm = [&](int cb) {
+                a3[cb] = ad[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Fmt16<T>::mfma16(w3[2 * cb], b2[0], a3[cb]);
+                Fmt16<T>::mfma16(w3[2 * cb + 1], b2[1], a3[cb]);
+                if constexpr (DS) {
+                    Fmt16<T>::mfma16(wd[2 * cb], x2[0], ad[cb]);
+                    Fmt16<T>::mfma16(wd[2 * cb + 1], x2[1], ad[cb]);
+                }
+            };
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) mm(cb);
             i32x4 o2[2];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
@@ -283,24 +284,30 @@ __global__ void __launch_bounds__(256, 2) bottleneck64_kernel(const ConvArgs c1,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += Fmt16<T>::tof(Fmt16<T>::one(ad[cb][r] * dsc[r] + dsh[r]));     // the branch is a stored tensor in the unfused path: rounded once
                 } else {
-                    const uint32_t r0 = (uint32_t)(int)rr[cb >> 1][2 * (cb & 1)], r1 = (uint32_t)(int)rr[cb >> 1][2 * (cb & 1) + 1];
+                    const uint32_t r0 = (uint32_t)(int)x2[cb >> 1][2 * (cb & 1)], r1 = (uint32_t)(int)x2[cb >> 1][2 * (cb & 1) + 1];
                     v[0] += Fmt16<T>::lo(r0);
                     v[1] += Fmt16<T>::hi(r0);
                     v[2] += Fmt16<T>::lo(r1);
                     v[3] += Fmt16<T>::hi(r1);
                 }
-                if (c3.relu) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-                }
-                o2[cb >> 1][2 * (cb & 1)] = Fmt16<T>::pack2(v[0], v[1]);
-                o2[cb >> 1][2 * (cb & 1) + 1] = Fmt16<T>::pack2(v[2], v[3]);
+                // ReLU on the packed pair (one v_pk_max_i16 per two values; relu(round(x)) == round(relu(x)))
+                const int floor16 = c3.relu ? 0 : (int)0x80008000u;
+                o2[cb >> 1][2 * (cb & 1)] = max_pk16(Fmt16<T>::pack2(v[0], v[1]), floor16);
+                o2[cb >> 1][2 * (cb & 1) + 1] = max_pk16(Fmt16<T>::pack2(v[2], v[3]), floor16);
             }
             if (pin) {
-                char* op = c3.out + (m * c3.out_pix_stride + 64 * wave + 8 * gv) * 2;
+                char* op = c3.out + ((m00 + (int64_t)y * W) * c3.out_pix_stride + 64 * wave + 8 * gv) * 2;
                 *(i32x4*)op = o2[0];
                 *(i32x4*)(op + 64) = o2[1];
             }
+        };
+        ld3(0, bq[0], xq[0]);
+#pragma unroll 1
+        for (int y = 0; y < 8; y += 2) {
+            ld3(y + 1, bq[1], xq[1]);
+            row3(y, bq[0], xq[0]);
+            if (y + 2 < 8) ld3(y + 2, bq[0], xq[0]);
+            row3(y + 1, bq[1], xq[1]);
         }
         par ^= 1;
     }
