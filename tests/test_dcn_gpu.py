@@ -267,43 +267,6 @@ def test_64_to_64_kernel_views_layouts_and_oracle(dtype, B, H, W, sigma):
     assert ((got - want).abs().max() / want.abs().max()).item() < (2e-2 if dtype == torch.bfloat16 else 2.5e-3)
 
 
-@pytest.mark.parametrize('C,O,B,H,W', [(64, 64, 2, 21, 37), (128, 128, 1, 16, 24), (256, 64, 1, 9, 13)])
-def test_opt_in_packed_fp16_blend(C, O, B, H, W):
-    """VD3D_DCN_PK16=1 (fp16 only, NOT the default): the four-corner blend on v_pk_fma_f16 with the modulated weights rounded to fp16 --
-    what the reference's own half instantiation does (deform_conv_cuda_kernel.cu:467-497 in scalar_t = half), 2 x fewer VALU
-    instructions.  Three more fp16 roundings than the default fp32 blend: held to 4 fp16 ulp of the default kernel's output (+ 1e-3 of
-    the scale for the 9 C-long sum of moved products) and to the oracle bar of the engine-path test."""
-    from visualdet3d_amd import _lib, hip_ops as ops
-    g = torch.Generator().manual_seed(C + H)
-    dtype = torch.float16
-    x = torch.randn(B, H, W, C, generator=g)
-    wt = torch.randn(O, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
-    off = torch.randn(B, H, W, 18, generator=g) * 1.2
-    msk = torch.randn(B, H, W, 9, generator=g) * 2.0
-    bias = torch.randn(O, generator=g) * 0.1
-    xd = x.cuda().to(dtype)
-    pd = ops.pack_dcn_weight(wt.cuda(), dtype)
-    logits = torch.cat([off, msk, torch.zeros(B, H, W, 5)], dim=3).cuda()
-    kw = dict(bias=bias.cuda(), stride=(1, 1), padding=(1, 1), dilation=(1, 1), mask_sigmoid=True, relu=False)
-
-    def run():
-        return ops.deform_conv_general(xd, pd, logits[..., :18], logits[..., 18:27], torch.empty((B, H, W, O), dtype=dtype, device='cuda'), 'nhwc', **kw)
-
-    base = run()
-    with _lib.test_switch('VD3D_DCN_PK16'):
-        pk = run()
-    torch.cuda.synchronize()
-    assert not torch.equal(pk, base), 'the switch selected nothing'
-    d = (pk.float() - base.float()).abs()
-    sc = base.float().abs().max()
-    assert bool((d <= base.float().abs() * (4 * 2.0 ** -10) + 1e-3 * sc).all()), 'max diff %.3e of scale %.3e' % (d.max().item(), sc.item())
-    rnd = lambda t: t.to(dtype).float()                             # noqa: E731
-    want = dcn_ref.deform_conv_forward(rnd(x).permute(0, 3, 1, 2), off.permute(0, 3, 1, 2), torch.sigmoid(msk).permute(0, 3, 1, 2), wt, bias,
-                                       1, 1, 1, 1, 1, rnd=rnd)
-    got = pk.float().cpu().permute(0, 3, 1, 2)
-    assert ((got - want).abs().max() / want.abs().max()).item() < 2.5e-3
-
-
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('C,O,B,H,W', [(64, 64, 2, 21, 37), (128, 64, 1, 16, 24), (256, 256, 1, 9, 13), (64, 128, 2, 8, 8)])
 def test_logit_staging_of_the_gather_kernel_is_bit_identical(dtype, C, O, B, H, W):

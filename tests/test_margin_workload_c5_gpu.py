@@ -216,8 +216,13 @@ def controlled_state_dict(sd, offset_scale):
     return out
 
 
-def build_case(N=2, H=512, W=1760, offset_scale=1.0 / 256):
-    """-> everything the test (and the CPU dry run of the design) needs; the oracle runs here (twice: the frames and their perturbed twin)."""
+_PASS1 = {}
+LIVE_JOINTS = (8, 0, 1)         # key point heat-map channels with live peaks in the `live_hp` variant: the centre point (snaps), a near corner (regressed ~9.5 px off: snaps or not by the box size), a far corner (~24 px: refused by the distance term)
+
+
+def build_case(N=2, H=512, W=1760, offset_scale=1.0 / 256, live_hp=False):
+    """-> everything the test (and the CPU dry run of the design) needs; the oracle runs here (twice: the frames and their perturbed twin).
+    ``live_hp``: the keypoint heat map carries live peaks (see test_config5_..._live_keypoint_heat_map)."""
     from visualdet3d_amd.networks.utils.registry import DETECTOR_DICT
     import visualdet3d_amd.networks.detectors  # noqa: F401
     from visualdet3d_amd.utils import synthetic as syn
@@ -237,8 +242,10 @@ def build_case(N=2, H=512, W=1760, offset_scale=1.0 / 256):
         return {t['key']: t for t in taps if t['kind'] == 'conv'}, [t['logits'][:, :18] for t in taps if t['kind'] == 'dcn']
 
     # pass 1: the oracle up to the hidden features of the nine head branches (their LAST convs do not feed back), and its twin
-    convs, offs = run(img)
-    twin, _ = run(img * (1 + 1e-6 * torch.randn(img.shape, generator=torch.Generator().manual_seed(5))))
+    key1 = (N, H, W, offset_scale)
+    if key1 not in _PASS1:                                                   # (shared by the two tests of this file: two minutes of host time)
+        _PASS1[key1] = (run(img), run(img * (1 + 1e-6 * torch.randn(img.shape, generator=torch.Generator().manual_seed(5)))))
+    (convs, offs), (twin, _) = _PASS1[key1]
     off_rms = max(o.pow(2).mean().sqrt().item() for o in offs)
     off_max = max(o.abs().max().item() for o in offs)
     hid = convs[p + 'hm.2']['x']
@@ -277,6 +284,22 @@ def build_case(N=2, H=512, W=1760, offset_scale=1.0 / 256):
     design['wh'] = best_wh
     sd2[p + 'hm_hp.2.weight'] = torch.zeros_like(sd[p + 'hm_hp.2.weight'])
     sd2[p + 'hm_hp.2.bias'] = torch.full_like(sd[p + 'hm_hp.2.bias'], -9.0)
+    hidden_of = {h: p + h + '.2' for h in orc.KM3D_HEADS}
+    if live_hp:
+        # The keypoint branch shares the heat-map branch's FIRST conv (identical hidden features in both implementations), and its channels LIVE_JOINTS
+        # are the class-0 logit moved so that the decode's 0.1 falls where the class threshold 0.3 falls: hm_hp[j] = hm[0] + logit(0.1) - logit(0.3).
+        # Their peaks above 0.1 are then exactly the class-0 peaks above 0.3 -- every margin of the heat-map design carries over -- and sit on the object
+        # centres: the centre key point (joint 8, regressed offset ~0) snaps to them, a far corner (joint 1, regressed ~24 px away) is refused by the
+        # distance term of the six-term mask (km3d_head.py:236-238).  hp_offset: the seeded conv x 1/16 + a constant sub-pixel shift, like `reg`.
+        for leaf in ('0.weight', '0.bias'):
+            sd2[p + 'hm_hp.' + leaf] = sd[p + 'hm.' + leaf].clone()
+        hidden_of['hm_hp'] = p + 'hm.2'
+        shift = math.log(0.1 / 0.9) - _thr_logit()
+        for j in LIVE_JOINTS:
+            sd2[p + 'hm_hp.2.weight'][j] = w_hm[0]
+            sd2[p + 'hm_hp.2.bias'][j] = b_hm[0] + shift
+        sd2[p + 'hp_offset.2.weight'] = sd[p + 'hp_offset.2.weight'] * 0.0625
+        sd2[p + 'hp_offset.2.bias'] = torch.tensor([0.25, 0.4])
     for h, bias in car.items():
         sd2[p + h + '.2.weight'] = sd[p + h + '.2.weight'] * 0.0625
         sd2[p + h + '.2.bias'] = bias.clone()
@@ -284,9 +307,9 @@ def build_case(N=2, H=512, W=1760, offset_scale=1.0 / 256):
     out = {}
     with torch.no_grad():
         for h in orc.KM3D_HEADS:
-            out[h] = F.conv2d(convs[p + h + '.2']['x'], orc.fp16_round(sd2[p + h + '.2.weight']), sd2[p + h + '.2.bias'])
+            out[h] = F.conv2d(convs[hidden_of[h]]['x'], orc.fp16_round(sd2[p + h + '.2.weight']), sd2[p + h + '.2.bias'])
         dets = orc.km3d_get_bboxes(out, P2, (H, W), THR, 0.5, const=sd.get('bbox_head.const'))
-    return dict(cfg=cfg, model=m, sd=sd2, img=img, P2=P2, maps=out, dets=dets, design=design, off_rms=off_rms, off_max=off_max, N=N, H=H, W=W)
+    return dict(cfg=cfg, model=m, sd=sd2, img=img, P2=P2, maps=out, dets=dets, design=design, off_rms=off_rms, off_max=off_max, N=N, H=H, W=W, live_hp=live_hp)
 
 
 def oracle_side_margins(case, noise, iou_thr=0.5):
@@ -306,7 +329,8 @@ def oracle_side_margins(case, noise, iou_thr=0.5):
         assert tm > MARGIN * noise[c], 'class %d: a local maximum sits %.3e from the threshold (noise %.3e)' % (c, tm, noise[c])
         assert lg.max().item() < TOP_LOGIT + 1.0, 'class %d: strongest logit %.2f would saturate the sigmoid' % (c, lg.max().item())
         n_peaks.append([int(((lg[b] > nb[b]) & (lg[b] > thr_l)).sum()) for b in range(N)])
-    assert hm[:, 2:].max().item() < -5 and maps['hm_hp'].max().item() < -5
+    dead = [j for j in range(9) if not (case.get('live_hp') and j in LIVE_JOINTS)]
+    assert hm[:, 2:].max().item() < -5 and maps['hm_hp'][:, dead].max().item() < -5
     per_frame = [sum(n_peaks[c][b] for c in range(len(n_peaks))) for b in range(N)]
     assert max(per_frame) < 100, 'more peaks than the top-K keeps: %s' % per_frame
     # NMS: the outcome must be out of reach of the noise (see nms_stability), and the rotation-bin decision of every detection too
@@ -338,9 +362,59 @@ def oracle_side_margins(case, noise, iou_thr=0.5):
     return dict(peaks=n_peaks, pairs=n_pairs, suppressions=n_sup, nms_stability=stab)
 
 
+def keypoint_margins(case, pos_noise):
+    """`live_hp`: every decision of the key point <-> heat-map association (km3d_head.py:205-244) for every candidate above the class threshold, on the
+    ORACLE's maps: which live peak is nearest, and each of the six terms of the reject mask, against `pos_noise` (feature pixels).  -> (snapped, refused by
+    distance) counts per frame; asserts the margins."""
+    maps, N = case['maps'], case['N']
+    hm = maps['hm']
+    Wm = hm.shape[3]
+    snapped, refused = [0] * N, [0] * N
+    for b in range(N):
+        heat = torch.sigmoid(hm[b])
+        pk = torch.nonzero((heat == F.max_pool2d(heat[None], 3, 1, 1)[0]) & (heat > THR))      # candidates (class, y, x) above the class threshold
+        ind = pk[:, 1] * Wm + pk[:, 2]
+        reg = maps['reg'][b].reshape(2, -1)[:, ind].t()
+        wh = maps['wh'][b].reshape(2, -1)[:, ind].t()
+        cx, cy = pk[:, 2].float() + reg[:, 0], pk[:, 1].float() + reg[:, 1]
+        l_, t_, r_, b_ = cx - wh[:, 0] / 2, cy - wh[:, 1] / 2, cx + wh[:, 0] / 2, cy + wh[:, 1] / 2
+        lim = torch.maximum(b_ - t_, r_ - l_) * 0.3
+        hps = maps['hps'][b].reshape(18, -1)[:, ind].t()
+        for j in LIVE_JOINTS:
+            hh = torch.sigmoid(maps['hm_hp'][b, j])
+            hp = torch.nonzero((hh == F.max_pool2d(hh[None, None], 3, 1, 1)[0, 0]) & (hh > 0.1))  # live peaks (y, x): the designed class-0 peaks
+            assert len(hp) >= 1 and len(hp) < 100
+            hi = hp[:, 0] * Wm + hp[:, 1]
+            off = maps['hp_offset'][b].reshape(2, -1)[:, hi].t()
+            hx, hy = hp[:, 1].float() + off[:, 0], hp[:, 0].float() + off[:, 1]
+            kx, ky = pk[:, 2].float() + hps[:, 2 * j], pk[:, 1].float() + hps[:, 2 * j + 1]     # regressed key point j of every candidate
+            d = ((kx[:, None] - hx[None]) ** 2 + (ky[:, None] - hy[None]) ** 2).sqrt()
+            ds, order = d.sort(dim=1)
+            if d.shape[1] > 1:
+                assert (ds[:, 1] - ds[:, 0]).min().item() > MARGIN * pos_noise, 'joint %d: two live peaks at nearly the same distance of a regressed key point' % j
+            sx, sy, dmin = hx[order[:, 0]], hy[order[:, 0]], ds[:, 0]
+            terms = torch.stack([sx - l_, r_ - sx, sy - t_, b_ - sy, lim - dmin], 1)             # each > 0 <=> that reject term is false
+            assert terms.abs().min().item() > MARGIN * pos_noise, 'joint %d: a term of the reject mask within %.3e px of flipping' % (j, terms.abs().min().item())
+            ok = (terms > 0).all(dim=1)
+            snapped[b] += int(ok.sum())
+            refused[b] += int((terms[:, 4] < 0).sum())
+    return snapped, refused
+
+
+def test_config5_km3d_fp16_batch16_live_keypoint_heat_map_snaps_identically():
+    """The association branch in the timed type at the timed size (VERDICT r5 missing #3): the same margin-controlled workload with LIVE peaks in the key point
+    heat map -- the centre key point of every detection snaps to a heat-map peak, a corner key point is refused by the distance term -- and the
+    detection set, every box field (the 3-D position is the least squares over the nine key points, snapped ones included) and every score still
+    meet the literal bar in all 8 replicas of the two oracle frames."""
+    _run_margin_case(build_case(2, live_hp=True))
+
+
 def test_config5_km3d_fp16_batch16_margin_controlled_detection_set_is_identical():
-    N, REP = 2, 8
-    case = build_case(N)
+    _run_margin_case(build_case(2))
+
+
+def _run_margin_case(case):
+    N, REP = case['N'], 8
     m, sd, cfg, H, W = case['model'], case['sd'], case['cfg'], case['H'], case['W']
     print('\n[margin workload C5] DCN offsets (16 blocks): worst rms %.3f px, max %.2f px' % (case['off_rms'], case['off_max']))
     assert case['off_max'] < 1.0, 'offsets are meant to be sub-pixel'
@@ -402,3 +476,14 @@ def test_config5_km3d_fp16_batch16_margin_controlled_detection_set_is_identical(
           'worst box field %.2e of its scale, worst score difference %.2e' % (n_det, N, REP, worst_f, worst_s))
     assert n_det >= 2 * N and summary['suppressions'] >= 3, 'workload must exercise the peak selection and NMS'
     assert worst_f <= 1e-3 and worst_s <= 1e-3
+    if case['live_hp']:
+        # positions entering the association: regressed offsets, sub-pixel shifts and box sizes -- their worst deviation between the two implementations (feature px)
+        pos_noise = max(max((maps_h[k].permute(0, 3, 1, 2).reshape(REP, N, *case['maps'][k].shape[1:])[r] - case['maps'][k]).abs().max().item() for r in range(REP))
+                        for k in ('hps', 'hp_offset', 'reg', 'wh'))
+        snapped, refused = keypoint_margins(case, pos_noise)
+        print('[margin workload C5, live key point heat map] position noise %.2e px; per frame: %s key points snapped to a heat-map peak, %s refused by the distance term'
+              % (pos_noise, snapped, refused))
+        assert min(snapped) >= 1 and min(refused) >= 1, 'every frame must exercise both outcomes of the association'
+        for j in LIVE_JOINTS:                                                 # the live channels ARE the class-0 logit moved by a constant
+            dj = (maps_h['hm_hp'][..., j] - (maps_h['hm'][..., 0] + (math.log(0.1 / 0.9) - _thr_logit()))).abs().max().item()
+            assert dj < 1e-3, dj

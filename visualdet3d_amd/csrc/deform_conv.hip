@@ -40,7 +40,6 @@ struct DcnArgs {
     int64_t out_sb, out_sc, out_sy, out_sx;
     int mask_sigmoid, relu;
     int no_lstage = 0;                       // VD3D_DCN_NO_LSTAGE=1: logits read lane = pixel from global memory (A/B; same values)
-    int pk16 = 0;                            // fp16, OPT-IN (VD3D_DCN_PK16=1): blend on v_pk_fma_f16 (below); 0 = fp32 blend on v_fma_mix_f32
 };
 
 template <typename T> VD3D_DEV float ld(const void* p, int64_t i);
@@ -237,25 +236,8 @@ VD3D_DEV float mix_mul_hi(int x, float w) { float d; asm("v_fma_mix_f32 %0, %1, 
 VD3D_DEV float mix_fma_lo(int x, float w, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(w), "v"(c)); return d; }
 VD3D_DEV float mix_fma_hi(int x, float w, float c) { float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "v"(w), "v"(c)); return d; }
 
-// fp16, packed blend (round 4, OPT-IN with VD3D_DCN_PK16=1): the reference's own half path blends in scalar_t = half
-// (deform_conv_cuda_kernel.cu:467-497 dmcn_im2col_bilinear instantiated by AT_DISPATCH_FLOATING_TYPES_AND_HALF).  Here: the four
-// modulated bilinear weights rounded ONCE to fp16 (RNE) and the four-term chain w0 x0 -> fma(w1, x1, .) -> fma(w2, x2, .) ->
-// fma(w3, x3, .) on v_pk_fma_f16: TWO channels per instruction and the result is already the packed fp16 pair the MFMA operand wants --
-// 16 VALU instructions per 8 channels instead of 32 v_fma_mix_f32 + 4 conversions.
-// MEASURED (16 x 128 x 440 fp16, same box): 64 -> 64 386 -> 365 us (-5.5 %), 128 -> 128 219 -> 194 (-11 %), 256 -> 256 216 -> 196 (-9 %);
-// config 5 8.94 -> 8.77 ms per step (-1.9 %).  PARITY: three more roundings of <= 1/2 ulp plus the weights' own rounding -- the 16
-// DCNv2 blocks of config 5 teacher-forced at size read 0.54 - 1.35 x (2 fp16 ulp + 5e-4 scale) against 0.37 x for the fp32 blend: outside
-// the bar the tests hold this path to, for 2 % of one configuration.  NOT the default; tests run it under the switch with a 4-ulp bar.
-VD3D_DEV int pk_mul_f16(int a, int b) { int d; asm("v_pk_mul_f16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-VD3D_DEV int pk_fma_f16(int a, int b, int c) { int d; asm("v_pk_fma_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-VD3D_DEV int dcn_pk_weight(float w) { return Fmt16<hf16>::pack2_1(w, w); }
-VD3D_DEV i32x4 dcn_blend8_pk(const i32x4& c0, const i32x4& c1, const i32x4& c2, const i32x4& c3, int w0, int w1, int w2, int w3) {
-    i32x4 o;
-#pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = pk_fma_f16(c3[d], w3, pk_fma_f16(c2[d], w2, pk_fma_f16(c1[d], w1, pk_mul_f16(c0[d], w0))));
-    return o;
-}
-
+// (Rounds 4 - 5: an opt-in packed fp16 blend on v_pk_fma_f16 -- the reference's own half path blends in scalar_t = half -- measured -2 % on config 5 at
+// 0.54 - 1.35 x the 2-ulp bar of the stage-tap tests: outside the parity bar, so it was removed from the library in round 6.)
 template <typename T, int BN>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 256 ? 2 : 4, 8))) dcn_nhwc_kernel(const DcnArgs p) {
     constexpr int ES = (int)sizeof(T);
@@ -388,10 +370,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
             *(float*)(geo_tab + (size_t)it * GE + 32) = m;   // weights stay unmodulated: the modulation multiplies the blended value
         }
         *(i32x4*)(geo_tab + (size_t)it * GE) = i32x4{(int)go[0], (int)go[1], (int)go[2], (int)go[3]};
-        if (std::is_same<T, hf16>::value && p.pk16)       // packed blend: the weights as fp16 pairs (w, w), same 16 bytes of the entry
-            *(i32x4*)(geo_tab + (size_t)it * GE + 16) = i32x4{dcn_pk_weight(gw[0]), dcn_pk_weight(gw[1]), dcn_pk_weight(gw[2]), dcn_pk_weight(gw[3])};
-        else
-            *(f32x4*)(geo_tab + (size_t)it * GE + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
+        *(f32x4*)(geo_tab + (size_t)it * GE + 16) = f32x4{gw[0], gw[1], gw[2], gw[3]};
         }
     }
     }
@@ -441,17 +420,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
             c1.raw = cv[i][0]; c2.raw = cv[i][1]; c3.raw = cv[i][2]; c4.raw = cv[i][3];
             float vals[VE];
             if constexpr (std::is_same<T, hf16>::value) {
-              if (p.pk16) {
-                o.raw = dcn_blend8_pk(cv[i][0], cv[i][1], cv[i][2], cv[i][3], __builtin_bit_cast(int, geo[i].w[0]), __builtin_bit_cast(int, geo[i].w[1]),
-                                      __builtin_bit_cast(int, geo[i].w[2]), __builtin_bit_cast(int, geo[i].w[3]));
-              } else {
                 // fp16: the four-term fma chain on v_fma_mix_f32 (fp16 operand read in place, fp32 weight and accumulator)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     vals[2 * d] = mix_fma_lo(cv[i][3][d], geo[i].w[3], mix_fma_lo(cv[i][2][d], geo[i].w[2], mix_fma_lo(cv[i][1][d], geo[i].w[1], mix_mul_lo(cv[i][0][d], geo[i].w[0]))));
                     vals[2 * d + 1] = mix_fma_hi(cv[i][3][d], geo[i].w[3], mix_fma_hi(cv[i][2][d], geo[i].w[2], mix_fma_hi(cv[i][1][d], geo[i].w[1], mix_mul_hi(cv[i][0][d], geo[i].w[0]))));
                 }
-              }
             } else {
 #pragma unroll
                 for (int e = 0; e < VE; ++e) {
@@ -464,10 +438,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 
                 }
             }
             if constexpr (sizeof(T) == 2) {
-                if (!(std::is_same<T, hf16>::value && p.pk16)) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
-                }
+                for (int e = 0; e < 4; ++e) o.set2(e, vals[2 * e], vals[2 * e + 1]);
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o.set(e, vals[e]);
@@ -793,7 +765,6 @@ int launch_dcn(const vd3d_dcn_params* q, hipStream_t s) {
     a.out_sb = q->out_strides[0]; a.out_sc = q->out_strides[1]; a.out_sy = q->out_strides[2]; a.out_sx = q->out_strides[3];
     a.mask_sigmoid = q->mask_sigmoid; a.relu = q->relu;
     a.no_lstage = vd3d_switch(VD3D_SW_DCN_NO_LSTAGE) ? 1 : 0;
-    a.pk16 = (q->dtype == VD3D_F16 && vd3d_switch(VD3D_SW_DCN_PK16)) ? 1 : 0;      // opt-in: leaves the 2-ulp bar (see dcn_blend8_pk)
     if (a.Ho <= 0 || a.Wo <= 0 || q->B <= 0) { vd3d_set_error("deform_conv: empty output"); return VD3D_EINVAL; }
     // channel-contiguous activations, one group: the NHWC fast path (everything the detectors launch)
     if (a.groups == 1 && a.dgroups == 1 && a.in_sc == 1 && a.out_sc == 1 && a.Cg % bke == 0 && ((uintptr_t)q->in & 15) == 0 &&
