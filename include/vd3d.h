@@ -366,8 +366,10 @@ int vd3d_km3d_head_fused(const vd3d_conv_params* p, const void* w2_packed, const
  * All maps are fp32 NHWC logits / regressions [B][H][W][n] (n: hm n_cls, wh 2, hps 18, rot 8, dim 3, prob 1, reg 2,
  * hm_hp 9, hp_offset 2); P2 [B][3][4]; kconst = the head's `const` buffer, 32 floats ([16][2]).
  * Outputs padded to K per sample in decreasing-score order: scores [B][K], boxes [B][K][11]
- * (x1,y1,x2,y2,cx,cy,z,w,h,l,alpha), cls [B][K] int32, count [B] int32 (-1: more peaks than max_peaks).
- * Limits (checked before anything is enqueued): n_joints == 9, K <= 128, n_cls * K <= 512, max_peaks a power of two in [K, 8192]
+ * (x1,y1,x2,y2,cx,cy,z,w,h,l,alpha), cls [B][K] int32, count [B] int32 (-1: a heat-map channel has more local maxima above its threshold than
+ * max_peaks -- the caller repeats the sample with a larger capacity: the reference's top-K has no cap, rtm3d_utils.py:201-228; capacities <= 8192
+ * sort in LDS, larger ones -- up to every pixel of the map -- in `workspace`).
+ * Limits (checked before anything is enqueued): n_joints == 9, K <= 128, n_cls * K <= 512, max_peaks a power of two in [K, 2^24]
  * (VD3D_EINVAL); n_cls <= 9 heat-map channels per map -- the tiled peaks kernel keeps all channels of a map per workgroup
  * (VD3D_ERANGE). */
 typedef struct vd3d_km3d_params {

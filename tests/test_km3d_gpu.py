@@ -123,6 +123,39 @@ def test_decode_matches_oracle_on_identical_maps(H, W, B, seed):
     assert torch.equal(s1.cpu(), got[0][0].cpu()) and l1.shape[1:] == (1,) and l1.dtype == torch.int64
 
 
+def test_more_peaks_than_the_captured_capacity_are_decoded_off_graph():
+    """The reference's `_topk` / `_topk_channel` have no cap (rtm3d_utils.py:201-228).  Here a key point heat map whose every local maximum passes 0.1
+    (192 x 640 map: ~13 600 local maxima per channel > max_peaks = 8192) marks the frame -1 in the batched call; `unpad(retry=)` / the reference-signature
+    `get_bboxes` decode it again with a capacity that fits (16 384: key lists sorted in global memory) -- equal to the oracle, next to an ordinary frame."""
+    from visualdet3d_amd.networks.heads.km3d_head import KM3DHead
+    H, W, B = 192, 640, 2
+    cfg = syn.km3d_cfg()
+    head = KM3DHead(**cfg.head).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    n = dict(hm=3, wh=2, hps=18, rot=8, dim=3, prob=1, reg=2, hm_hp=9, hp_offset=2)
+    maps = {k: torch.randn(B, c, H, W, generator=g) for k, c in n.items()}
+    maps['hm'] = maps['hm'] * 1.5 - 4.0
+    maps['hm_hp'] = maps['hm_hp'] * 1.5 - 5.5
+    maps['hm_hp'][0] = maps['hm_hp'][0] * 0.05 + 6.0          # frame 0: every local maximum of every key point channel is far above 0.1
+    maps['wh'] = maps['wh'].abs() * 6 + 2
+    maps['hps'] = maps['hps'] * 3
+    maps['dim'] = maps['dim'].abs() + 1
+    P2, _ = syn.kitti_calib(W * 4, batch=B)
+    want = orc.km3d_get_bboxes(maps, P2, (H * 4, W * 4), score_thr=0.3, nms_iou_thr=0.5)
+    dev = {k: v.permute(0, 2, 3, 1).contiguous().cuda() for k, v in maps.items()}
+    padded = head.get_bboxes_batched(dev, P2.cuda(), (H * 4, W * 4))
+    counts = padded[3].tolist()
+    assert counts[0] == -1 and counts[1] >= 0, counts
+    with pytest.raises(RuntimeError):
+        head.unpad(padded)
+    got = head.unpad(padded, retry=lambda b: head.decode_unbounded({k: v[b:b + 1] for k, v in dev.items()}, P2[b:b + 1].cuda(), (H * 4, W * 4)))
+    for b in range(B):
+        assert len(want[b][0]) >= 3
+        assert_detections_close(tuple(t.cpu() for t in got[b]), want[b], rtol=1e-3, what='sample %d' % b)
+    s1, b1, l1 = head.get_bboxes({k: v[:1].cuda() for k, v in maps.items()}, P2[:1].cuda(), torch.zeros(1, 3, H * 4, W * 4))
+    assert torch.equal(s1.cpu(), got[0][0].cpu()) and torch.equal(b1.cpu(), got[0][1].cpu())
+
+
 @pytest.mark.parametrize('name', ['km3d_dla34_96x320', 'km3d_dla34_192x640', 'km3d_dla34_512x1760'])      # the last: BASELINE config 5 at size
 def test_fp32_mode_matches_reference_golden(name):
     g = load_golden(name)

@@ -35,6 +35,7 @@ struct KArgs {
     float* top_score;      // [B][n_ch][K]
     int32_t* top_idx;      // [B][n_ch][K]
     int32_t* overflow;     // [B]
+    uint64_t* big_keys;    // max_peaks > 8192 only: [B][n_ch][max_peaks] sort keys in global memory (the caller's retry after a peak-list overflow)
     float* out_scores; float* out_boxes; int32_t* out_cls; int32_t* out_count;
 };
 
@@ -164,13 +165,15 @@ __global__ void __launch_bounds__(256) km3d_peaks_kernel(const KArgs p, int tile
 constexpr int kTopkSort = 1024;
 __global__ void __launch_bounds__(kNmsThreads) km3d_topk_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* keys = (uint64_t*)smem;                               // [max_peaks]
-    uint64_t* cand = keys + p.max_peaks;                            // [kTopkSort]
+    const int nch = p.n_cls + p.J;
+    const int slot = blockIdx.y * nch + blockIdx.x;   // (b, ch)
+    // capacities beyond the LDS sort size (the caller's retry after an overflow; the reference's top-K has no cap, rtm3d_utils.py:201-228): the key
+    // list lives in global memory, same steps (a workgroup's global accesses are ordered by __syncthreads like its LDS accesses)
+    uint64_t* keys = p.big_keys ? p.big_keys + (int64_t)slot * p.max_peaks : (uint64_t*)smem;     // [max_peaks]
+    uint64_t* cand = p.big_keys ? (uint64_t*)smem : keys + p.max_peaks;                            // [kTopkSort]
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix, s_below;
     __shared__ int s_ncand;
-    const int nch = p.n_cls + p.J;
-    const int slot = blockIdx.y * nch + blockIdx.x;   // (b, ch)
     int n = p.peak_count[slot];
     if (n > p.max_peaks) {
         if (threadIdx.x == 0) p.overflow[blockIdx.y] = 1;
@@ -436,11 +439,13 @@ __global__ void __launch_bounds__(256) km3d_decode_kernel(const KArgs p) {
     if (tid == 0) p.out_count[b] = kept;
 }
 
+constexpr int kTopkLds = 8192;        // key lists up to this many peaks are sorted in LDS
 struct Ws {
-    int32_t* peak_count; float* peak_score; int32_t* peak_idx; float* top_score; int32_t* top_idx; int32_t* overflow;
+    int32_t* peak_count; float* peak_score; int32_t* peak_idx; float* top_score; int32_t* top_idx; int32_t* overflow; uint64_t* big_keys;
 };
 inline int64_t ws_bytes(int B, int nch, int max_peaks, int K) {
-    return 1024 + (int64_t)B * nch * 4 + (int64_t)B * 4 + (int64_t)B * nch * max_peaks * 8 + (int64_t)B * nch * K * 8;
+    return 1024 + (int64_t)B * nch * 4 + (int64_t)B * 4 + (int64_t)B * nch * max_peaks * 8 + (int64_t)B * nch * K * 8 +
+           (max_peaks > kTopkLds ? 256 + (int64_t)B * nch * max_peaks * 8 : 0);
 }
 inline Ws carve(void* base, int B, int nch, int max_peaks, int K) {
     Ws w;
@@ -450,7 +455,8 @@ inline Ws carve(void* base, int B, int nch, int max_peaks, int K) {
     w.peak_score = (float*)p; p += (int64_t)B * nch * max_peaks * 4;
     w.peak_idx = (int32_t*)p; p += (int64_t)B * nch * max_peaks * 4;
     w.top_score = (float*)p; p += (int64_t)B * nch * K * 4;
-    w.top_idx = (int32_t*)p;
+    w.top_idx = (int32_t*)p; p += (int64_t)B * nch * K * 4;
+    w.big_keys = max_peaks > kTopkLds ? (uint64_t*)(((uintptr_t)p + 255) & ~(uintptr_t)255) : nullptr;
     return w;
 }
 
@@ -467,8 +473,8 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
         return VD3D_EINVAL;
     }
     if (q->n_joints != kMaxJ || q->K < 1 || q->K > kMaxK || q->n_cls < 1 || q->n_cls * q->K > 512 || q->max_peaks < q->K ||
-        q->max_peaks > 8192 || (q->max_peaks & (q->max_peaks - 1))) {
-        vd3d_set_error("km3d_decode: need 9 joints, K <= 128, n_cls*K <= 512, max_peaks a power of two in [K, 8192]");
+        q->max_peaks > (1 << 24) || (q->max_peaks & (q->max_peaks - 1))) {
+        vd3d_set_error("km3d_decode: need 9 joints, K <= 128, n_cls*K <= 512, max_peaks a power of two in [K, 2^24]");
         return VD3D_EINVAL;
     }
     // validated with the other parameters, BEFORE anything is enqueued (include/vd3d.h states the limit)
@@ -483,6 +489,7 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     a.img_h = q->img_h; a.img_w = q->img_w; a.score_thr = q->score_thr; a.nms_thr = q->nms_iou_thr;
     a.peak_count = w.peak_count; a.peak_score = w.peak_score; a.peak_idx = w.peak_idx; a.top_score = w.top_score; a.top_idx = w.top_idx;
     a.overflow = w.overflow;
+    a.big_keys = w.big_keys;
     a.out_scores = q->out_scores; a.out_boxes = q->out_boxes; a.out_cls = q->out_cls; a.out_count = q->out_count;
     const int nz = (int)(((int64_t)q->B * nch * 4 + 255) / 256 * 256 + (int64_t)q->B * 4) / 4;
     hipLaunchKernelGGL(km3d_zero_kernel, dim3((nz + 255) / 256), dim3(256), 0, s, w.peak_count, nz);
@@ -497,7 +504,7 @@ extern "C" int vd3d_km3d_decode(const vd3d_km3d_params* q, void* stream) {
     }
     int rc = vd3d_check_launch("km3d_peaks");
     if (rc) return rc;
-    const int lds = (q->max_peaks + kTopkSort) * 8;      // the key list + the compacted candidates of the radix select
+    const int lds = ((q->max_peaks > kTopkLds ? 0 : q->max_peaks) + kTopkSort) * 8;      // the key list (when it fits) + the compacted candidates of the radix select
     static Vd3dLdsLimit lim;
     rc = vd3d_raise_lds_limit((const void*)km3d_topk_kernel, lds, lim, "hipFuncSetAttribute(km3d_topk)");
     if (rc) return rc;

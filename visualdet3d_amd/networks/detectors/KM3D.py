@@ -45,7 +45,9 @@ class KM3D(GraphedForward, nn.Module):
         # the calibration in kernel form (contiguous fp32 on the device) BEFORE the graph cache: the graph's static input is then what the
         # kernels read, and a float64 / host / strided P2 of a later frame reaches them through the per-call copy into it
         P2 = torch.as_tensor(P2).to(device=img_batch.device, dtype=torch.float32).contiguous()
-        return self.bbox_head.unpad(self._graphed(img_batch, P2), own=True)      # hipGraph cache, lib/graphed.py
+        return self.bbox_head.unpad(self._graphed(img_batch, P2), own=True,      # hipGraph cache, lib/graphed.py
+                                    retry=lambda b: self.bbox_head.decode_unbounded({k: v[b:b + 1] for k, v in self._last_raw.items()}, P2[b:b + 1],
+                                                                                    img_batch.shape[2:]))
 
     @torch.no_grad()
     def test_forward(self, img_batch, P2):

@@ -44,7 +44,9 @@ class KM3DHead(nn.Module):
         self.num_classes, self.num_joints, self.max_objects = num_classes, num_joints, max_objects
         self.clipper = ClipBoxes()
         self._cache = fused.PackCache()
-        self.max_peaks = 8192      # per (sample, heat-map channel) capacity of the peak list (LDS sort size)
+        # per (sample, heat-map channel) capacity of the peak list INSIDE the captured forward (<= 8192: sorted in LDS).  Not a limit of the head: a frame with
+        # more local maxima above a threshold (a plateau makes every pixel one) is decoded again off-graph with a capacity that fits (decode_unbounded)
+        self.max_peaks = 8192
         self._workspaces = {}
         self._workspace = None
         self.fuse_head = True        # bf16: the nine head branches in one launch (vd3d_km3d_head_fused)
@@ -106,23 +108,40 @@ class KM3DHead(nn.Module):
         return {k: v.permute(0, 3, 1, 2).contiguous() for k, v in self.forward_nhwc(fused.to_nhwc(x)).items()}
 
     # ---- decode --------------------------------------------------------------------------------------------------
-    def get_bboxes_batched(self, maps, P2, img_hw):
+    def decode_unbounded(self, maps, P2, img_hw):
+        """ONE frame (maps [1, H, W, n]) whose peak list did not fit ``max_peaks``: the same kernels, eagerly, with a doubled capacity until the frame
+        fits -- at most every pixel of the map (beyond 8192 the lists are sorted in global memory, csrc/km3d_decode.hip).  The reference's ``_topk`` has no cap
+        (rtm3d_utils.py:201-228).  -> (scores [n], boxes [n, 11], cls [n, 1] int64), private."""
+        assert maps['hm'].shape[0] == 1
+        H, W = maps['hm'].shape[1:3]
+        limit = 1 << max(H * W - 1, 1).bit_length()
+        cap = int(self.max_peaks)
+        while True:
+            cap = min(cap * 2, limit)
+            scores, boxes, cls, count = self.get_bboxes_batched({k: v.contiguous() for k, v in maps.items()}, P2, img_hw, max_peaks=cap)
+            k = int(count.item())
+            if k >= 0:
+                return scores[0, :k].clone(), boxes[0, :k].clone(), cls[0, :k].long().unsqueeze(-1)
+            assert cap < limit, 'a capacity of every pixel of the map cannot overflow'
+
+    def get_bboxes_batched(self, maps, P2, img_hw, max_peaks=None):
         """maps: dict of fp32 NHWC tensors.  Returns padded device tensors (scores [B,K], boxes [B,K,11], cls [B,K] i32,
-        count [B] i32) -- no host sync."""
+        count [B] i32) -- no host sync.  ``max_peaks``: a capacity other than the head's (decode_unbounded): a private scratch buffer."""
         from ..._lib import Km3dParams
         hm = maps['hm']
         B, H, W, ncls = hm.shape
         dev = hm.device
         K = self.TOPK
         J = self.num_joints
+        cap = int(max_peaks or self.max_peaks)
         # one scratch buffer per (batch, capacities, device), kept for the life of the head: hipGraphs bake its address, so it is never
         # replaced by a larger one (a later B = 16 call must not free the buffer a cached B = 1 graph writes on every replay)
-        wkey = (B, ncls, J, self.max_peaks, K, dev)
-        ws = self._workspaces.get(wkey)
+        wkey = (B, ncls, J, cap, K, dev)
+        ws = self._workspaces.get(wkey) if max_peaks is None else None
         if ws is None:
-            need = _lib.lib().vd3d_km3d_workspace_bytes(B, ncls, J, self.max_peaks, K)
+            need = _lib.lib().vd3d_km3d_workspace_bytes(B, ncls, J, cap, K)
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            if not torch.cuda.is_current_stream_capturing():     # (first seen inside a capture: private to that graph's pool)
+            if max_peaks is None and not torch.cuda.is_current_stream_capturing():     # (first seen inside a capture: private to that graph's pool)
                 self._workspaces[wkey] = ws
         self._workspace = ws
         scores = torch.empty((B, K), dtype=torch.float32, device=dev)
@@ -139,7 +158,7 @@ class KM3DHead(nn.Module):
         p.P2 = P2.data_ptr()
         kconst = self.const.detach().to(device=dev, dtype=torch.float32).contiguous()
         p.kconst = kconst.data_ptr()
-        p.B, p.H, p.W, p.n_cls, p.n_joints, p.K, p.max_peaks = B, H, W, ncls, J, K, self.max_peaks
+        p.B, p.H, p.W, p.n_cls, p.n_joints, p.K, p.max_peaks = B, H, W, ncls, J, K, cap
         p.img_h, p.img_w = int(img_hw[0]), int(img_hw[1])
         p.score_thr = float(getattr(self.test_cfg, 'score_thr', 0.1))
         p.nms_iou_thr = float(getattr(self.test_cfg, 'nms_iou_thr', 0.5))
@@ -149,8 +168,9 @@ class KM3DHead(nn.Module):
         return scores, boxes, cls, count
 
     @staticmethod
-    def unpad(padded, own=False):
-        """``own=True``: views of private copies made BEFORE the host sync (see AnchorBasedDetection3DHead.unpad)"""
+    def unpad(padded, own=False, retry=None):
+        """``own=True``: views of private copies made BEFORE the host sync (see AnchorBasedDetection3DHead.unpad).  ``retry(b)``: called for a sample whose
+        peak list overflowed the captured capacity; returns that sample's tuple (``decode_unbounded``); without it an overflow raises."""
         scores, boxes, cls, count = padded
         outs = []
         from ..lib.graphed import COPY_AFTER_SYNC, read_counts
@@ -160,7 +180,10 @@ class KM3DHead(nn.Module):
             rows = list(zip(scores.unbind(0), boxes.unbind(0), cls.unbind(0)))
         for b, k in enumerate(read_counts(count)):
             if k < 0:
-                raise RuntimeError('sample %d: more heat-map peaks than KM3DHead.max_peaks' % b)
+                if retry is None:
+                    raise RuntimeError('sample %d: more heat-map peaks than KM3DHead.max_peaks' % b)
+                outs.append(retry(b))
+                continue
             if early:
                 s, bx, c = rows[b]
                 outs.append((s[:k], bx[:k], c[:k]))
@@ -174,4 +197,4 @@ class KM3DHead(nn.Module):
         """Reference signature: ``output`` = dict of NCHW fp32 maps (as returned by ``forward``), batch 1."""
         maps = {k: v.permute(0, 2, 3, 1).contiguous().float() for k, v in output.items()}
         assert img_batch is not None
-        return self.unpad(self.get_bboxes_batched(maps, P2, img_batch.shape[2:]))[0]
+        return self.unpad(self.get_bboxes_batched(maps, P2, img_batch.shape[2:]), retry=lambda b: self.decode_unbounded(maps, P2, img_batch.shape[2:]))[0]
