@@ -1367,6 +1367,9 @@ static SplitPlan plan_splitk_strip(const ConvArgs& a) {
     if (pl.splits < 2) { pl.splits = 1; return pl; }
     pl.bn = 288;
     pl.ws_bytes = (int64_t)pl.splits * tiles * 256 * 288 * 4;
+    // the fp32 partials are a per-call allocation (and live once per captured graph): bounded -- a layer that would need more stays unsplit
+    // (config 3's 2176 -> 576 conv, the largest shape the split was measured on, takes 212 MB)
+    if (pl.ws_bytes > (256ll << 20)) return SplitPlan();
     return pl;
 }
 
