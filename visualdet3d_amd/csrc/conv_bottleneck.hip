@@ -187,12 +187,10 @@ __global__ void __launch_bounds__(256, 2) bottleneck64_kernel(const ConvArgs c1,
             const bool v = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
             float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[r] = a1[j][r] * s1[r] + h1[r];
-                if (c1.relu) o[r] = fmaxf(o[r], 0.f);
-                o[r] = v ? o[r] : 0.f;
-            }
-            *(i32x2*)(smem + t_addr(row)) = i32x2{Fmt16<T>::pack2(o[0], o[1]), Fmt16<T>::pack2(o[2], o[3])};
+            for (int r = 0; r < 4; ++r) o[r] = a1[j][r] * s1[r] + h1[r];
+            // round (one packed conversion per pair), ReLU on the packed pairs, zero outside the image: 8 instructions for 4 values
+            const int q0 = max_pk16(Fmt16<T>::pack2_1(o[0], o[1]), 0), q1 = max_pk16(Fmt16<T>::pack2_1(o[2], o[3]), 0);
+            *(i32x2*)(smem + t_addr(row)) = i32x2{v ? q0 : 0, v ? q1 : 0};
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -227,11 +225,8 @@ __global__ void __launch_bounds__(256, 2) bottleneck64_kernel(const ConvArgs c1,
         for (int y = 0; y < 8; ++y) {
             float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o[r] = a2[y][r] * s2[r] + h2[r];
-                if (c2.relu) o[r] = fmaxf(o[r], 0.f);
-            }
-            *(i32x2*)(smem + t_addr(16 * y + pxv)) = i32x2{Fmt16<T>::pack2(o[0], o[1]), Fmt16<T>::pack2(o[2], o[3])};
+            for (int r = 0; r < 4; ++r) o[r] = a2[y][r] * s2[r] + h2[r];
+            *(i32x2*)(smem + t_addr(16 * y + pxv)) = i32x2{max_pk16(Fmt16<T>::pack2_1(o[0], o[1]), 0), max_pk16(Fmt16<T>::pack2_1(o[2], o[3]), 0)};
         }
         // the next tile's images (issued before conv2) have had conv2's time to land: waited for HERE, while no store is in flight yet
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -269,11 +264,14 @@ __global__ void __launch_bounds__(256, 2) bottleneck64_kernel(const ConvArgs c1,
                     Fmt16<T>::mfma16(wd[2 * cb + 1], x2[1], ad[cb]);
                 }
             };
+            if constexpr (!DS) {
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) mm(cb);
+                for (int cb = 0; cb < 4; ++cb) mm(cb);
+            }
             i32x4 o2[2];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
+                if constexpr (DS) mm(cb);          // (two accumulator sets: one channel block at a time keeps the first-block variant inside its 256 registers)
                 const int ch = 64 * wave + 32 * (cb >> 1) + 8 * gv + 4 * (cb & 1);
                 const f32x4 sc = *(const f32x4*)(ss + ch), sh = *(const f32x4*)(ss + 256 + ch);
                 float v[4];
@@ -292,8 +290,8 @@ __global__ void __launch_bounds__(256, 2) bottleneck64_kernel(const ConvArgs c1,
                 }
                 // ReLU on the packed pair (one v_pk_max_i16 per two values; relu(round(x)) == round(relu(x)))
                 const int floor16 = c3.relu ? 0 : (int)0x80008000u;
-                o2[cb >> 1][2 * (cb & 1)] = max_pk16(Fmt16<T>::pack2(v[0], v[1]), floor16);
-                o2[cb >> 1][2 * (cb & 1) + 1] = max_pk16(Fmt16<T>::pack2(v[2], v[3]), floor16);
+                o2[cb >> 1][2 * (cb & 1)] = max_pk16(Fmt16<T>::pack2_1(v[0], v[1]), floor16);
+                o2[cb >> 1][2 * (cb & 1) + 1] = max_pk16(Fmt16<T>::pack2_1(v[2], v[3]), floor16);
             }
             if (pin) {
                 char* op = c3.out + ((m00 + (int64_t)y * W) * c3.out_pix_stride + 64 * wave + 8 * gv) * 2;
@@ -301,13 +299,22 @@ __global__ void __launch_bounds__(256, 2) bottleneck64_kernel(const ConvArgs c1,
                 *(i32x4*)(op + 64) = o2[1];
             }
         };
-        ld3(0, bq[0], xq[0]);
+        if constexpr (!DS) {
+            ld3(0, bq[0], xq[0]);
 #pragma unroll 1
-        for (int y = 0; y < 8; y += 2) {
-            ld3(y + 1, bq[1], xq[1]);
-            row3(y, bq[0], xq[0]);
-            if (y + 2 < 8) ld3(y + 2, bq[0], xq[0]);
-            row3(y + 1, bq[1], xq[1]);
+            for (int y = 0; y < 8; y += 2) {
+                ld3(y + 1, bq[1], xq[1]);
+                row3(y, bq[0], xq[0]);
+                if (y + 2 < 8) ld3(y + 2, bq[0], xq[0]);
+                row3(y + 1, bq[1], xq[1]);
+            }
+        } else {
+            // (the first-block variant holds 144 weight registers: no look-ahead, one row at a time)
+#pragma unroll 1
+            for (int y = 0; y < 8; ++y) {
+                ld3(y, bq[0], xq[0]);
+                row3(y, bq[0], xq[0]);
+            }
         }
         par ^= 1;
     }
