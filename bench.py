@@ -143,7 +143,8 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
-    orig = dict(conv2d=ops.conv2d, dcn=ops.deform_conv_general, cols=ops.deform_columns, head=ops.km3d_head_fused, pair=ops.conv2d_pair)
+    orig = dict(conv2d=ops.conv2d, dcn=ops.deform_conv_general, cols=ops.deform_columns, head=ops.km3d_head_fused, pair=ops.conv2d_pair,
+                bottleneck=ops.conv2d_bottleneck)
 
     def conv2d(x, pc, out=None, residual=None, relu=False, out_f32=False):
         s, e = ev(), ev()
@@ -222,6 +223,17 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
         records.append(('conv', fl, s, e, nbytes, '3x3 s1 %d->%d + 3x3 s2 %d->%d (one launch) @ %dx%dx%d' % (pc_a.Cin, pc_a.Cout, pc_b.Cin, Co, B, H, W)))
         return o
 
+    def bottleneck(x, pc1, pc2, pc3, pc_ds=None, out=None):
+        s, e = ev(), ev()
+        s.record()
+        o = orig['bottleneck'](x, pc1, pc2, pc3, pc_ds, out=out)
+        e.record()
+        B, H, W, Cx = x.shape
+        fl = 2.0 * B * H * W * (Cx * 64 + 576 * 64 + 64 * 256 + (Cx * 256 if pc_ds is not None else 0))
+        records.append(('conv', fl, s, e, x.numel() * x.element_size() + o.numel() * o.element_size(),
+                        'bottleneck %d->64->64->256%s (one launch) @ %dx%dx%d' % (Cx, ' + ds' if pc_ds is not None else '', B, H, W)))
+        return o
+
     # the HBM-bound stages north_star names (stem, cosine volumes, fused cost volume, ghost depth-wise convs, head selection + NMS): same
     # per-launch events, algorithmic bytes = every operand read once + every result written once
     def nbytes(*ts):
@@ -257,6 +269,7 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
              lambda a, kw, o: nbytes(a[0], o) + (nbytes(kw.get('add')) if kw.get('add') is not None else (nbytes(a[3]) if len(a) > 3 else 0.0)))
     hbm_wrap('image_conv', lambda a, kw, o: 'image_conv7_kernel (7x7/s1 on the fp32 image) -> %s' % (tuple(o.shape),), lambda a, kw, o: nbytes(a[0], o))
     ops.conv2d, ops.deform_conv_general, ops.deform_columns, ops.km3d_head_fused, ops.conv2d_pair = conv2d, dcn, cols, head, pair
+    ops.conv2d_bottleneck = bottleneck
     switches = []
     for mod, attr in ((getattr(model, 'bbox_head', None), 'overlap_towers'), (getattr(model, 'core', None), 'overlap_neck')):
         if mod is not None and hasattr(mod, attr):
@@ -274,6 +287,7 @@ def profile_ops(model, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS'):
     finally:
         ops.conv2d, ops.deform_conv_general, ops.deform_columns, ops.km3d_head_fused = orig['conv2d'], orig['dcn'], orig['cols'], orig['head']
         ops.conv2d_pair = orig['pair']
+        ops.conv2d_bottleneck = orig['bottleneck']
         for name in ('stem_conv_pool', 'psm_cosine', 'cost_volume_fused', 'dwconv3x3', 'head_postprocess', 'dwconv_transpose', 'image_conv'):
             setattr(ops, name, orig[name])
         for mod, attr, v in switches:

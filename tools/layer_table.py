@@ -19,6 +19,7 @@ if hasattr(m.core, 'overlap_neck'):
 rec = []
 orig = ops.conv2d
 orig_pair = ops.conv2d_pair
+orig_bn = ops.conv2d_bottleneck
 
 
 def timed(x, pc, out=None, residual=None, relu=False, out_f32=False):
@@ -45,16 +46,30 @@ def timed_pair(x, pa, pb, relu_a=True, relu_b=True):
     return o
 
 
+def timed_bottleneck(x, pc1, pc2, pc3, pc_ds=None, out=None):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    o = orig_bn(x, pc1, pc2, pc3, pc_ds, out=out)
+    e.record()
+    B, H, W, Cx = x.shape
+    fl = 2.0 * B * H * W * (Cx * 64 + 576 * 64 + 64 * 256 + (Cx * 256 if pc_ds is not None else 0))
+    rec.append(('bottleneck %d->64->64->256%s @ %dx%dx%d (one launch)' % (Cx, ' + ds' if pc_ds is not None else '', B, H, W), fl,
+                x.numel() * x.element_size() + o.numel() * o.element_size(), s, e))
+    return o
+
+
 with torch.no_grad():
     m.forward_device(*inputs)
     torch.cuda.synchronize()
     ops.conv2d = timed
     ops.conv2d_pair = timed_pair
+    ops.conv2d_bottleneck = timed_bottleneck
     rec.clear()
     m.forward_device(*inputs)
     torch.cuda.synchronize()
 ops.conv2d = orig
 ops.conv2d_pair = orig_pair
+ops.conv2d_bottleneck = orig_bn
 tot = 0.0
 for d, fl, by, s, e in rec:
     t = s.elapsed_time(e) * 1e-3
