@@ -22,6 +22,7 @@ from visualdet3d_amd.utils import synthetic as syn  # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else 'mono'
 per_xcd = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+empty = len(sys.argv) > 3 and sys.argv[3] == 'empty'      # the same fork / launch / join structure, the touch kernel reads nothing: the structure's own cost
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'l2_touch.so'))
 lib.l2_touch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 
@@ -79,7 +80,7 @@ def capture(warm):
                 for t in (nxt.w, nxt.w_frag):
                     if t is not None and t.numel() * t.element_size() <= (8 << 20):      # (a 36 MB head panel does not fit a 4 MB L2: skipped)
                         nb = t.numel() * t.element_size()
-                        lib.l2_touch(t.data_ptr(), nb, per_xcd, sink.data_ptr(), side.cuda_stream)
+                        lib.l2_touch(t.data_ptr(), 0 if empty else nb, per_xcd, sink.data_ptr(), side.cuda_stream)
                         touched[0] += nb
         return orig(x, pc, **kw)
 
@@ -128,5 +129,5 @@ med = lambda v: sorted(v)[len(v) // 2]      # noqa: E731
 same = all(torch.equal(a, b) for a, b in zip(out0, out1))
 print('%s batch 1, %d conv launches per forward, %.1f MB of next-layer weights touched per forward through all 8 L2s (%d blocks per XCD)' % (kind, len(order), nb / 1e6, per_xcd))
 print('replay, plain graph:        %s  median %.4f ms' % (' '.join('%.4f' % v for v in res[0]), med(res[0])))
-print('replay, with L2 warmers:    %s  median %.4f ms' % (' '.join('%.4f' % v for v in res[1]), med(res[1])))
+print('replay, with %s:    %s  median %.4f ms' % ('EMPTY side launches' if empty else 'L2 warmers', ' '.join('%.4f' % v for v in res[1]), med(res[1])))
 print('results identical: %s' % same)
