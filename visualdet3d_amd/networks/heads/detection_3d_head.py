@@ -60,6 +60,11 @@ class AnchorBasedDetection3DHead(nn.Module):
         self._cache = fused.PackCache()
         self._side_streams = {}
         self.overlap_towers = True   # False: run the towers back to back on one stream (per-kernel profiling)
+        # The overlap needs a LONG branch to pay: a forked launch inside a hipGraph costs ~13.6 us (profiles/r06_b1_l2_warm_experiment.txt).  With the mono head's
+        # two towers of similar, short length (256-wide features) it loses 4.5 % at batch 1 - 4 (0.531 -> 0.507 ms per call), ties at 8, wins 2.5 % at 16
+        # (tools/ab_overlap_b1.py); the stereo towers (1408 / 2176-wide reg tower against a 256-wide cls tower) win at every batch.  Below this many input
+        # values (pixels x channels of the head's input) the towers run on one stream:
+        self.overlap_min_elems = 2_500_000      # (mono 384x1280: batches 1 - 5 on one stream; the stereo head's 1408-wide input: every batch overlaps)
         # per-sample capacity of the device candidate list INSIDE the captured forward (a power of two; <= 8192 keeps the lists in LDS).  Not a
         # limit of the head: a frame with more candidates is re-run off-graph with a doubled capacity (get_bboxes_unbounded) -- the reference's
         # list has no cap (detection_3d_head.py:341-400)
@@ -130,7 +135,7 @@ class AnchorBasedDetection3DHead(nn.Module):
         CUs the reg tower's partially-filled last tile rounds leave idle (fork/join is captured into the hipGraph)."""
         feat = inputs['features']
         self._p2_conv = None         # a calibration conversion is shared by the stages of ONE forward only (see _device_p2)
-        if not self.overlap_towers:
+        if not self.overlap_towers or feat.numel() < self.overlap_min_elems:
             return self._cls_forward_nhwc(feat), self._reg_forward_nhwc(feat, inputs)
         main = torch.cuda.current_stream()
         side = self._side_streams.get(feat.device)

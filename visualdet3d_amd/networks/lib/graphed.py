@@ -94,7 +94,7 @@ class GraphedForward:
         self.drop_graphs()                       # storages are about to be replaced
         return super()._apply(fn, *a, **k)
 
-    _KNOBS = (('bbox_head', ('overlap_towers', 'overlap_select', 'max_candidates', 'max_peaks', 'TOPK')), ('core', ('overlap_neck',)),
+    _KNOBS = (('bbox_head', ('overlap_towers', 'overlap_select', 'overlap_min_elems', 'max_candidates', 'max_peaks', 'TOPK')), ('core', ('overlap_neck',)),
               ('bbox_head.anchors', ('filter_y_threshold_min_max', 'filter_x_threshold', 'readConfigFile')))
 
     def _knob_objects(self):
