@@ -179,6 +179,7 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         // ---- epilogue: scale/shift (+residual) (+ReLU), 2 x 16-byte NHWC stores per lane (half-wave pairing) ----
+        const int relu_floor = p.relu ? 0 : (int)0x80008000u;
         int pk[4][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -203,12 +204,9 @@ __global__ void __launch_bounds__(512) conv_resident64_kernel(const ConvArgs p, 
                 v[2] += Fmt16<T>::lo(r1);
                 v[3] += Fmt16<T>::hi(r1);
             }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            pk[g][0] = Fmt16<T>::pack2(v[0], v[1]);
-            pk[g][1] = Fmt16<T>::pack2(v[2], v[3]);
+            // round, then ReLU on the packed pairs (bit-identical to fmaxf before the rounding; 4 instead of ~12 instructions per four values)
+            pk[g][0] = max_pk16(Fmt16<T>::pack2_1(v[0], v[1]), relu_floor);
+            pk[g][1] = max_pk16(Fmt16<T>::pack2_1(v[2], v[3]), relu_floor);
         }
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
@@ -500,12 +498,8 @@ __global__ void __launch_bounds__(256) conv_regw_kernel(const ConvArgs p, int nt
                         v[2] += Fmt16<T>::lo(r1);
                         v[3] += Fmt16<T>::hi(r1);
                     }
-                    if (p.relu) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    pk[g][0] = Fmt16<T>::pack2(v[0], v[1]);
-                    pk[g][1] = Fmt16<T>::pack2(v[2], v[3]);
+                    pk[g][0] = max_pk16(Fmt16<T>::pack2_1(v[0], v[1]), p.relu ? 0 : (int)0x80008000u);      // round, then ReLU on the packed pairs (bit-identical)
+                    pk[g][1] = max_pk16(Fmt16<T>::pack2_1(v[2], v[3]), p.relu ? 0 : (int)0x80008000u);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
@@ -886,10 +880,8 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
                         v[2] += Fmt16<T>::lo(r1);
                         v[3] += Fmt16<T>::hi(r1);
                     }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
-                    pk[g][0] = Fmt16<T>::pack2(v[0], v[1]);
-                    pk[g][1] = Fmt16<T>::pack2(v[2], v[3]);
+                    pk[g][0] = max_pk16(Fmt16<T>::pack2_1(v[0], v[1]), p.relu ? 0 : (int)0x80008000u);      // round, then ReLU on the packed pairs (bit-identical)
+                    pk[g][1] = max_pk16(Fmt16<T>::pack2_1(v[2], v[3]), p.relu ? 0 : (int)0x80008000u);
                 }
 #pragma unroll
                 for (int g = 0; g < 4; g += 2) {
@@ -973,6 +965,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN ==
                     rs.v[cb][j] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, roff, (cb * 32 + 16 * j) * 2, 0));
         }
     };
+    const int relu_floor = p.relu ? 0 : (int)0x80008000u;      // packed-pair floor: ReLU | identity
     auto finish = [&](int blk, const Blk& q, const Res& rs) {
         f32x16 acc[2];
 #pragma unroll
@@ -1013,12 +1006,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN ==
                     v[2] += Fmt16<T>::lo(r1);
                     v[3] += Fmt16<T>::hi(r1);
                 }
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                pk[g][0] = Fmt16<T>::pack2(v[0], v[1]);
-                pk[g][1] = Fmt16<T>::pack2(v[2], v[3]);
+                // round (one packed conversion per pair), then ReLU on the packed pairs (relu(round(x)) == round(relu(x)): bit-identical to fmaxf first;
+                // fmaxf on an accumulator costs a canonicalise + a max per value, v_pk_max_i16 one instruction per two)
+                pk[g][0] = max_pk16(Fmt16<T>::pack2_1(v[0], v[1]), relu_floor);
+                pk[g][1] = max_pk16(Fmt16<T>::pack2_1(v[2], v[3]), relu_floor);
             }
             // through the wave's LDS tile: the MFMA layout gives a lane 8 bytes of one pixel; stored from there an instruction
             // writes 32 bytes into each of 32 lines.  Re-read row-major, a store instruction covers 8 pixels x 128 bytes: whole lines
