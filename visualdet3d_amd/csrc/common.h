@@ -94,6 +94,7 @@ VD3D_DEV int relu_pk16(int p) {
 
 template <> struct Fmt16<float> {      // never used for arithmetic: lets 16-bit-only epilogue code compile in fp32 instantiations
     static VD3D_DEV int pack2(float lo, float hi) { return Fmt16<short>::pack2(lo, hi); }
+    static VD3D_DEV int pack2_1(float lo, float hi) { return Fmt16<short>::pack2_1(lo, hi); }
     static VD3D_DEV float lo(uint32_t u) { return Fmt16<short>::lo(u); }
     static VD3D_DEV float hi(uint32_t u) { return Fmt16<short>::hi(u); }
     static VD3D_DEV float one(float f) { return f; }

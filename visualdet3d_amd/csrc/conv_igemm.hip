@@ -252,6 +252,7 @@ VD3D_DEV void conv_epilogue16_lines(const ConvArgs& p, f32x4 (&acc)[TN][TM], con
                                     int lane, char* tile, const float* ltab, int ltn) {
     constexpr int ROWB = WTN * 2 + 16;                 // bytes per parked pixel row (16-byte aligned; + 16 spreads the banks)
     constexpr int CPR = WTN / 8;                       // 16-byte chunks per pixel row
+    const int relu_floor = p.relu ? 0 : (int)0x80008000u;      // packed-pair floor: ReLU | identity
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = mrow[j];
@@ -272,11 +273,8 @@ VD3D_DEV void conv_epilogue16_lines(const ConvArgs& p, f32x4 (&acc)[TN][TM], con
                 v[2] += Fmt16<T>::lo(r1);
                 v[3] += Fmt16<T>::hi(r1);
             }
-            if (p.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            *(i32x2*)(tile + l16 * ROWB + (i * 16 + 4 * q) * 2) = i32x2{Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3])};
+            // round, then ReLU on the packed pairs (bit-identical to fmaxf before the rounding: 4 instead of ~12 instructions per four values)
+            *(i32x2*)(tile + l16 * ROWB + (i * 16 + 4 * q) * 2) = i32x2{max_pk16(Fmt16<T>::pack2_1(v[0], v[1]), relu_floor), max_pk16(Fmt16<T>::pack2_1(v[2], v[3]), relu_floor)};
         }
 #pragma unroll
         for (int it = 0; it < (16 * CPR + 63) / 64; ++it) {
@@ -450,6 +448,7 @@ template <typename T, int TM>
 VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const int (&mrow)[TM], int mblock0, int nw, int half, int lr, int lane,
                                   char* tile, const float* ltab, int ltn, int n0) {
     const int prow = lane >> 3, pslot = lane & 7;
+    const int relu_floor = p.relu ? 0 : (int)0x80008000u;      // packed-pair floor: ReLU | identity
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = mrow[j];
@@ -476,11 +475,8 @@ VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const
                     v[2] += Fmt16<T>::lo(r1);
                     v[3] += Fmt16<T>::hi(r1);
                 }
-                if (p.relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                *(i32x2*)(tile + lr * kLineRow + (i * 32 + 8 * g + 4 * half) * 2) = i32x2{Fmt16<T>::pack2(v[0], v[1]), Fmt16<T>::pack2(v[2], v[3])};
+                *(i32x2*)(tile + lr * kLineRow + (i * 32 + 8 * g + 4 * half) * 2) =
+                    i32x2{max_pk16(Fmt16<T>::pack2_1(v[0], v[1]), relu_floor), max_pk16(Fmt16<T>::pack2_1(v[2], v[3]), relu_floor)};      // round, then ReLU on the pairs (bit-identical)
             }
         }
 #pragma unroll
