@@ -274,3 +274,44 @@ def test_bench_gpus_flag_is_honoured(tmp_path):
     env = dict(os.environ, WORLD_SIZE='4', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '8'], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == '' and 'disagree' in r.stderr
+
+
+def test_bench_dcn_sampling_stats_and_workload_weights():
+    """bench.py's DCN workload statistics (CPU tensors): zero offsets on a 4 x 5 map with a 3 x 3 / pad 1 kernel -- every sample sits on a pixel centre, so the corners
+    inside the image are exactly the in-image taps' own corners -- and a known shift; and the realistic-workload state dict scales every conv_offset entry and sets the
+    KM3D heat-map biases while the legacy one leaves the seeded values."""
+    import os
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    H, W, K = 4, 5, 9
+    off = torch.zeros(1, H, W, 2 * K)
+    sq, n, inside, total = bench.dcn_sampling_stats(off, 'nhwc', (3, 3), (1, 1), (1, 1), (1, 1), (H, W))
+    assert sq == 0.0 and n == H * W * K * 2 and total == 4 * H * W * K
+    want = 0
+    for y in range(H):
+        for x in range(W):
+            for ky in range(3):
+                for kx in range(3):
+                    y0, x0 = y - 1 + ky, x - 1 + kx
+                    want += sum((0 <= yy <= H - 1) and (0 <= xx <= W - 1) for yy in (y0, y0 + 1) for xx in (x0, x0 + 1))
+    assert inside == want
+    # NCHW layout, every sample moved 10 px down: nothing of the lower taps stays inside
+    off2 = torch.zeros(1, 2 * K, H, W)
+    off2[:, 0::2] = 10.0
+    sq2, n2, inside2, total2 = bench.dcn_sampling_stats(off2, 'nchw', (3, 3), (1, 1), (1, 1), (1, 1), (H, W))
+    assert abs(sq2 - 100.0 * H * W * K) < 1e-6 and inside2 == 0 and total2 == total
+
+    class M:
+        def state_dict(self):
+            return {'core.up.conv.conv_offset.weight': torch.zeros(27, 64, 3, 3), 'core.up.conv.conv_offset.bias': torch.zeros(27),
+                    'bbox_head.head_layers.hm.2.bias': torch.zeros(3), 'bbox_head.head_layers.hm_hp.2.bias': torch.zeros(9),
+                    'bbox_head.head_layers.hm.2.weight': torch.zeros(3, 256, 1, 1), 'core.x.weight': torch.zeros(8, 8, 3, 3)}
+    c = dict(kind='km3d', offset_scale=0.25, hm_bias=-2.0, hm_hp_bias=-3.5, head_gain=0.5)
+    new, old = bench.other_config_state_dict(c, M()), bench.other_config_state_dict(c, M(), legacy=True)
+    assert torch.allclose(new['core.up.conv.conv_offset.weight'], 0.25 * old['core.up.conv.conv_offset.weight'])
+    assert torch.allclose(new['core.up.conv.conv_offset.bias'], 0.25 * old['core.up.conv.conv_offset.bias'])
+    assert float(new['bbox_head.head_layers.hm.2.bias'][0]) == -2.0 and float(new['bbox_head.head_layers.hm_hp.2.bias'][0]) == -3.5
+    assert torch.allclose(new['bbox_head.head_layers.hm.2.weight'], 0.5 * old['bbox_head.head_layers.hm.2.weight'])
+    assert torch.equal(new['core.x.weight'], old['core.x.weight'])
