@@ -112,6 +112,28 @@ def test_fused_bottleneck_at_config3_size_many_tiles_per_workgroup():
         assert float((d > 0).float().mean()) < 2e-2 and bool((d <= sep.float().abs() * 2.0 ** -6 + scale * 1e-3).all()), d.max().item()
 
 
+def test_fused_bottleneck_at_the_full_config3_batch():
+    """64 x 72 x 320 (config 3's stacked left / right batch: 755 MB of input, 11 520 tiles, 22.5 per workgroup): both variants against their separate launches --
+    byte offsets up to 2^29.5, every workgroup through many tiles and both ring parities."""
+    from visualdet3d_amd import hip_ops as ops
+    dt = torch.bfloat16
+    for ds in (False, True):
+        cin = 64 if ds else 256
+        P, g = _make(cin, ds, seed=13)
+        xd = (torch.randn(4, 72, 320, cin, generator=g).abs() * 0.8).cuda().to(dt).repeat(16, 1, 1, 1)
+        xd[1::2] *= 0.5                                   # (not 16 identical copies)
+        pc1, pc2, pc3, pcd = _packs(P, dt)
+        got = ops.conv2d_bottleneck(xd, pc1, pc2, pc3, pcd)
+        t2 = ops.conv2d(ops.conv2d(xd, pc1, relu=True), pc2, relu=True)
+        sep = ops.conv2d(t2, pc3, residual=ops.conv2d(xd, pcd, relu=False) if ds else xd, relu=True)
+        torch.cuda.synchronize()
+        d = (got.float() - sep.float()).abs()
+        scale = sep.float().abs().max().item()
+        assert float((d > 0).float().mean()) < 2e-2 and bool((d <= sep.float().abs() * 2.0 ** -6 + scale * 1e-3).all()), d.max().item()
+        del got, t2, sep, d
+        torch.cuda.empty_cache()
+
+
 def test_unsupported_shapes_are_refused():
     from visualdet3d_amd import _lib, hip_ops as ops
     P, g = _make(256, False, 3)
