@@ -512,13 +512,20 @@ def pin_to_gpu_numa_node(local_rank, n_local=None):
 
 class Stepper:
     """One configuration's timed step: warm-up, optional side-stream pass, hipGraph capture of `forward_device + pack`, then per
-    step: replay, copy the packed [B, KDET + 1, 13] record to pinned host memory, ONE host sync, check the counts."""
+    step: replay, copy the packed [B, KDET + 1, 13] record to pinned host memory (slot i & 1), ONE host sync, check the counts.
+    The host sync of step i is taken AFTER step i + 1 has been enqueued (the copy sits in front of the next replay on the same stream, so the
+    record is out before the replay overwrites it): the host's wake-up, its check and the graph launch no longer leave the GPU idle between
+    steps.  Every step's results are still read and checked inside the timed region (the last one behind the loop).  VD3D_BENCH_SYNC_EACH_STEP=1:
+    the round 1 - 5 loop (sync and check before the next replay is launched), for the A/B."""
 
     def __init__(self, model, inputs, B, device, use_graph=True, pre=None):
         from visualdet3d_amd import hip_ops
         self.model, self.inputs, self.B, self.pre = model, inputs, B, pre
         self.pack_static = torch.zeros((B, KDET + 1, 13), dtype=torch.float32, device=device)
         self.pinned = torch.empty((1, B, KDET + 1, 13), dtype=torch.float32).pin_memory()
+        self.pinned_ring = [self.pinned, torch.empty((1, B, KDET + 1, 13), dtype=torch.float32).pin_memory()]
+        self.copied = [torch.cuda.Event() for _ in range(2)]
+        self.sync_each_step = bool(os.environ.get('VD3D_BENCH_SYNC_EACH_STEP'))
         self.graph = None
 
         def step_device():
@@ -562,13 +569,24 @@ class Stepper:
 
     def run(self, n, before_step=None):
         counts = None
+        main = torch.cuda.current_stream()
         for i in range(n):
             if before_step is not None:
                 before_step(i)
             self.forward_step()
-            self.pinned[0].copy_(self.pack_static, non_blocking=True)      # device -> host copy of the step's results
-            torch.cuda.current_stream().synchronize()                       # the one host sync per step
-            counts = self.check(self.pinned)
+            s = 0 if self.sync_each_step else i & 1
+            self.pinned_ring[s][0].copy_(self.pack_static, non_blocking=True)   # device -> host copy of the step's results
+            if self.sync_each_step:
+                main.synchronize()
+                counts = self.check(self.pinned_ring[0])
+                continue
+            self.copied[s].record(main)
+            if i >= 1:
+                self.copied[s ^ 1].synchronize()                                # the one host sync per step: step i - 1's record is on the host
+                counts = self.check(self.pinned_ring[s ^ 1])
+        if n >= 1 and not self.sync_each_step:
+            self.copied[(n - 1) & 1].synchronize()
+            counts = self.check(self.pinned_ring[(n - 1) & 1])
         return counts
 
     def timed(self, steps, warmup, regions=3):
