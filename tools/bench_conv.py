@@ -37,6 +37,13 @@ SHAPES = [  # name, B, H, W, Cin, Cout
     ('r50 l2 up 1x1 128->512', 64, 36, 160, 128, 512, 1),
     ('r50 l3 up 1x1 256->1024', 64, 18, 80, 256, 1024, 1),
     ('c3 dcn gemm 1x1 19584->2176', 32, 18, 80, 19584, 2176, 1),       # config 3's column GEMM (K = 9 x 2176 sampled columns)
+    ('b1 head 1408->256', 1, 24, 80, 1408, 256),            # one frame per call (C1 / C2_B1_api): the layers that run on 128-pixel tiles with split-K
+    ('b1 cls 256->144', 1, 24, 80, 256, 144),
+    ('b1 neck 288->288', 1, 24, 80, 288, 288),
+    ('b1 ghost 384->384', 1, 24, 80, 384, 384),
+    ('b1 head 1024->256 mono', 1, 24, 80, 1024, 256),
+    ('b1 layer3 256->256', 2, 24, 80, 256, 256),
+    ('b1 layer4 512->512', 1, 12, 40, 512, 512),
 ]
 cfgs = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]
 

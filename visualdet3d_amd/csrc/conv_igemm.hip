@@ -501,9 +501,18 @@ VD3D_DEV void conv_epilogue_lines(const ConvArgs& p, f32x16 (&acc)[2][TM], const
 // tiles of 128 x 128 for 256 CUs -- run as tiles x splits workgroups over disjoint K ranges + one reduction pass (two launches, no
 // atomics: the partials are added in split order, results do not depend on scheduling).  KS = 0 instantiations compile to the code
 // they were before the parameter existed.
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int KS = 0, int STG = 0>
-__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(const ConvArgs p) {
+// KG = 2 (round 6): TWO K groups inside one workgroup.  Waves [0, NW) and [NW, 2 NW) are two copies of the NW-wave tile kernel on the SAME output tile:
+// each walks its own half of the K slices through its own pair of operand stages, with its own DMA pieces -- nothing is shared but the workgroup
+// barrier and, at the end, LDS: group 1 parks its accumulators, group 0 adds them (fixed order: deterministic) and runs the epilogue.  For layers whose
+// tiles fill the chip only ONCE with a 4-wave workgroup (config 2's 288 -> 288 neck convs: 240 tiles of 128 x 144; every deep layer of a batch-1 call):
+// one wave per SIMD has nobody to hide its DMA issue, fragment reads and barrier skew behind; split-K over workgroups gives the second wave too, but
+// pays fp32 partials through HBM and a reduction launch.  SIMD mates (w, w + NW) belong to different groups; with STG > 0 group 1 issues its pieces
+// at fragment STG (the staggered schedule of the strips).  MEASURED AND NOT SHIPPED (tuning build only, see plan_kgroups below): correct (every forced id
+// against the oracle on the awkward shapes of tests/test_conv_tiles_gpu.py), faster per launch in the micro-benchmark, no gain in any whole configuration.
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int KS = 0, int STG = 0, int KG = 1>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * KG * 64) conv_igemm_dma_kernel(const ConvArgs p) {
     constexpr int NW = WARPS_M * WARPS_N;
+    static_assert(KG == 1 || (KG == 2 && PIPE && !HEADF && STG < 100), "K groups: pipelined loop, plain epilogues");
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
     constexpr int BKE = 128 / ES;
@@ -519,7 +528,10 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     constexpr int A_STAGE = BM * 128, STAGE = (BM + BN) * 128;
     static_assert((BM / 8) % NW == 0 && BN % 16 == 0, "pixel rows must split evenly into 8-row pieces per wave");
     static_assert((8 * NW) % 16 == 0, "piece stride must keep the swizzle phase constant");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    // K group of this wave and the group's own operand stages (KG == 1: the whole workgroup, the whole buffer)
+    const int kg = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / (NW * 64)) : 0;
+    char* const smem = smem_raw + kg * (2 * STAGE);
 
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -542,7 +554,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int tid = threadIdx.x;
+    const int tid = (int)threadIdx.x - kg * (NW * 64);       // thread / wave index inside the K group
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
@@ -568,7 +580,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     // the epilogues read them with ds_read instead of two global loads per accumulator quad at the end of the tile
     // (requested here, written to LDS after the prologue's DMAs are issued: the wait for these two loads must not delay them)
     constexpr int TE = (BN + NW * 64 - 1) / (NW * 64);       // table entries per thread (1, or 2 for the 4-wave 288 / 352 strips)
-    float* ltab = (float*)(smem + 2 * (BM + BN) * 128);
+    float* ltab = (float*)(smem_raw + KG * 2 * (BM + BN) * 128);     // (both K groups write the same values)
     float tsc[TE], tsh[TE];
 #pragma unroll
     for (int u = 0; u < TE; ++u) {
@@ -632,10 +644,21 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     }
     const uint32_t w_row = (uint32_t)(((n0 + 8 * wave + prow) * p.Kpad + slot * VE) * ES);
     uint32_t w_off = w_row;
-    int nk_l = p.nk;                             // K slices this workgroup walks
-    if constexpr (KS) {
-        const int kt0 = split * p.ks_per;        // first slice of this split: put the walk's state there
-        nk_l = p.nk - kt0 < p.ks_per ? p.nk - kt0 : p.ks_per;
+    int nk_l = p.nk;                             // K slices this workgroup (K group) walks
+    int nk_loop = p.nk;                          // ... and the trip count of the slice loop (K groups: the same for both; a missing slice is zeros)
+    if constexpr (KS != 0 || KG > 1) {
+        int kt0 = 0;                             // first slice of this split / K group: put the walk's state there
+        if constexpr (KS) {
+            kt0 = split * p.ks_per;
+            nk_l = p.nk - kt0 < p.ks_per ? p.nk - kt0 : p.ks_per;
+        }
+        nk_loop = nk_l;
+        if constexpr (KG > 1) {
+            const int per = (nk_l + KG - 1) / KG, k0g = kg * per;
+            nk_loop = per;
+            kt0 += k0g;
+            nk_l = nk_l - k0g < per ? (nk_l - k0g > 0 ? nk_l - k0g : 0) : per;
+        }
         if (kt0 > 0) {
             if (p.chunk_major) {
                 const int chunk = kt0 / p.ntaps;
@@ -777,7 +800,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             return *(const i32x4*)(smem + st * STAGE + row * 128 + (((SPK * ks + half) ^ ((row >> 1) & 7)) << 4));
         };
 #pragma unroll
-        for (int g = 0; g < 4; ++g) issue_group(0, g);
+        for (int g = 0; g < 4; ++g) issue_group(0, g, KG == 1 || nk_l > 0);
         advance_k();
         // STG > 0 (experiment, round 4): the two waves of a SIMD (w and w + NW / 2) issue their DMA pieces at DIFFERENT points of the slice
         // -- behind the barrier both waves of a SIMD are in lock step, so both sat in their DMA bursts (60 - 185 issue cycles per piece, ten
@@ -785,7 +808,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         // fragment STG of slice t instead (its stage was freed by the barrier of slice t - 1), the lower half keeps the schedule below
         // STG < 100: two phases (upper half at fragment STG); STG = 100 + d: FOUR phases -- wave pairs (0,1) (2,3) (4,5) (6,7) at the base
         // schedule, d, 2d, 3d: SIMD mates (w, w + 4) are 2d fragments apart and the CU's texture path sees four bursts of 20 pieces
-        const int ph = STG >= 100 ? (wave >> 1) : (STG > 0 && wave >= NW / 2 ? 1 : 0);
+        const int ph = KG > 1 ? (STG > 0 ? kg : 0) : (STG >= 100 ? (wave >> 1) : (STG > 0 && wave >= NW / 2 ? 1 : 0));
         const bool hiw = ph != 0;
         if (!hiw) {
             issue_group(1, 0, nk_l > 1);
@@ -807,7 +830,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
         for (int j = 0; j < TM; ++j) fb[0][j] = ld_a(0, 0, j);
         constexpr int NMFMA = sizeof(T) == 2 ? TM : 4 * TM;               // MFMA instructions per weight fragment
         auto group_size = [](int g) { return (NPIECE - g + 3) / 4; };
-        for (int kt = 0; kt < nk_l; ++kt) {
+        for (int kt = 0; kt < nk_loop; ++kt) {
             const int st = kt & 1;
             const bool more1 = kt + 1 < nk_l, more2 = kt + 2 < nk_l;
 #pragma unroll
@@ -888,6 +911,37 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
             }
         }
     }
+    if constexpr (KG > 1) {
+        // the two K groups' partial sums meet in LDS (register order: one conflict-free 1 KiB row per vector and wave), at the END of the operand
+        // stages -- group 0's epilogue parks its output lines at the start
+        constexpr int AVK = MS * MS / 64 / 4, NVK = TN * TM * AVK;
+        constexpr int kRedOff = KG * 2 * STAGE - NW * NVK * 1024;
+        static_assert(kRedOff >= NW * 32 * 160 && kRedOff % 16 == 0, "K groups: the partial sums must not overlap the epilogue's line buffers");
+        f32x4* red = (f32x4*)(smem_raw + kRedOff) + wave * NVK * 64 + lane;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (disabled look-ahead pieces write zeros into the stages)
+        __syncthreads();                                      // every wave of both groups is done with the operand stages
+        if (kg == 1) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+#pragma unroll
+                    for (int v = 0; v < AVK; ++v)
+                        red[((i * TM + j) * AVK + v) * 64] = f32x4{acc[i][j][4 * v], acc[i][j][4 * v + 1], acc[i][j][4 * v + 2], acc[i][j][4 * v + 3]};
+        }
+        __syncthreads();
+        if (kg == 1) return;                                  // (no workgroup barrier below this point in a KG build)
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int v = 0; v < AVK; ++v) {
+                    const f32x4 q = red[((i * TM + j) * AVK + v) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * v + e] += q[e];
+                }
+    }
     int mrow[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -967,7 +1021,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     }
     if constexpr (MS == 32 && WTN == 64 && sizeof(T) == 2) {
         if (p.line_store) {          // (host: 16-bit output, Cout % 64 == 0, aligned rows -- every wave's 64-channel strip is whole)
-            __syncthreads();         // every wave is done with the operand stages
+            if constexpr (KG == 1) __syncthreads();         // every wave is done with the operand stages
             if (n0 + wn * WTN < p.Cout)
                 conv_epilogue_lines<T, TM>(p, acc, mrow, m0 + wm * WTM, n0 + wn * WTN, half, lr, lane, smem + wave * (32 * kLineRow), ltab, BN, n0);
             return;
@@ -976,7 +1030,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv_igemm_dma_kernel(c
     if constexpr (MS == 16 && WTN % 8 == 0 && !HEADF) {
         // strips: whole-line stores when the wave's channel strip lies inside Cout and the output rows are 16-byte aligned
         if (p.strip_lines) {
-            __syncthreads();         // every wave is done with the operand stages (workgroup-uniform branch)
+            if constexpr (KG == 1) __syncthreads();         // every wave is done with the operand stages (workgroup-uniform branch)
             if (n0 + wn * WTN + WTN <= p.Cout) {
                 conv_epilogue16_lines<T, TM, TN, WTN>(p, acc, mrow, m0 + wm * WTM, n0, n0 + wn * WTN, half, lr, lane,
                                                       smem + wave * (16 * (WTN * 2 + 16)), ltab, BN);
@@ -1190,15 +1244,15 @@ int launch_halo(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_halo");
 }
 
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int STG = 0>
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, bool DMA = false, bool PIPE = false, int MS = 32, int RING = 0, int ABL = 0, bool HEADF = false, int STG = 0, int KG = 1>
 int launch(ConvArgs& a, hipStream_t stream) {
-    constexpr int NT = WARPS_M * WARPS_N * 64;
-    constexpr int LDS = 2 * (BM + BN) * 128 + (HEADF ? 16384 + 1024 + 128 : (DMA ? 2 * BN * 4 : 0));    // + fused head: W2 fragments and biases; DMA tiles: scale | shift table
+    constexpr int NT = WARPS_M * WARPS_N * KG * 64;
+    constexpr int LDS = KG * 2 * (BM + BN) * 128 + (HEADF ? 16384 + 1024 + 128 : (DMA ? 2 * BN * 4 : 0));    // + fused head: W2 fragments and biases; DMA tiles: scale | shift table
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     static Vd3dLdsLimit lim;
     void (*kern)(const ConvArgs);
-    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL, HEADF, 0, STG>;
+    if constexpr (DMA) kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, ABL, HEADF, 0, STG, KG>;
     else kern = conv_igemm_kernel<T, BM, BN, WARPS_M, WARPS_N>;
     if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_igemm)")) return rc;
     const int64_t grid = (int64_t)a.tiles_m * a.tiles_n;
@@ -1208,7 +1262,7 @@ int launch(ConvArgs& a, hipStream_t stream) {
 }
 
 // ---- split-K (KS = 1 instantiations): two launches of the same kernel, phase 1 over tiles x splits, phase 2 over tiles -------------
-struct SplitPlan { int bn = 0; int splits = 1; int64_t ws_bytes = 0; };     // bn: 128 (128 x 128 tiles) | 64 (128 x 64), 0 = do not split
+struct SplitPlan { int bn = 0; int splits = 1; int64_t ws_bytes = 0; int kg = 1; };     // bn: 128 (128 x 128 tiles) | 64 (128 x 64) | 144 | 288, 0 = do not split; kg = 2: workgroups of two K groups
 
 // Low-parallelism shapes only: fewer 128-row tiles than ~1.2 x CUs (a batch-1 / batch-2 call at stride 16 or 32) AND a K deep enough
 // (>= 24 slices) that the extra reduction launch (~6 us) pays.  Splits fill two workgroup slots per CU, keep >= 4 slices per split.
@@ -1309,10 +1363,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const ConvArgs p, in
     }
 }
 
-template <typename T, int BN, int WARPS_M, int WARPS_N, bool PIPE, int BM = 128, int MS = 32, int RING = 0>
+template <typename T, int BN, int WARPS_M, int WARPS_N, bool PIPE, int BM = 128, int MS = 32, int RING = 0, int KG = 1>
 int launch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
-    constexpr int NT = WARPS_M * WARPS_N * 64;
-    constexpr int LDS = 2 * (BM + BN) * 128 + 2 * BN * 4;
+    constexpr int NT = WARPS_M * WARPS_N * KG * 64;
+    constexpr int LDS = KG * 2 * (BM + BN) * 128 + 2 * BN * 4;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.Cout + BN - 1) / BN;
     a.group_m = 0;
@@ -1320,7 +1374,7 @@ int launch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
     a.ks_per = (a.nk + pl.splits - 1) / pl.splits;
     a.ks_phase = 1;
     static Vd3dLdsLimit lim;
-    auto kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, 0, false, 1>;
+    auto kern = conv_igemm_dma_kernel<T, BM, BN, WARPS_M, WARPS_N, PIPE, MS, RING, 0, false, 1, 0, KG>;
     if (const int rc = vd3d_raise_lds_limit((const void*)kern, LDS, lim, "hipFuncSetAttribute(conv_igemm split-K)")) return rc;
     const int64_t tiles = (int64_t)a.tiles_m * a.tiles_n;
     if (tiles <= 0 || tiles * pl.splits > 0x7fffffff) return VD3D_EINVAL;
@@ -1368,6 +1422,54 @@ static SplitPlan plan_splitk_strip(const ConvArgs& a) {
     if (pl.ws_bytes > (256ll << 20)) return SplitPlan();
     return pl;
 }
+
+#ifdef VD3D_TUNING
+// EXPERIMENT (round 6, tuning build only; forced ids 145 / 176 / 147): workgroups of two K groups (conv_igemm_dma_kernel, KG = 2) as a general replacement of the
+// split over workgroups on 128-pixel tiles -- alone when the tiles fill at least half the chip, as phase 1 of a shallower split otherwise.  The micro-benchmark
+// (tools/bench_conv.py, back-to-back launches on dense random operands) liked it everywhere: batch 8: 1408 -> 256 849 (two-way split-K) -> 961 TF/s, 256 -> 144
+// 270 -> 397; one frame per call: 256 -> 144 63 -> 82, 288 -> 288 123 -> 145, 384 -> 384 191 -> 228, 1024 -> 256 307 -> 348, 512 -> 512 at 12 x 40 107 -> 136.  IN THE
+// MODEL it loses or does nothing: per-launch trace of the headline step 1408 -> 256 96.1 + 8.9 (reduce) -> 127.1 us, 256 -> 144 24.0 + 8.5 -> 38.5 us; whole
+// configurations, same box: C1 0.5016 / 0.5000 -> 0.5005 / 0.5036 ms per call, C2_B1_api 1.0929 / 1.0898 -> 1.0913 / 1.1006.  Only the 288 -> 288 neck convs
+// (forced id 173) keep their gain per launch (43.3 / 46.9 -> 37.8 / 41.0 us) -- and the step does not move (3.461 / 3.460 against 3.461 / 3.461 ms): that part
+// of the neck runs on the side stream under backbone layer3.  Nothing of this is in the product library.  profiles/r06_kgroups_ab.txt.
+static SplitPlan plan_kgroups(const ConvArgs& a, int bn, bool forced = false) {
+    SplitPlan pl;
+    const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
+    const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((a.Cout + bn - 1) / bn);
+    pl.bn = bn;
+    pl.kg = 2;
+    int sp = (int)(cus / tiles);
+    if (sp > a.nk / 8) sp = a.nk / 8;             // >= 4 slices per K group
+    if (sp > 16) sp = 16;
+    if (sp < 2) return pl;
+    const int per = (a.nk + sp - 1) / sp;
+    const int splits = (a.nk + per - 1) / per;    // every split is non-empty
+    if (splits < 2) return pl;
+    const int64_t ws = (int64_t)splits * tiles * 128 * bn * 4;
+    // a slice of a 128-pixel tile costs ~0.7 us; the reduction launch ~7 us + its partials written and read back at ~3 TB/s
+    const double saved_us = 0.7 * (a.nk - per), cost_us = 7.0 + 2.0 * (double)ws / 3.0e6;
+    if (!forced && saved_us <= cost_us) return pl;
+    pl.splits = splits;
+    pl.ws_bytes = ws;
+    return pl;
+}
+// (launches of a K-group plan: 16-bit formats)
+template <typename T>
+int dispatch_kgroups(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
+    if constexpr (sizeof(T) == 2) {
+        const bool split = pl.splits >= 2 && a.ks_ws && a.ks_ws_bytes >= pl.ws_bytes;      // (no scratch handed over: K groups alone)
+        if (pl.bn == 144) {
+            if (split) return launch_splitk<T, 144, 4, 1, true, 128, 16, 0, 2>(a, stream, pl);
+            return launch<T, 128, 144, 4, 1, true, true, 16, 0, 0, false, 0, 2>(a, stream);
+        }
+        if (split) return launch_splitk<T, 128, 2, 2, true, 128, 32, 0, 2>(a, stream, pl);
+        return launch<T, 128, 128, 2, 2, true, true, 32, 0, 0, false, 0, 2>(a, stream);
+    } else {
+        vd3d_set_error("conv2d_igemm: K-group tiles are 16-bit only");
+        return VD3D_EINVAL;
+    }
+}
+#endif
 
 template <typename T>
 int dispatch_splitk(ConvArgs& a, hipStream_t stream, const SplitPlan& pl) {
@@ -1535,6 +1637,24 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
                     default: return launch_regw(a, stream, VD3D_BF16, 2, 0);
                 }
             } else return forced_tile_error("is a bf16-only tile");
+        // workgroups of two K groups (KG = 2): 128 x 144 / 128 x 128 tiles alone (173 / 145), and as phase 1 of a split over workgroups (176 / 147)
+        case 173: VD3D_BF16_ONLY(launch<T, 128, 144, 4, 1, true, true, 16, 0, 0, false, 0, 2>(a, stream));
+        case 145: case 176: case 147: {
+            if constexpr (kBf16) {
+                const int bn = g_force_cfg == 176 ? 144 : 128;
+                SplitPlan pl = plan_kgroups(a, bn, true);
+                if (g_force_cfg == 145) { pl.splits = 1; pl.ws_bytes = 0; }
+                else {
+                    if (pl.splits < 2) return forced_tile_error("K groups + split-K: needs >= 16 K slices and 128-pixel tiles on at most half the CUs");
+                    if (!a.ks_ws || a.ks_ws_bytes < pl.ws_bytes) return forced_tile_error("split-K: workspace missing or too small (vd3d_conv2d_workspace_bytes)");
+                }
+                return dispatch_kgroups<T>(a, stream, pl);
+            } else return forced_tile_error("is a 16-bit-only tile");
+        }
+        // two K groups with the staggered DMA issue of the second group (measured slower than the plain schedule, ids 173 / 145)
+        case 174: VD3D_BF16_ONLY(launch<T, 128, 144, 4, 1, true, true, 16, 0, 0, false, 5, 2>(a, stream));
+        case 175: VD3D_BF16_ONLY(launch<T, 128, 144, 4, 1, true, true, 16, 0, 0, false, 9, 2>(a, stream));
+        case 146: VD3D_BF16_ONLY(launch<T, 128, 128, 2, 2, true, true, 32, 0, 0, false, 3, 2>(a, stream));
         case 1: return launch<T, 128, 128, 2, 2>(a, stream);
         case 2: return launch<T, 128, 128, 2, 2, true>(a, stream);
         case 8: return launch<T, 256, 256, 2, 4, true>(a, stream);
@@ -1834,6 +1954,9 @@ extern "C" int64_t vd3d_conv2d_workspace_bytes(const vd3d_conv_params* p) {
     q.splitk_ws = nullptr;
     if (fill_conv_args(&q, a)) return -1;
     if (g_force_cfg == 144 || g_force_cfg == 130) return plan_splitk(a, true).ws_bytes;
+#ifdef VD3D_TUNING
+    if (g_force_cfg == 147 || g_force_cfg == 176) return plan_kgroups(a, g_force_cfg == 147 ? 128 : 144, true).ws_bytes;
+#endif
     if (g_force_cfg != 0) return 0;
     // fp32 never splits under natural dispatch (see dispatch()); a shape one of the resident-weight / streaming kernels takes never splits
     if (p->dtype == VD3D_F32 || special_route(a) != ROUTE_NONE) return 0;
