@@ -236,3 +236,34 @@ def test_fused_stem_reads_the_fp32_image_directly(B0, B1, H, W):
     torch.cuda.synchronize()
     assert a.shape == b.shape == (B0 + B1, H // 4, W // 4, 64)
     assert torch.equal(a, b), (a.float() - b.float()).abs().max().item()
+
+
+def test_dwconv_runs_of_four_pixels_equal_the_one_pixel_kernel_bit_for_bit():
+    """vd3d_dwconv3x3 (round 6): a thread owns four output pixels of a row (weights / folded BN from LDS); `VD3D_DWCONV_PLAIN` is the one-pixel kernel.  Same taps
+    in the same order in fp32 -> identical bits: the ghost modules' shapes (24 channels at stride 4 as a slice of the 72-channel buffer, 96, 384), widths that are
+    not multiples of four, one-pixel-wide and one-row images, every storage type."""
+    from visualdet3d_amd import _lib, hip_ops as ops
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.bfloat16, torch.float16, torch.float32):
+        for (B, H, W, C, tot, off_in, off_out) in ((2, 24, 80, 24, 72, 24, 48), (1, 13, 37, 96, 288, 96, 192), (1, 7, 2, 384, 384, 0, 0), (2, 1, 9, 24, 24, 0, 0),
+                                                  (1, 5, 1, 8, 8, 0, 0), (8, 96, 320, 24, 72, 24, 48)):
+            w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+            bn = (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5, 1e-5)
+            pd = ops.pack_dwconv(w.cuda(), tuple(v.cuda() if torch.is_tensor(v) else v for v in bn))
+            buf = torch.randn(B, H, W, tot, generator=g).cuda().to(dtype)
+            src = buf[..., off_in:off_in + C]
+            same = off_in == off_out
+            outs = []
+            for plain in (False, True):
+                dst = torch.full((B, H, W, tot), 3.0, dtype=dtype, device='cuda')
+                o = dst[..., off_out:off_out + C]
+                if plain:
+                    with _lib.test_switch('VD3D_DWCONV_PLAIN'):
+                        ops.dwconv3x3(src, pd, out=o, relu=not same)
+                else:
+                    ops.dwconv3x3(src, pd, out=o, relu=not same)
+                torch.cuda.synchronize()
+                outs.append(dst)
+            assert torch.equal(outs[0], outs[1]), (dtype, B, H, W, C)
+            if tot > C:
+                assert bool((outs[0][..., :off_out] == 3.0).all()) and bool((outs[0][..., off_out + C:] == 3.0).all()), 'wrote outside its channel slice'

@@ -168,7 +168,7 @@ __device__ __forceinline__ int fastdiv(int n, FastDiv f) { return (int)((uint32_
 // per process (no getenv on the launch path, no race with setenv); tests flip them through vd3d_test_set_switch (test_hooks.h).
 enum Vd3dSwitch {
     VD3D_SW_CONV_DEBUG, VD3D_SW_FORCE_GROUP_M, VD3D_SW_NO_GROUP_M, VD3D_SW_NO_LINE_STORE, VD3D_SW_DCN_GENERIC,
-    VD3D_SW_DCN_COLUMNS_GENERIC, VD3D_SW_CONV3D_VALU, VD3D_SW_PSM_VALU, VD3D_SW_NO_NARROW, VD3D_SW_DWCONVT_GENERIC, VD3D_SW_HEAD_PARKED, VD3D_SW_STEM_WG4, VD3D_SW_HEAD_NO_STAGGER, VD3D_SW_CONV_NO_STAGGER, VD3D_SW_DCN_NO_LSTAGE, VD3D_SW_NO_STRIP_SPLIT, VD3D_SW_PLAIN_TILE_WALK, VD3D_SW_COUNT
+    VD3D_SW_DCN_COLUMNS_GENERIC, VD3D_SW_CONV3D_VALU, VD3D_SW_PSM_VALU, VD3D_SW_NO_NARROW, VD3D_SW_DWCONVT_GENERIC, VD3D_SW_HEAD_PARKED, VD3D_SW_STEM_WG4, VD3D_SW_HEAD_NO_STAGGER, VD3D_SW_CONV_NO_STAGGER, VD3D_SW_DCN_NO_LSTAGE, VD3D_SW_NO_STRIP_SPLIT, VD3D_SW_PLAIN_TILE_WALK, VD3D_SW_DWCONV_PLAIN, VD3D_SW_COUNT
 };
 bool vd3d_switch(Vd3dSwitch s);
 

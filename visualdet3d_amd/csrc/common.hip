@@ -23,7 +23,7 @@ int vd3d_check_launch(const char* what) {
 
 static const char* const kSwitchNames[VD3D_SW_COUNT] = {
     "VD3D_CONV_DEBUG", "VD3D_FORCE_GROUP_M", "VD3D_NO_GROUP_M", "VD3D_NO_LINE_STORE", "VD3D_DCN_GENERIC",
-    "VD3D_DCN_COLUMNS_GENERIC", "VD3D_CONV3D_VALU", "VD3D_PSM_VALU", "VD3D_NO_NARROW", "VD3D_DWCONVT_GENERIC", "VD3D_HEAD_PARKED", "VD3D_STEM_WG4", "VD3D_HEAD_NO_STAGGER", "VD3D_CONV_NO_STAGGER", "VD3D_DCN_NO_LSTAGE", "VD3D_NO_STRIP_SPLIT", "VD3D_PLAIN_TILE_WALK"};
+    "VD3D_DCN_COLUMNS_GENERIC", "VD3D_CONV3D_VALU", "VD3D_PSM_VALU", "VD3D_NO_NARROW", "VD3D_DWCONVT_GENERIC", "VD3D_HEAD_PARKED", "VD3D_STEM_WG4", "VD3D_HEAD_NO_STAGGER", "VD3D_CONV_NO_STAGGER", "VD3D_DCN_NO_LSTAGE", "VD3D_NO_STRIP_SPLIT", "VD3D_PLAIN_TILE_WALK", "VD3D_DWCONV_PLAIN"};
 static std::atomic<int> g_switch[VD3D_SW_COUNT];
 static std::once_flag g_switch_once;
 

@@ -159,6 +159,87 @@ __global__ void dwconv3x3_kernel(const T* __restrict__ in, const float* __restri
     }
 }
 
+// The same arithmetic (taps added row-major in fp32, a tap outside the image adds nothing: bit-identical to dwconv3x3_kernel) with a thread owning a RUN
+// of XR output pixels of one row and one 16-byte channel vector: 3 x (XR + 2) vector loads per XR outputs instead of 9 per output, weights and folded BN
+// from LDS instead of per-thread global loads.  (Round 6: the step is throughput bound -- tools/side_work_cost.py -- so the ghost modules' depth-wise
+// launches, 59 us of a headline step on the old kernel, count even on the side stream.)
+template <typename T, int XR>
+__global__ void __launch_bounds__(256) dwconv3x3_run_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ out, int B, int H, int W, int C,
+                                                            int ips, int ops, int relu) {
+    constexpr int VE = ElemTraits<T>::kVec;
+    extern __shared__ __attribute__((aligned(16))) float wl[];            // [9][C] weights | scale[C] | shift[C]
+    for (int i = threadIdx.x; i < 11 * C; i += blockDim.x) wl[i] = i < 9 * C ? w[i] : (i < 10 * C ? scale[i - 9 * C] : shift[i - 10 * C]);
+    __syncthreads();
+    const int cv = C / VE, xr = (W + XR - 1) / XR;
+    const int64_t total = (int64_t)B * H * xr * cv;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VE;
+        const int64_t r = i / cv;
+        const int xb = (int)(r % xr) * XR, y = (int)((r / xr) % H), b = (int)(r / ((int64_t)xr * H));
+        float s[XR][VE];
+#pragma unroll
+        for (int q = 0; q < XR; ++q)
+#pragma unroll
+            for (int e = 0; e < VE; ++e) s[q][e] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = y - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            const T* row = in + ((int64_t)b * H + iy) * W * ips + c;
+            Vec16<T> v[XR + 2];
+#pragma unroll
+            for (int j = 0; j < XR + 2; ++j) {
+                const int ix = xb - 1 + j;
+                if ((unsigned)ix < (unsigned)W) v[j].raw = *(const i32x4*)(row + (int64_t)ix * ips);
+                else v[j].raw = i32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                float wt[VE];
+#pragma unroll
+                for (int e4 = 0; e4 < VE; e4 += 4) {
+                    const f32x4 t4 = *(const f32x4*)(wl + (dy * 3 + dx) * C + c + e4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) wt[e4 + e] = t4[e];
+                }
+#pragma unroll
+                for (int q = 0; q < XR; ++q) {
+                    // (a tap left / right of the image holds zeros: fmaf(0, w, s) == s, the old kernel skipped it)
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) s[q][e] = fmaf(v[q + dx].get(e), wt[e], s[q][e]);
+                }
+            }
+        }
+        float sc[VE], sh[VE];
+#pragma unroll
+        for (int e4 = 0; e4 < VE; e4 += 4) {
+            const f32x4 a4 = *(const f32x4*)(wl + 9 * C + c + e4), b4 = *(const f32x4*)(wl + 10 * C + c + e4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[e4 + e] = a4[e]; sh[e4 + e] = b4[e]; }
+        }
+        T* orow = out + (((int64_t)b * H + y) * W + xb) * ops + c;
+#pragma unroll
+        for (int q = 0; q < XR; ++q) {
+            if (xb + q >= W) break;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) {
+                const float v1 = s[q][e] * sc[e] + sh[e];
+                s[q][e] = relu ? fmaxf(v1, 0.f) : v1;
+            }
+            Vec16<T> o;
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set2(e, s[q][2 * e], s[q][2 * e + 1]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o.set(e, s[q][e]);
+            }
+            *(i32x4*)(orow + (int64_t)q * ops) = o.raw;
+        }
+    }
+}
+
 template <typename T>
 __global__ void copy_channels_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t n_pix, int C, int ips, int ops) {
     constexpr int VE = ElemTraits<T>::kVec;
@@ -239,7 +320,16 @@ extern "C" int vd3d_avgpool2x2(const void* in, void* out, int B, int H, int W, i
 extern "C" int vd3d_dwconv3x3(const void* in, const float* weight, const float* scale, const float* shift, void* out,
                               int B, int H, int W, int C, int ips, int ops, int relu, int dtype, void* stream) {
     if (!vec_ok(dtype, C, ips, ops, in, out) || !weight || !scale || !shift) { vd3d_set_error("dwconv3x3: bad args"); return VD3D_EINVAL; }
-    const int64_t total = (int64_t)B * H * W * (C / (dtype == VD3D_F32 ? 4 : 8));
+    const int ve = dtype == VD3D_F32 ? 4 : 8;
+    if (C <= 1024 && !vd3d_switch(VD3D_SW_DWCONV_PLAIN)) {
+        // runs of four pixels per thread (VD3D_DWCONV_PLAIN=1: the one-pixel kernel, bit-identical; A/B)
+        constexpr int XR = 4;
+        const int64_t total = (int64_t)B * H * ((W + XR - 1) / XR) * (C / ve);
+        VD3D_DISPATCH(dtype, hipLaunchKernelGGL((dwconv3x3_run_kernel<T, XR>), dim3(grid_for(total)), dim3(kThreads), 11 * C * sizeof(float), (hipStream_t)stream,
+                                                 (const T*)in, weight, scale, shift, (T*)out, B, H, W, C, ips, ops, relu));
+        return vd3d_check_launch("dwconv3x3");
+    }
+    const int64_t total = (int64_t)B * H * W * (C / ve);
     VD3D_DISPATCH(dtype, hipLaunchKernelGGL(dwconv3x3_kernel<T>, dim3(grid_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                                              (const T*)in, weight, scale, shift, (T*)out, B, H, W, C, ips, ops, relu));
     return vd3d_check_launch("dwconv3x3");
