@@ -50,6 +50,11 @@ def parse():
                          'back; value / ms_per_step are the MEDIAN region, `spread` carries all of them (box-to-box and run-to-run noise is +-3 %%: '
                          'a single sample cannot carry a 1 %% claim)')
     ap.add_argument('--no-graph', action='store_true', help='launch kernels eagerly instead of replaying a hipGraph')
+    ap.add_argument('--in-flight', type=int, default=2, choices=[1, 2],
+                    help='steps in flight per GPU.  2 (default): two replicas of the detector (same weights; each its own hipGraph, static buffers and scratch) '
+                         'are replayed alternately on two streams, so that step i + 1 starts under the tail of step i (select / NMS on 8 CUs, pack, D2H) and its '
+                         'partially-filled rounds.  Every step is still one forward over `batch` pairs, read back and checked inside the timed region.  1: one '
+                         'replica, steps back to back (rounds 1 - 5; also reported in the line as `one_in_flight`).  --feed host / --no-graph run with 1.')
     ap.add_argument('--no-overlap', action='store_true',
                     help='no side streams (cls tower / stereo neck run serially on the main stream): the configuration whose '
                          'rocprofv3 --kernel-trace durations are additive (profiles/*_serial_*), NOT the headline configuration')
@@ -661,25 +666,30 @@ class HostFeed:
         self.upload(i + 1)
 
 
-def time_other_config(c, device, steps, warmup):
-    """-> the `other_configs` entry of one BASELINE configuration, or {'error': ...}."""
+def time_other_config(c, device, steps, warmup, in_flight=2):
+    """-> the `other_configs` entry of one BASELINE configuration, or {'error': ...}.  in_flight = 2: timed like the headline, two replicas of the detector
+    replayed alternately on two streams (`one_in_flight`: the same steps on one replica, one region)."""
     from visualdet3d_amd.networks.utils.registry import DETECTOR_DICT
     import visualdet3d_amd.networks.detectors  # noqa: F401
     from visualdet3d_amd.utils import synthetic as syn
     tmp = tempfile.mkdtemp()
-    if c['kind'] == 'stereo':
-        cfg = syn.stereo3d_cfg(tmp, depth=c['depth'], score_thr=c.get('score_thr', 0.75), nms_iou_thr=0.4)
-        syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
-        if c.get('dcn_head'):
-            from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3DBaseHead
-            m = Stereo3DBaseHead(cfg)
+
+    def make():
+        if c['kind'] == 'stereo':
+            cfg = syn.stereo3d_cfg(tmp, depth=c['depth'], score_thr=c.get('score_thr', 0.75), nms_iou_thr=0.4)
+            syn.write_synthetic_priors(tmp, cfg.obj_types, 3)
+            if c.get('dcn_head'):
+                from visualdet3d_amd.networks.detectors.yolostereo3d_detector import Stereo3DBaseHead
+                mm = Stereo3DBaseHead(cfg)
+            else:
+                mm = DETECTOR_DICT[cfg.name](cfg)
         else:
-            m = DETECTOR_DICT[cfg.name](cfg)
-    else:
-        cfg = syn.km3d_cfg(output_w=c['W'] // 4)
-        m = DETECTOR_DICT[cfg.name](cfg)
-    m = m.to(device).eval()
-    m.compute_dtype = torch.float16 if c['dtype'] == 'fp16' else torch.bfloat16
+            cfg = syn.km3d_cfg(output_w=c['W'] // 4)
+            mm = DETECTOR_DICT[cfg.name](cfg)
+        mm = mm.to(device).eval()
+        mm.compute_dtype = torch.float16 if c['dtype'] == 'fp16' else torch.bfloat16
+        return mm
+    m = make()
     B, H, W = c['B'], c['H'], c['W']
     P2, _ = syn.kitti_calib(W, batch=B)
     if c['kind'] == 'stereo':
@@ -700,7 +710,27 @@ def time_other_config(c, device, steps, warmup):
         torch.cuda.empty_cache()
     prepare_other_config(c, m, inputs)
     st = Stepper(m, inputs, B, device)
-    elapsed, all_s, counts = st.timed(steps, warmup)
+    one = None
+    if in_flight == 2:
+        m2 = make()
+        m2.load_state_dict(m.state_dict())           # the calibrated workload, a second time (weights are the only thing the replicas have in common)
+        reps = [(st, torch.cuda.Stream()), (Stepper(m2, inputs, B, device), torch.cuda.Stream())]
+        torch.cuda.synchronize()
+        run_in_flight(reps, warmup)
+        all_s = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            counts = run_in_flight(reps, steps)
+            torch.cuda.synchronize()
+            all_s.append(time.perf_counter() - t0)
+        elapsed = sorted(all_s)[1]
+        el1, _, _ = st.timed(steps, 2, regions=1)
+        one = dict(ms_per_step=round(el1 / steps * 1e3, 3), value=round(B * steps / el1, 2))
+        del reps, m2
+        torch.cuda.empty_cache()
+    else:
+        elapsed, all_s, counts = st.timed(steps, warmup)
     fam, dominant, _ = profile_ops(m, inputs, reps=3, verbose_env='VD3D_BENCH_LAYERS_OTHER')
     value = B * steps / elapsed
     # the single (family, layer shape) that costs the step most
@@ -713,7 +743,7 @@ def time_other_config(c, device, steps, warmup):
                  whole_path_frac=round(value * c['gf'] / 1e3 / PEAK_BF16_TFLOPS, 4), gflop_per_unit=c['gf'],
                  detections_last_step=int(counts.sum()), detections_per_frame=per_frame,
                  dcn_sampling=dict(profile_ops.dcn_sampling or {}, conv_offset_scale=c.get('offset_scale', 1.0)),
-                 legacy_workload=legacy,
+                 legacy_workload=legacy, in_flight=in_flight, one_in_flight=one,
                  families={k: dict(launches=int(round(v['launches'])), ms=round(v['secs'] * 1e3, 3),
                                    achieved_tflops=round(v['flops'] / v['secs'] / 1e12, 1) if v['flops'] else None,
                                    frac=round(v['flops'] / v['secs'] / 1e12 / PEAK_BF16_TFLOPS, 4) if v['flops'] else None)
@@ -795,6 +825,33 @@ def time_api_config(c, device, calls=100, warm=10):
     return entry
 
 
+def run_in_flight(reps, n):
+    """n steps over the replicas `reps` = [(Stepper, stream), ...], step i on replica i % len(reps): replay, copy the packed record to the replica's pinned
+    slot, record; the host waits for (and checks) step i - 1's record after step i is enqueued.  -> the counts of the last step."""
+    k = len(reps)
+    counts = None
+    lag = 1       # the host reads step i - 1 after enqueuing step i (reading 2 or 3 steps behind measured no different); a replica's two pinned slots alternate
+
+    def collect(i):
+        st = reps[i % k][0]
+        slot = (i // k) & 1
+        st.copied[slot].synchronize()
+        return st.check(st.pinned_ring[slot])
+
+    for i in range(n):
+        st, s = reps[i % k]
+        slot = (i // k) & 1
+        with torch.cuda.stream(s):
+            st.forward_step()
+            st.pinned_ring[slot][0].copy_(st.pack_static, non_blocking=True)
+            st.copied[slot].record(s)
+        if i >= lag:
+            counts = collect(i - lag)
+    for j in range(max(0, n - lag), n):
+        counts = collect(j)
+    return counts
+
+
 def main():
     args = parse()
     try:
@@ -838,12 +895,14 @@ def main():
     L, R, P2 = L.to(device), R.to(device), P2.to(device)   # inputs resident in HBM before the timed region
     inputs = (L, R, P2)
 
-    if os.environ.get('VD3D_BENCH_NONECK') or args.no_overlap:
-        model.core.overlap_neck = False
-    if os.environ.get('VD3D_BENCH_NOTOWER') or args.no_overlap:
-        model.bbox_head.overlap_towers = False
-    if os.environ.get('VD3D_BENCH_NOSELECT'):
-        model.bbox_head.overlap_select = False      # A/B: candidate selection after the towers instead of on the cls tower's stream
+    def apply_knobs(m):
+        if os.environ.get('VD3D_BENCH_NONECK') or args.no_overlap:
+            m.core.overlap_neck = False
+        if os.environ.get('VD3D_BENCH_NOTOWER') or args.no_overlap:
+            m.bbox_head.overlap_towers = False
+        if os.environ.get('VD3D_BENCH_NOSELECT'):
+            m.bbox_head.overlap_select = False      # A/B: candidate selection after the towers instead of on the cls tower's stream
+    apply_knobs(model)
     from visualdet3d_amd import hip_ops
 
     feed = None
@@ -863,6 +922,15 @@ def main():
 
     stepper = Stepper(model, inputs, B, device, use_graph=not args.no_graph, pre=feed.preprocess if feed else None)
     graph, pack_static = stepper.graph, stepper.pack_static
+    # Steps in flight: replica r = (its Stepper, the stream its steps are enqueued on).  One replica: the current stream, steps back to back.  Two: a second
+    # detector object with the same weights (nothing is shared between the two but the read-only inputs), each on its own stream; step i runs on replica i & 1.
+    n_fl = 1 if (feed or args.no_graph or graph is None) else args.in_flight
+    reps = [(stepper, torch.cuda.current_stream())]
+    if n_fl == 2:
+        model2 = build_model(args, device)[0]
+        apply_knobs(model2)
+        reps = [(stepper, torch.cuda.Stream()), (Stepper(model2, inputs, B, device), torch.cuda.Stream())]
+        torch.cuda.synchronize()
 
     # Results leave the device every step, inside the timed region: the packed record of the step (B x (KDET + 1) x 13 floats,
     # ~53 KB) is copied to pinned host memory and its counts are checked on the host.
@@ -874,49 +942,93 @@ def main():
     if dist:
         import torch.distributed as td
         from visualdet3d_amd.distributed import DetectionGather
-        gatherers = [DetectionGather(B, KDET, device, world) for _ in range(2)]
+        # ring of RD step slots (send buffer, events, pinned block).  One step in flight: RD = 2, the host reads step i - 1 after enqueuing step i (rounds 1 - 5).
+        # Two: RD = 4, the host-ordered loop in run() (VD3D_BENCH_COMM_STREAM=1: the GPU-ordered loop with two replicas, for the A/B).
+        RD = 2 * n_fl
+        lag = 1
+        host_ordered = n_fl == 2 and not os.environ.get('VD3D_BENCH_COMM_STREAM')
+        gatherers = [DetectionGather(B, KDET, device, world) for _ in range(RD)]
         comm_stream = torch.cuda.Stream()
-        packed_ev = [torch.cuda.Event() for _ in range(2)]
-        taken_ev = [torch.cuda.Event() for _ in range(2)]
-        done_ev = [torch.cuda.Event() for _ in range(2)]
-        pinned = [torch.empty((world, B, KDET + 1, 13), dtype=torch.float32).pin_memory() for _ in range(2)]
+        packed_ev = [torch.cuda.Event() for _ in range(RD)]
+        taken_ev = [torch.cuda.Event() for _ in range(RD)]
+        done_ev = [torch.cuda.Event() for _ in range(RD)]
+        pinned = [torch.empty((world, B, KDET + 1, 13), dtype=torch.float32).pin_memory() for _ in range(RD)]
     else:
         pinned = [stepper.pinned]
 
     def run(n):
         """n steps; returns the (host) detection counts [ranks, B] of the last one."""
         if not dist:
-            return stepper.run(n, before_step=feed.before_step if feed else None)
+            if n_fl == 1:
+                return stepper.run(n, before_step=feed.before_step if feed else None)
+            return run_in_flight(reps, n)
         counts = None
-        main = torch.cuda.current_stream()
 
         def collect(i):
-            done_ev[i & 1].synchronize()
-            return Stepper.check(pinned[i & 1])
+            done_ev[i % RD].synchronize()
+            return Stepper.check(pinned[i % RD])
+
+        if host_ordered:
+            # Two steps in flight.  A stream that WAITS on a replica's event for a whole forward (the comm stream of the loop below) stopped the two replays
+            # from overlapping (same box, world 1: 3.60 ms against 3.50 with no cross-stream wait at all; the collective on the replica's own stream is worse,
+            # 3.70: RCCL runs on its own stream and waits there).  So the HOST orders a step's collective behind its forward: the replica's stream copies the
+            # record into send buffer i % 4 and records; one step later the host has seen that event and enqueues gather + D2H on the comm stream, which waits
+            # on nothing; the block is read one more step later.  No GPU-side wait longer than the collective itself.
+            def tail(j):
+                q = j % RD
+                packed_ev[q].synchronize()
+                with torch.cuda.stream(comm_stream):
+                    t_s, t_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t_s.record(comm_stream)
+                    out = gatherers[q].gather()
+                    t_e.record(comm_stream)
+                    gather_ev.append((t_s, t_e))
+                    pinned[q].copy_(out, non_blocking=True)
+                    done_ev[q].record(comm_stream)
+
+            for i in range(n):
+                q = i % RD
+                st, main = reps[i % n_fl]
+                with torch.cuda.stream(main):
+                    st.forward_step()
+                    gatherers[q].pack.copy_(st.pack_static, non_blocking=True)
+                    packed_ev[q].record(main)
+                if i >= 1:
+                    tail(i - 1)
+                if i >= 2:
+                    counts = collect(i - 2)
+            if n >= 1:
+                tail(n - 1)
+            for j in range(max(0, n - 2), n):
+                counts = collect(j)
+            return counts
 
         for i in range(n):
-            g = gatherers[i & 1]
-            if i >= 1:
-                main.wait_event(taken_ev[(i - 1) & 1])       # step i-1's record has been copied out of the static buffer
-            if feed:
-                feed.before_step(i)
-            stepper.forward_step()
-            packed_ev[i & 1].record(main)
+            q = i % RD
+            g = gatherers[q]
+            st, main = reps[i % n_fl]
+            with torch.cuda.stream(main):
+                if i >= n_fl:
+                    main.wait_event(taken_ev[(i - n_fl) % RD])   # this replica's previous record (step i - n_fl) has been copied out of its static buffer
+                if feed:
+                    feed.before_step(i)
+                st.forward_step()
+                packed_ev[q].record(main)
             with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(packed_ev[i & 1])
-                g.pack.copy_(pack_static, non_blocking=True)
-                taken_ev[i & 1].record(comm_stream)
+                comm_stream.wait_event(packed_ev[q])
+                g.pack.copy_(st.pack_static, non_blocking=True)
+                taken_ev[q].record(comm_stream)
                 t_s, t_e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t_s.record(comm_stream)
                 out = g.gather()
                 t_e.record(comm_stream)
                 gather_ev.append((t_s, t_e))
-                pinned[i & 1].copy_(out, non_blocking=True)
-                done_ev[i & 1].record(comm_stream)
-            if i >= 1:
-                counts = collect(i - 1)
-        if n >= 1:
-            counts = collect(n - 1)
+                pinned[q].copy_(out, non_blocking=True)
+                done_ev[q].record(comm_stream)
+            if i >= lag:
+                counts = collect(i - lag)
+        for j in range(max(0, n - lag), n):
+            counts = collect(j)
         return counts
 
     dbg = bool(os.environ.get('VD3D_BENCH_DEBUG'))
@@ -954,7 +1066,14 @@ def main():
     assert counts is not None and float(counts.min()) >= 0, 'candidate overflow in the head post-processing'
     if os.environ.get('VD3D_BENCH_DUMP'):
         # test hook (tests/test_bench_dist_gpu.py): the last step's host-side results next to forward_device's own
-        torch.save(dict(host=pinned[(args.steps - 1) & 1 if dist else 0].clone(), direct=[t.cpu() for t in stepper.forward_step()],
+        last = args.steps - 1
+        if dist:
+            host_block = pinned[last % RD]
+        elif n_fl == 1:
+            host_block = stepper.pinned_ring[0 if stepper.sync_each_step else last & 1]
+        else:
+            host_block = reps[last % n_fl][0].pinned_ring[(last // n_fl) & 1]
+        torch.save(dict(host=host_block.clone(), direct=[t.cpu() for t in stepper.forward_step()],
                         inputs=[L.cpu(), R.cpu()] if feed else None),
                    os.environ['VD3D_BENCH_DUMP'])
 
@@ -994,6 +1113,7 @@ def main():
                                    % (args.height, args.width, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
                        'side_streams': not args.no_overlap, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world),
+                       'in_flight': n_fl,
                        'feed': args.feed if not feed else 'host: %d uint8 bytes uploaded per step and rank (2 x %d frames of %dx%dx3) + vd3d_preprocess_image inside the step'
                                % (feed.bytes_per_step, B, feed.HS, feed.WS)},
             'roofline': {'bound': 'mfma', 'kernel': 'vd3d_conv2d_igemm family: conv_igemm_dma / conv_halo / conv_resident64 / conv_regw / conv_ksplit256 / conv_small / conv_pw, split-K launches incl. their splitk_reduce (all %d vd3d_conv2d_igemm calls per step)' % nl,
@@ -1011,14 +1131,26 @@ def main():
         }
         if gather_us is not None:
             line['config']['all_gather_us_per_step_rank0'] = round(gather_us, 1)
+        if n_fl == 2:
+            # for the record: the same steps one at a time on replica 0 (this rank alone, no collective): rounds 1 - 5's loop
+            torch.cuda.synchronize()
+            stepper.run(args.warmup)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            stepper.run(args.steps)
+            torch.cuda.synchronize()
+            el1 = time.perf_counter() - t1
+            line['one_in_flight'] = {'ms_per_step': round(el1 / args.steps * 1e3, 3), 'value_this_rank': round(B * args.steps / el1, 2), 'unit': 'img/s',
+                                     'what': 'ONE replica, steps back to back on one stream (--in-flight 1), one timed region on rank 0 after the headline regions'}
         if world == 1 and not dist and not args.no_other_configs and args.feed == 'resident' and args.dtype == 'bf16' and not args.no_graph:
             # BASELINE configs 3 and 5 as stated, driver-observed: same rules, after the headline's timed region (~10 s extra)
             del stepper
+            del reps[:]                     # (the second replica's graph and buffers go too)
             torch.cuda.empty_cache()
             others = []
             for c in OTHER_CONFIGS:
                 try:
-                    others.append(time_other_config(c, device, steps=max(5, min(args.steps, 20)), warmup=max(2, min(args.warmup, 5))))
+                    others.append(time_other_config(c, device, steps=max(5, min(args.steps, 20)), warmup=max(2, min(args.warmup, 5)), in_flight=n_fl))
                 except Exception as e:      # noqa: BLE001  (an extra config must never take the headline line down with it)
                     others.append(dict(config=c['key'], workload=c['workload'], error='%s: %s' % (type(e).__name__, e)))
             for c in API_CONFIGS:               # batch-1 calls through the reference's own entry point

@@ -54,6 +54,37 @@ def test_bench_force_dist_gathers_the_detections_forward_device_returns(graph):
     assert total >= 8
 
 
+@pytest.mark.parametrize('steps,in_flight', [(4, 2), (3, 2), (4, 1)])
+def test_bench_in_flight_records_are_the_detections_forward_device_returns(steps, in_flight):
+    """`python bench.py` (one process, no collective): with two steps in flight (two replicas of the detector on two streams, the default) the LAST step's
+    host-side record -- replica (steps - 1) % 2, pinned slot ((steps - 1) // 2) & 1 -- holds exactly what `forward_device` returns, and the line says how many steps
+    were in flight and what one in flight measures."""
+    dump = os.path.join(tempfile.mkdtemp(), 'dump.pt')
+    env = dict(os.environ, VD3D_BENCH_DUMP=dump, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'VD3D_BENCH_FORCE_DIST'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--steps', str(steps), '--warmup', '2', '--no-cpu-baseline', '--no-other-configs', '--regions', '1',
+           '--in-flight', str(in_flight)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip())
+    assert line['config']['in_flight'] == in_flight and ('one_in_flight' in line) == (in_flight == 2)
+    if in_flight == 2:
+        assert line['one_in_flight']['ms_per_step'] > 0
+    d = torch.load(dump)
+    host = d['host']
+    scores, boxes, labels, aidx, count = d['direct']
+    k = host.shape[2] - 1
+    total = 0
+    for b in range(scores.shape[0]):
+        n = int(count[b])
+        assert n >= 0 and int(host[0, b, k, 0]) == n
+        assert torch.equal(host[0, b, :n, 0], scores[b, :n]) and torch.equal(host[0, b, :n, 1:12], boxes[b, :n])
+        assert torch.equal(host[0, b, :n, 12].long(), labels[b, :n].long()) and bool((host[0, b, n:k] == 0).all())
+        total += n
+    assert total >= 8
+
+
 def test_pack_detections_kernel_matches_host_pack():
     from visualdet3d_amd import distributed as vdist, hip_ops
     g = torch.Generator().manual_seed(0)
