@@ -54,7 +54,7 @@ def parse():
                     help='steps in flight per GPU.  2 (default): two replicas of the detector (same weights; each its own hipGraph, static buffers and scratch) '
                          'are replayed alternately on two streams, so that step i + 1 starts under the tail of step i (select / NMS on 8 CUs, pack, D2H) and its '
                          'partially-filled rounds.  Every step is still one forward over `batch` pairs, read back and checked inside the timed region.  1: one '
-                         'replica, steps back to back (rounds 1 - 5; also reported in the line as `one_in_flight`).  --feed host / --no-graph run with 1.')
+                         'replica, steps back to back (rounds 1 - 5; also reported in the line as `one_in_flight`).  --feed host / --no-graph / --no-overlap run with 1.')
     ap.add_argument('--no-overlap', action='store_true',
                     help='no side streams (cls tower / stereo neck run serially on the main stream): the configuration whose '
                          'rocprofv3 --kernel-trace durations are additive (profiles/*_serial_*), NOT the headline configuration')
@@ -924,7 +924,7 @@ def main():
     graph, pack_static = stepper.graph, stepper.pack_static
     # Steps in flight: replica r = (its Stepper, the stream its steps are enqueued on).  One replica: the current stream, steps back to back.  Two: a second
     # detector object with the same weights (nothing is shared between the two but the read-only inputs), each on its own stream; step i runs on replica i & 1.
-    n_fl = 1 if (feed or args.no_graph or graph is None) else args.in_flight
+    n_fl = 1 if (feed or args.no_graph or graph is None or args.no_overlap) else args.in_flight      # (--no-overlap: ONE stream, kernel durations additive)
     reps = [(stepper, torch.cuda.current_stream())]
     if n_fl == 2:
         model2 = build_model(args, device)[0]
