@@ -1,6 +1,6 @@
-"""EXPERIMENT: two headline steps in flight -- two replicas of the detector (same weights), each with its own hipGraph, static buffers and scratch, replayed
+"""EXPERIMENT (became bench.py --in-flight 2): K headline steps in flight -- two replicas of the detector (same weights), each with its own hipGraph, static buffers and scratch, replayed
 alternately on two streams: step i + 1 starts while step i's tail (select / NMS on 8 CUs, pack, D2H) and its partially-filled rounds still run.
-    python tools/two_in_flight.py        (ms per step: one in flight | two in flight, round-robin, same process)"""
+    python tools/two_in_flight.py [K]    (ms per step: one in flight | K in flight, round-robin, same process)"""
 import sys
 import time
 import types
@@ -18,7 +18,8 @@ def main():
     L, R = syn.stereo_pair(8, 384, 1280, seed=100)
     P2, _ = syn.kitti_calib(1280, batch=8)
     reps = []
-    for r in range(2):
+    K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    for r in range(K):
         model, cfg, sd = bench.build_model(args, dev)
         inputs = (L.to(dev).clone(), R.to(dev).clone(), P2.to(dev).clone())
         s = torch.cuda.Stream()
@@ -31,22 +32,7 @@ def main():
         return reps[0][0].run(n)
 
     def run_two(n):
-        counts = None
-        for i in range(n):
-            st, s = reps[i & 1]
-            with torch.cuda.stream(s):
-                st.forward_step()
-                st.pinned_ring[0][0].copy_(st.pack_static, non_blocking=True)
-                st.copied[0].record(s)
-            if i >= 1:
-                pst = reps[(i - 1) & 1][0]
-                pst.copied[0].synchronize()
-                counts = pst.check(pst.pinned_ring[0])
-        if n >= 1:
-            pst = reps[(n - 1) & 1][0]
-            pst.copied[0].synchronize()
-            counts = pst.check(pst.pinned_ring[0])
-        return counts
+        return bench.run_in_flight(reps, n)
 
     res = {'one': [], 'two': []}
     for rnd in range(4):
