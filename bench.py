@@ -690,6 +690,12 @@ def time_other_config(c, device, steps, warmup, in_flight=2):
         mm.compute_dtype = torch.float16 if c['dtype'] == 'fp16' else torch.bfloat16
         return mm
     m = make()
+
+    def forks(mm, on):
+        if hasattr(getattr(mm, 'core', None), 'overlap_neck'):
+            mm.core.overlap_neck = on
+        if hasattr(getattr(mm, 'bbox_head', None), 'overlap_towers'):
+            mm.bbox_head.overlap_towers = on
     B, H, W = c['B'], c['H'], c['W']
     P2, _ = syn.kitti_calib(W, batch=B)
     if c['kind'] == 'stereo':
@@ -709,12 +715,15 @@ def time_other_config(c, device, steps, warmup, in_flight=2):
         del st
         torch.cuda.empty_cache()
     prepare_other_config(c, m, inputs)
-    st = Stepper(m, inputs, B, device)
+    st = Stepper(m, inputs, B, device)           # (intra-step side streams on: the one-in-flight loop)
     one = None
     if in_flight == 2:
-        m2 = make()
-        m2.load_state_dict(m.state_dict())           # the calibrated workload, a second time (weights are the only thing the replicas have in common)
-        reps = [(st, torch.cuda.Stream()), (Stepper(m2, inputs, B, device), torch.cuda.Stream())]
+        side = bool(os.environ.get('VD3D_BENCH_SIDE_STREAMS'))
+        ms_ = [make(), make()]
+        for mm in ms_:
+            mm.load_state_dict(m.state_dict())       # the calibrated workload (weights are the only thing the replicas have in common)
+            forks(mm, side)                          # two in flight: every step a one-stream graph (see main())
+        reps = [(Stepper(mm, inputs, B, device), torch.cuda.Stream()) for mm in ms_]
         torch.cuda.synchronize()
         run_in_flight(reps, warmup)
         all_s = []
@@ -727,7 +736,7 @@ def time_other_config(c, device, steps, warmup, in_flight=2):
         elapsed = sorted(all_s)[1]
         el1, _, _ = st.timed(steps, 2, regions=1)
         one = dict(ms_per_step=round(el1 / steps * 1e3, 3), value=round(B * steps / el1, 2))
-        del reps, m2
+        del reps, ms_
         torch.cuda.empty_cache()
     else:
         elapsed, all_s, counts = st.timed(steps, warmup)
@@ -895,10 +904,17 @@ def main():
     L, R, P2 = L.to(device), R.to(device), P2.to(device)   # inputs resident in HBM before the timed region
     inputs = (L, R, P2)
 
-    def apply_knobs(m):
-        if os.environ.get('VD3D_BENCH_NONECK') or args.no_overlap:
+    # Intra-step side streams (neck s4 / s8 under backbone layer2 / layer3, cls tower next to the reg tower) fill a lone step's gaps; with TWO steps in flight the
+    # other step does that, and the forks only cost (same box, two in flight: 3.467 / 3.453 ms with them, 3.364 / 3.393 / 3.396 without the neck fork, 3.352 / 3.355 /
+    # 3.385 / 3.391 without any; one in flight: 3.66 with, 3.74 - 3.76 without).  So: two in flight = every step a ONE-stream graph (VD3D_BENCH_SIDE_STREAMS=1
+    # keeps the forks, for the A/B); one in flight = forks on (--no-overlap: off).
+    n_fl_wanted = 1 if (args.feed == 'host' or args.no_graph or args.no_overlap) else args.in_flight
+    no_forks = args.no_overlap or (n_fl_wanted == 2 and not os.environ.get('VD3D_BENCH_SIDE_STREAMS'))
+
+    def apply_knobs(m, no_forks=no_forks):
+        if os.environ.get('VD3D_BENCH_NONECK') or no_forks:
             m.core.overlap_neck = False
-        if os.environ.get('VD3D_BENCH_NOTOWER') or args.no_overlap:
+        if os.environ.get('VD3D_BENCH_NOTOWER') or no_forks:
             m.bbox_head.overlap_towers = False
         if os.environ.get('VD3D_BENCH_NOSELECT'):
             m.bbox_head.overlap_select = False      # A/B: candidate selection after the towers instead of on the cls tower's stream
@@ -1112,7 +1128,7 @@ def main():
             'config': {'workload': 'Stereo3D_example (YOLOStereo3D, ResNet-34) %dx%d stereo pairs, batch=%d per GPU'
                                    % (args.height, args.width, B),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world, 'hip_graph': graph is not None,
-                       'side_streams': not args.no_overlap, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world),
+                       'side_streams': not no_forks, 'results_d2h_bytes_per_step': int(pack_static.numel() * 4 * world),
                        'in_flight': n_fl,
                        'feed': args.feed if not feed else 'host: %d uint8 bytes uploaded per step and rank (2 x %d frames of %dx%dx3) + vd3d_preprocess_image inside the step'
                                % (feed.bytes_per_step, B, feed.HS, feed.WS)},
@@ -1132,16 +1148,21 @@ def main():
         if gather_us is not None:
             line['config']['all_gather_us_per_step_rank0'] = round(gather_us, 1)
         if n_fl == 2:
-            # for the record: the same steps one at a time on replica 0 (this rank alone, no collective): rounds 1 - 5's loop
+            # for the record: the same steps one at a time (this rank alone, no collective), with the intra-step side streams that suit a lone step: rounds
+            # 1 - 5's loop.  A third detector object for it (the replicas' graphs were captured without forks)
+            model1 = build_model(args, device)[0]
+            apply_knobs(model1, no_forks=False)
+            stepper1 = Stepper(model1, inputs, B, device)
             torch.cuda.synchronize()
-            stepper.run(args.warmup)
+            stepper1.run(args.warmup)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            stepper.run(args.steps)
+            stepper1.run(args.steps)
             torch.cuda.synchronize()
             el1 = time.perf_counter() - t1
+            del stepper1, model1
             line['one_in_flight'] = {'ms_per_step': round(el1 / args.steps * 1e3, 3), 'value_this_rank': round(B * args.steps / el1, 2), 'unit': 'img/s',
-                                     'what': 'ONE replica, steps back to back on one stream (--in-flight 1), one timed region on rank 0 after the headline regions'}
+                                     'what': 'ONE detector object, steps back to back, intra-step side streams on (--in-flight 1: the loop of rounds 1 - 5), one timed region on rank 0 after the headline regions'}
         if world == 1 and not dist and not args.no_other_configs and args.feed == 'resident' and args.dtype == 'bf16' and not args.no_graph:
             # BASELINE configs 3 and 5 as stated, driver-observed: same rules, after the headline's timed region (~10 s extra)
             del stepper
