@@ -8,6 +8,8 @@
 A step = one test_forward_batched-equivalent pass over one batch of synthetic pairs already resident in HBM:
 stem -> ResNet-34 (L and R stacked) -> cost volumes -> ghost pyramid -> head towers -> device-side decode/NMS ->
 (N > 1: RCCL all_gather of the padded detections, the only collective) -> one host sync for the counts.
+Two steps are in flight per GPU by default (--in-flight 2: two replicas of the detector with the same weights, step i on replica i & 1, each on its own stream;
+every step is still one forward over `batch` pairs whose record is read and checked inside the timed region; `one_in_flight` in the line = the steps one at a time).
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
 """
 import argparse

@@ -21,6 +21,9 @@ def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     for r in range(K):
         model, cfg, sd = bench.build_model(args, dev)
+        if K >= 2:                      # K in flight: one-stream graphs (bench.py main(): the intra-step forks cost there)
+            model.core.overlap_neck = False
+            model.bbox_head.overlap_towers = False
         inputs = (L.to(dev).clone(), R.to(dev).clone(), P2.to(dev).clone())
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
@@ -28,7 +31,7 @@ def main():
         torch.cuda.synchronize()
         reps.append((st, s))
 
-    def run_one(n):
+    def run_one(n):         # (replica 0 alone; with K >= 2 it has no intra-step forks: NOT bench.py's one_in_flight)
         return reps[0][0].run(n)
 
     def run_two(n):
