@@ -1261,6 +1261,23 @@ int launch(ConvArgs& a, hipStream_t stream) {
     return vd3d_check_launch("conv_igemm");
 }
 
+// EXPERIMENTS of the tuning build (environment variables read once; never in the product library): routing decisions that were taken for ONE step in flight,
+// re-tested with two (bench.py --in-flight 2), where a badly-filled round is filled by the other step.  VD3D_X_FILL_BLIND: a one-round tile choice is scored
+// without its fill, and the strips are not split to fill the chip; VD3D_X_NO_SMALL_SPLIT: no split over workgroups when the tiles already fill half the chip;
+// VD3D_X_L3_TILE: ResNet layer3 on 256 x 128 tiles also when they make one round.
+// MEASURED (headline, two in flight, same box, alternating, ms per step): none 3.462 / 3.469; FILL_BLIND 3.470 / 3.485; NO_SMALL_SPLIT 3.461 / 3.463; L3_TILE 3.470 / 3.436 --
+// nothing moves: the routes chosen for one step in flight stand.
+#ifdef VD3D_TUNING
+static bool x_flag(const char* name) { const char* v = getenv(name); return v && *v && *v != '0'; }
+static bool x_fill_blind() { static const bool f = x_flag("VD3D_X_FILL_BLIND"); return f; }
+static bool x_no_small_split() { static const bool f = x_flag("VD3D_X_NO_SMALL_SPLIT"); return f; }
+static bool x_l3_tile() { static const bool f = x_flag("VD3D_X_L3_TILE"); return f; }
+#else
+static constexpr bool x_fill_blind() { return false; }
+static constexpr bool x_no_small_split() { return false; }
+static constexpr bool x_l3_tile() { return false; }
+#endif
+
 // ---- split-K (KS = 1 instantiations): two launches of the same kernel, phase 1 over tiles x splits, phase 2 over tiles -------------
 struct SplitPlan { int bn = 0; int splits = 1; int64_t ws_bytes = 0; int kg = 1; };     // bn: 128 (128 x 128 tiles) | 64 (128 x 64) | 144 | 288, 0 = do not split; kg = 2: workgroups of two K groups
 
@@ -1274,6 +1291,7 @@ static SplitPlan plan_splitk(const ConvArgs& a, bool forced) {
     const int bn = a.Cout <= 64 ? 64 : 128;
     const int64_t tiles = (int64_t)((a.M + 127) / 128) * ((a.Cout + bn - 1) / bn);
     if (!forced && (a.nk < 24 || tiles * 10 > (int64_t)cus * 12)) return pl;
+    if (!forced && x_no_small_split() && tiles * 2 >= cus) return pl;
     if (a.nk < 2) return pl;
     int s = (int)((2 * (int64_t)cus) / tiles);
     if (s > a.nk / 4) s = a.nk / 4;
@@ -1407,6 +1425,7 @@ static SplitPlan plan_splitk_strip(const ConvArgs& a) {
         if (!(fill(tiles) < 0.8 && fill(2 * tiles) >= 0.9 && a.nk >= 160)) return pl;
         sp = 2;
     } else {
+        if (x_fill_blind() && tiles * 4 >= cus) return pl;
         sp = (int)(cus / tiles);
         if (sp > a.nk / 16) sp = a.nk / 16;
         if (sp > 16) sp = 16;
@@ -1536,7 +1555,7 @@ static bool tile256x128_fills(const ConvArgs& a) {
     if (a.Cout % 128 != 0 || a.out_f32) return false;
     const int cus = vd3d_device_cu_count() > 0 ? vd3d_device_cu_count() : 256;
     const int64_t tm = (a.M + 255) / 256, tiles = tm * (a.Cout / 128), rounds = (tiles + cus - 1) / cus;
-    return rounds >= 2 && (int64_t)a.M * 100 >= tm * 256 * 95 && tiles * 100 >= rounds * cus * 90;
+    return (rounds >= 2 || x_l3_tile()) && (int64_t)a.M * 100 >= tm * 256 * 95 && tiles * 100 >= rounds * cus * 90;
 }
 static SpecialRoute special_route(const ConvArgs& a) {
     if (a.Cin == 128 && regw_shape_ok(a)) return ROUTE_REGW;
@@ -1788,6 +1807,7 @@ int dispatch(ConvArgs& a, hipStream_t stream) {
         const double tm = (a.M + bm - 1) / bm, tn = (a.Cout + bn - 1) / bn;
         const double tiles = tm * tn;
         const double rounds = (double)((int64_t)((tiles + slots - 1) / slots));
+        if (x_fill_blind() && rounds == 1.0 && tiles * 4 >= slots) return ((double)a.M * a.Cout) / (tm * bm * tn * bn);
         return ((double)a.M * a.Cout) / (tm * bm * tn * bn) * tiles / (rounds * slots);
     };
     double best = 1000.0 * util(128, 128, kSlots2);
