@@ -27,6 +27,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+from visualdet3d_amd.networks.pipelines.in_flight import CapturedStep, InFlight  # noqa: E402
+
 GFLOP_PER_PAIR = 473.82          # conv/GEMM 2*MAC per 384x1280 pair (Stereo3D R34)
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
@@ -517,96 +519,15 @@ def pin_to_gpu_numa_node(local_rank, n_local=None):
         return 'not pinned (%s)' % e
 
 
-class Stepper:
-    """One configuration's timed step: warm-up, optional side-stream pass, hipGraph capture of `forward_device + pack`, then per
-    step: replay, copy the packed [B, KDET + 1, 13] record to pinned host memory (slot i & 1), ONE host sync, check the counts.
-    The host sync of step i is taken AFTER step i + 1 has been enqueued (the copy sits in front of the next replay on the same stream, so the
-    record is out before the replay overwrites it): the host's wake-up, its check and the graph launch no longer leave the GPU idle between
-    steps.  Every step's results are still read and checked inside the timed region (the last one behind the loop).  VD3D_BENCH_SYNC_EACH_STEP=1:
-    the round 1 - 5 loop (sync and check before the next replay is launched), for the A/B."""
+class Stepper(CapturedStep):
+    """One configuration's timed step = `visualdet3d_amd.networks.pipelines.in_flight.CapturedStep` (two warm-up passes, hipGraph capture of `forward_device` +
+    pack; per step: replay, copy the packed [B, KDET + 1, 13] record to a pinned slot, ONE host sync -- taken after the next step is enqueued -- and a check of
+    the counts) with this file's record size and A/B switches: VD3D_BENCH_SYNC_EACH_STEP=1 = the round 1 - 5 loop (sync and check before the next replay is
+    launched), VD3D_BENCH_NOSIDE=1 = no pass off the default stream before the capture."""
 
     def __init__(self, model, inputs, B, device, use_graph=True, pre=None):
-        from visualdet3d_amd import hip_ops
-        self.model, self.inputs, self.B, self.pre = model, inputs, B, pre
-        self.pack_static = torch.zeros((B, KDET + 1, 13), dtype=torch.float32, device=device)
-        self.pinned = torch.empty((1, B, KDET + 1, 13), dtype=torch.float32).pin_memory()
-        self.pinned_ring = [self.pinned, torch.empty((1, B, KDET + 1, 13), dtype=torch.float32).pin_memory()]
-        self.copied = [torch.cuda.Event() for _ in range(2)]
-        self.sync_each_step = bool(os.environ.get('VD3D_BENCH_SYNC_EACH_STEP'))
-        self.graph = None
-
-        def step_device():
-            """One step on the device: (host feed: preprocessing of the uploaded frames,) the whole forward incl. decode + NMS,
-            then ONE launch that packs the padded results (scores, boxes, labels, per-frame count) into the record."""
-            if self.pre is not None:
-                self.pre()
-            out = model.forward_device(*inputs)
-            hip_ops.pack_detections(out[0], out[1], out[2], out[-1], KDET, out=self.pack_static)
-            return out
-
-        self.step_device = step_device
-        with torch.no_grad():
-            for _ in range(2):                       # packs weights, builds anchor tables, warms the allocator
-                self.static_out = step_device()
-            torch.cuda.synchronize()
-            if use_graph:
-                if not os.environ.get('VD3D_BENCH_NOSIDE'):
-                    side = torch.cuda.Stream()
-                    side.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side):
-                        step_device()
-                    torch.cuda.current_stream().wait_stream(side)
-                self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph):
-                    self.static_out = step_device()
-
-    def forward_step(self):
-        if self.graph is not None:
-            self.graph.replay()
-            return self.static_out
-        with torch.no_grad():
-            return self.step_device()
-
-    @staticmethod
-    def check(host_block):
-        """host_block [ranks, B, KDET + 1, 13] (pinned): per-frame counts ride in row KDET."""
-        c = host_block[:, :, KDET, 0]
-        assert float(c.min()) >= 0, 'candidate overflow in the head post-processing'
-        return c.clone()
-
-    def run(self, n, before_step=None):
-        counts = None
-        main = torch.cuda.current_stream()
-        for i in range(n):
-            if before_step is not None:
-                before_step(i)
-            self.forward_step()
-            s = 0 if self.sync_each_step else i & 1
-            self.pinned_ring[s][0].copy_(self.pack_static, non_blocking=True)   # device -> host copy of the step's results
-            if self.sync_each_step:
-                main.synchronize()
-                counts = self.check(self.pinned_ring[0])
-                continue
-            self.copied[s].record(main)
-            if i >= 1:
-                self.copied[s ^ 1].synchronize()                                # the one host sync per step: step i - 1's record is on the host
-                counts = self.check(self.pinned_ring[s ^ 1])
-        if n >= 1 and not self.sync_each_step:
-            self.copied[(n - 1) & 1].synchronize()
-            counts = self.check(self.pinned_ring[(n - 1) & 1])
-        return counts
-
-    def timed(self, steps, warmup, regions=3):
-        """-> (median seconds of `regions` back-to-back timed regions of `steps` steps, every region's seconds, last counts)"""
-        self.run(warmup)
-        all_s, counts = [], None
-        for _ in range(regions):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            counts = self.run(steps)
-            torch.cuda.synchronize()
-            all_s.append(time.perf_counter() - t0)
-        return sorted(all_s)[len(all_s) // 2], all_s, counts
+        super().__init__(model, inputs, B, device, k=KDET, use_graph=use_graph, pre=pre, side_pass=not os.environ.get('VD3D_BENCH_NOSIDE'),
+                         sync_each_step=bool(os.environ.get('VD3D_BENCH_SYNC_EACH_STEP')))
 
 
 class HostFeed:
@@ -837,30 +758,9 @@ def time_api_config(c, device, calls=100, warm=10):
 
 
 def run_in_flight(reps, n):
-    """n steps over the replicas `reps` = [(Stepper, stream), ...], step i on replica i % len(reps): replay, copy the packed record to the replica's pinned
-    slot, record; the host waits for (and checks) step i - 1's record after step i is enqueued.  -> the counts of the last step."""
-    k = len(reps)
-    counts = None
-    lag = 1       # the host reads step i - 1 after enqueuing step i (reading 2 or 3 steps behind measured no different); a replica's two pinned slots alternate
-
-    def collect(i):
-        st = reps[i % k][0]
-        slot = (i // k) & 1
-        st.copied[slot].synchronize()
-        return st.check(st.pinned_ring[slot])
-
-    for i in range(n):
-        st, s = reps[i % k]
-        slot = (i // k) & 1
-        with torch.cuda.stream(s):
-            st.forward_step()
-            st.pinned_ring[slot][0].copy_(st.pack_static, non_blocking=True)
-            st.copied[slot].record(s)
-        if i >= lag:
-            counts = collect(i - lag)
-    for j in range(max(0, n - lag), n):
-        counts = collect(j)
-    return counts
+    """n steps over the replicas `reps` = [(Stepper, stream), ...], step i on replica i % len(reps): `InFlight.run` -- replay, copy the packed record to the replica's
+    pinned slot, record; the host waits for (and checks) step i - 1's record after step i is enqueued.  -> the counts of the last step."""
+    return InFlight([st for st, _ in reps], [s for _, s in reps]).run(n)
 
 
 def main():
@@ -984,7 +884,7 @@ def main():
 
         def collect(i):
             done_ev[i % RD].synchronize()
-            return Stepper.check(pinned[i % RD])
+            return stepper.check(pinned[i % RD])
 
         if host_ordered:
             # Two steps in flight.  A stream that WAITS on a replica's event for a whole forward (the comm stream of the loop below) stopped the two replays
