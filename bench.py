@@ -642,7 +642,7 @@ def time_other_config(c, device, steps, warmup, in_flight=2):
     one = None
     if in_flight == 2:
         side = bool(os.environ.get('VD3D_BENCH_SIDE_STREAMS'))
-        ms_ = [make(), make()]
+        ms_ = [make() for _ in range(int(os.environ.get('VD3D_BENCH_REPLICAS', '2')))]      # (more than two: measured no better, tools/two_in_flight.py)
         for mm in ms_:
             mm.load_state_dict(m.state_dict())       # the calibrated workload (weights are the only thing the replicas have in common)
             forks(mm, side)                          # two in flight: every step a one-stream graph (see main())
