@@ -11,6 +11,17 @@ stem -> ResNet-34 (L and R stacked) -> cost volumes -> ghost pyramid -> head tow
 Two steps are in flight per GPU by default (--in-flight 2: two replicas of the detector with the same weights, step i on replica i & 1, each on its own stream;
 every step is still one forward over `batch` pairs whose record is read and checked inside the timed region; `one_in_flight` in the line = the steps one at a time).
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` and `cpu_baseline`.
+
+Environment knobs (A/B and diagnostics; none is needed for the contract run):
+  VD3D_BENCH_FORCE_DIST=1      the RCCL path at world 1 (process group, collective, host-ordered loop)
+  VD3D_BENCH_COMM_STREAM=1     two in flight with the GPU-ordered comm-stream loop of rounds 1 - 5 (the default orders the collective from the host)
+  VD3D_BENCH_SIDE_STREAMS=1    two in flight WITH the intra-step side streams (default: the replicas are one-stream graphs)
+  VD3D_BENCH_REPLICAS=k        k replicas for configs 3 / 5 (default 2)
+  VD3D_BENCH_SYNC_EACH_STEP=1  one in flight: host sync and check BEFORE the next replay is launched (rounds 1 - 5)
+  VD3D_BENCH_NONECK / NOTOWER / NOSELECT=1   single intra-step forks off;  VD3D_BENCH_NOSIDE=1  no side pass before the capture
+  VD3D_BENCH_NO_LEGACY=1       skip the round-5 workload of configs 3 / 5;  VD3D_BENCH_SEED=n  input seed
+  VD3D_BENCH_DUMP=path         (tests) the last step's host record next to forward_device's own results
+  VD3D_BENCH_LAYERS / VD3D_BENCH_LAYERS_OTHER / VD3D_BENCH_DEBUG=1   per-launch tables / progress on stderr
 """
 import argparse
 import ctypes
