@@ -705,7 +705,9 @@ constexpr int kKsRedOff = kKsNst * kKsStage;                                    
 constexpr int kKsSsOff = kKsRedOff + 2 * 3 * 8192;
 constexpr int kKsLds = kKsSsOff + 512;
 
-template <typename T, bool RES>
+// ABL != 0: timing ablations of the tuning build (WRONG results by construction; VD3D_X_KSPLIT_ABL): 1 = every second pixel-fragment read dropped (the LDS
+// traffic of a wave that owned 64 channels x half a chunk), 2 = no pixel-fragment reads in the tile loop, 3 = no K reduction through LDS, 4 = no MFMAs.
+template <typename T, bool RES, int ABL = 0>
 __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, int ntiles, int nslices) {
     constexpr int PIECES = 4 * kKsImgPieces;       // 52 per stage
     constexpr int P = (PIECES + 7) / 8;            // 7 per wave (overshoot repeats the wave's previous piece)
@@ -813,12 +815,18 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
                 issue_halo(t + 2 * tstride, stage);
             }
             constexpr int f = m >> 1, j = m & 1;
-            if constexpr (f == 0) {
+            if constexpr (ABL == 4) {
+                if constexpr (f == 0) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[j][e] = __builtin_bit_cast(float, ring[m % RING][e & 3]);
+                }
+            } else if constexpr (f == 0) {
                 const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 Fmt16<T>::mfma32z(wf[0], ring[m % RING], zero, acc[j]);
             } else
                 Fmt16<T>::mfma32(wf[f], ring[m % RING], acc[j]);
-            ring[m % RING] = m + RING < 72 ? ld_frag(stage, m + RING) : ld_frag(stage ^ 1, m + RING - 72);
+            if constexpr (ABL == 0 || ABL >= 3 || (ABL == 1 && (m & 2) == 0))
+                ring[m % RING] = m + RING < 72 ? ld_frag(stage, m + RING) : ld_frag(stage ^ 1, m + RING - 72);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         });
@@ -843,7 +851,7 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
                 }
             }
         }
-        if (!own) {
+        if (ABL != 3 && !own) {
             char* mine = red + ((kq - owner - 1) & 3) * 8192;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -864,7 +872,7 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
                 for (int g = 0; g < 4; ++g) {
                     float v[4] = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
 #pragma unroll
-                    for (int w = 0; w < 3; ++w) {
+                    for (int w = 0; w < (ABL == 3 ? 0 : 3); ++w) {
                         const f32x4 q = *(const f32x4*)(red + w * 8192 + ((j * 4 + g) * 64 + lane) * 16);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += q[e];
@@ -1575,6 +1583,17 @@ bool ksplit_shape_ok(const ConvArgs& a) {
            (int64_t)a.M * a.out_pix_stride * 2 < 0x7ffffff0ll && (!a.residual || (int64_t)a.M * a.res_pix_stride * 2 < 0x7ffffff0ll);
 }
 
+#ifdef VD3D_TUNING
+static int ksplit_abl() { static const int v = getenv("VD3D_X_KSPLIT_ABL") ? atoi(getenv("VD3D_X_KSPLIT_ABL")) : 0; return v; }
+template <typename T, int ABL>
+static int launch_ksplit_abl(ConvArgs& a, hipStream_t stream, int grid, int ntiles, int nslices) {
+    static Vd3dLdsLimit lim;
+    if (const int rc = vd3d_raise_lds_limit((const void*)conv_ksplit256_kernel<T, true, ABL>, kKsLds, lim, "hipFuncSetAttribute(conv_ksplit256 abl)")) return rc;
+    hipLaunchKernelGGL((conv_ksplit256_kernel<T, true, ABL>), dim3(grid), dim3(512), kKsLds, stream, a, ntiles, nslices);
+    return vd3d_check_launch("conv_ksplit256 abl");
+}
+#endif
+
 template <typename T>
 static int launch_ksplit_t(ConvArgs& a, hipStream_t stream) {
     static Vd3dLdsLimit lim_res, lim_nores;
@@ -1590,6 +1609,16 @@ static int launch_ksplit_t(ConvArgs& a, hipStream_t stream) {
     if (lanes > need) lanes = need;
     if (lanes < 1) lanes = 1;
     const int grid = 8 * lanes * nslices;
+#ifdef VD3D_TUNING
+    if (a.residual && ksplit_abl() > 0) {       // timing ablations (the residual variant only)
+        switch (ksplit_abl()) {
+            case 1: return launch_ksplit_abl<T, 1>(a, stream, grid, ntiles, nslices);
+            case 2: return launch_ksplit_abl<T, 2>(a, stream, grid, ntiles, nslices);
+            case 3: return launch_ksplit_abl<T, 3>(a, stream, grid, ntiles, nslices);
+            default: return launch_ksplit_abl<T, 4>(a, stream, grid, ntiles, nslices);
+        }
+    }
+#endif
     if (a.residual) hipLaunchKernelGGL((conv_ksplit256_kernel<T, true>), dim3(grid), dim3(512), kKsLds, stream, a, ntiles, nslices);
     else hipLaunchKernelGGL((conv_ksplit256_kernel<T, false>), dim3(grid), dim3(512), kKsLds, stream, a, ntiles, nslices);
     return vd3d_check_launch("conv_ksplit256");
