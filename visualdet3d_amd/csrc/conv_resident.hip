@@ -706,7 +706,8 @@ constexpr int kKsSsOff = kKsRedOff + 2 * 3 * 8192;
 constexpr int kKsLds = kKsSsOff + 512;
 
 // ABL != 0: timing ablations of the tuning build (WRONG results by construction; VD3D_X_KSPLIT_ABL): 1 = every second pixel-fragment read dropped (the LDS
-// traffic of a wave that owned 64 channels x half a chunk), 2 = no pixel-fragment reads in the tile loop, 3 = no K reduction through LDS, 4 = no MFMAs.
+// traffic of a wave that owned 64 channels x half a chunk), 2 = no pixel-fragment reads in the tile loop, 3 = no K reduction through LDS, 4 = no MFMAs,
+// 5 = no owner epilogue (no residual loads, no partial reads, no stores), 6 = no halo DMA in the tile loop, 7 = no barriers in the tile loop, 8 = 5 + 6 + 7.
 template <typename T, bool RES, int ABL = 0>
 __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, int ntiles, int nslices) {
     constexpr int PIECES = 4 * kKsImgPieces;       // 52 per stage
@@ -810,9 +811,9 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
                 // all reads of this stage are issued (and, with lgkmcnt(0), done); the next tile's halos (issued one tile ago) must
                 // have landed.  The queue differs per wave (residual loads / stores of the owners): drain it.
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if constexpr (ABL != 7 && ABL != 8) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                issue_halo(t + 2 * tstride, stage);
+                if constexpr (ABL != 6 && ABL != 8) issue_halo(t + 2 * tstride, stage);
             }
             constexpr int f = m >> 1, j = m & 1;
             if constexpr (ABL == 4) {
@@ -836,7 +837,7 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
         // of the tile would hold 16 registers through the MFMA loop and spill)
         uint32_t o_off[2];
         i32x2 rr[2][4];
-        if (own) {
+        if (own && ABL != 5 && ABL != 8) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int y = ty * kKsTH + 4 * j + lr / kKsTW, x = tx * kKsTW + (lr & (kKsTW - 1));
@@ -862,9 +863,9 @@ __global__ void __launch_bounds__(512) conv_ksplit256_kernel(const ConvArgs p, i
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (ABL != 7 && ABL != 8) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (own) {
+        if (own && ABL != 5 && ABL != 8) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 int pk[4][2];
@@ -1615,6 +1616,10 @@ static int launch_ksplit_t(ConvArgs& a, hipStream_t stream) {
             case 1: return launch_ksplit_abl<T, 1>(a, stream, grid, ntiles, nslices);
             case 2: return launch_ksplit_abl<T, 2>(a, stream, grid, ntiles, nslices);
             case 3: return launch_ksplit_abl<T, 3>(a, stream, grid, ntiles, nslices);
+            case 5: return launch_ksplit_abl<T, 5>(a, stream, grid, ntiles, nslices);
+            case 6: return launch_ksplit_abl<T, 6>(a, stream, grid, ntiles, nslices);
+            case 7: return launch_ksplit_abl<T, 7>(a, stream, grid, ntiles, nslices);
+            case 8: return launch_ksplit_abl<T, 8>(a, stream, grid, ntiles, nslices);
             default: return launch_ksplit_abl<T, 4>(a, stream, grid, ntiles, nslices);
         }
     }
