@@ -44,7 +44,8 @@ def _batches(n, B, H, W):
 def _direct(m, batch, k):
     """the synchronous answer: forward_device on a lone object, unpadded"""
     with torch.no_grad():
-        scores, boxes, labels, _, count = m.forward_device(*batch)
+        out = m.forward_device(*batch)
+        scores, boxes, labels, count = out[0], out[1], out[2], out[-1]          # (the anchor heads return the anchor indices too)
     torch.cuda.synchronize()
     res = []
     for b in range(scores.shape[0]):
@@ -97,3 +98,37 @@ def test_run_on_static_inputs_counts_and_slot_lifetime():
         pipe.submit()
     with pytest.raises(AssertionError):
         pipe.collect(t)                                                 # 2 x replicas later the slot has been rewritten
+
+
+@pytest.mark.parametrize('name', ['groundaware_r34_96x320', 'km3d_dla34_96x320'])
+def test_monocular_detectors_in_flight(name):
+    """The same API over the monocular detectors (`forward_device(img, P2)`): GroundAwareYolo3D and the KM3D keypoint detector, two replicas, a different batch per step."""
+    from tests.common import load_golden, mono_case_from_golden
+    from visualdet3d_amd.networks.pipelines.in_flight import CapturedStep, InFlight
+    from visualdet3d_amd.networks.utils.registry import DETECTOR_DICT
+    import visualdet3d_amd.networks.detectors  # noqa: F401
+    from visualdet3d_amd.utils import synthetic as syn
+    g = load_golden(name)
+    if name.startswith('km3d'):
+        cfg = syn.km3d_cfg(output_w=320 // 4)
+        winit = dict(seed=int(g['meta'][4]), head_std=float(g['head_std'])) if 'head_std' in g else dict(seed=1)
+    else:
+        cfg, _, winit = mono_case_from_golden(g, name)
+    ms, sd = [], None
+    for i in range(3):
+        m = DETECTOR_DICT[cfg.name](cfg)
+        if sd is None:
+            sd = syn.seeded_state_dict(m.state_dict(), **winit)
+        m.load_state_dict(sd)
+        ms.append(m.cuda().eval())
+    B, H, W, K = 2, 96, 320, 64
+    P2, _ = syn.kitti_calib(W, batch=B)
+    batches = [(syn.mono_image(B, H, W, seed=70 + i).cuda(), P2.cuda()) for i in range(5)]
+    want = [_direct(ms[0], bt, K) for bt in batches]
+    pipe = InFlight([CapturedStep(m, batches[0], B, k=K, own_inputs=True) for m in ms[1:]])
+    for rnd in range(2):
+        tickets = [pipe.submit(*bt) for bt in batches[:4]]                # four submits = 2 x replicas: every record still valid
+        got = [[(s.clone(), b.clone(), l.clone()) for s, b, l in pipe.detections(t)] for t in tickets]
+        for j in range(4):
+            for f in range(B):
+                assert torch.equal(got[j][f][0], want[j][f][0]) and torch.equal(got[j][f][1], want[j][f][1]) and torch.equal(got[j][f][2], want[j][f][2]), (rnd, j, f)
