@@ -69,7 +69,7 @@ def parse():
                     help='steps in flight per GPU.  2 (default): two replicas of the detector (same weights; each its own hipGraph, static buffers and scratch) '
                          'are replayed alternately on two streams, so that step i + 1 starts under the tail of step i (select / NMS on 8 CUs, pack, D2H) and its '
                          'partially-filled rounds.  Every step is still one forward over `batch` pairs, read back and checked inside the timed region.  1: one '
-                         'replica, steps back to back (rounds 1 - 5; also reported in the line as `one_in_flight`).  --feed host / --no-graph / --no-overlap run with 1.')
+                         'replica, steps back to back (rounds 1 - 5; also reported in the line as `one_in_flight` for the resident feed).  --no-graph / --no-overlap run with 1.')
     ap.add_argument('--no-overlap', action='store_true',
                     help='no side streams (cls tower / stereo neck run serially on the main stream): the configuration whose '
                          'rocprofv3 --kernel-trace durations are additive (profiles/*_serial_*), NOT the headline configuration')
@@ -546,7 +546,7 @@ class HostFeed:
     copy stream; the step itself (captured in the hipGraph) starts with vd3d_preprocess_image on a STATIC device frame buffer
     (crop / cv2-style resize / pad / normalise -> the fp32 NCHW network input), which the main stream refreshes from ring slot
     (i & 1) right before the replay.  Upload i + 1 overlaps step i."""
-    def __init__(self, B, H, W, device, L, R, seed=0):
+    def __init__(self, B, H, W, device, L, R, seed=0, replicas=1):
         from visualdet3d_amd import hip_ops
         # The frames are the resident workload's own images as uint8 camera frames of the NETWORK's size (de-normalised, rounded to bytes): the
         # preprocessed input then equals the resident one up to the byte rounding (0.02 sigma) and the timed decode / NMS see the same ~100
@@ -556,7 +556,9 @@ class HostFeed:
         self.HS, self.WS = H, W
         self.host = [f.pin_memory() for f in self.slot_frames(L, R)]
         self.ring = [torch.empty((2 * B, self.HS, self.WS, 3), dtype=torch.uint8, device=device) for _ in range(2)]
-        self.frames = torch.empty((2 * B, self.HS, self.WS, 3), dtype=torch.uint8, device=device)       # the graph's static source
+        # the graphs' static sources: one per replica of the detector (two steps in flight: step i's frames are copied in while step i - 1 still reads its own)
+        self.frames_all = [torch.empty((2 * B, self.HS, self.WS, 3), dtype=torch.uint8, device=device) for _ in range(max(1, replicas))]
+        self.frames = self.frames_all[0]
         self.copy_stream = torch.cuda.Stream()
         self.uploaded = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
@@ -564,7 +566,8 @@ class HostFeed:
         self.mean, self.std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
         self.bytes_per_step = self.host[0].numel()
         self.hip_ops = hip_ops
-        self.frames.copy_(self.host[0])
+        for f in self.frames_all:
+            f.copy_(self.host[0])
 
     @staticmethod
     def slot_frames(L, R):
@@ -587,15 +590,15 @@ class HostFeed:
             self.ring[s].copy_(self.host[s], non_blocking=True)
             self.uploaded[s].record(self.copy_stream)
 
-    def before_step(self, i):
-        """main stream, right before step i's replay: wait for step i's frames, refresh the graph's static source from ring slot
+    def before_step(self, i, r=0):
+        """current stream (replica r's), right before step i's replay: wait for step i's frames, refresh that replica's static source from ring slot
         (i & 1), then start step i + 1's upload so that it travels while step i computes."""
         main = torch.cuda.current_stream()
         s = i & 1
         if i == 0:
             self.upload(0)                                          # first step of a run: nothing was prefetched for it
         main.wait_event(self.uploaded[s])
-        self.frames.copy_(self.ring[s], non_blocking=True)          # D2D, 22 MB at HBM speed
+        self.frames_all[r].copy_(self.ring[s], non_blocking=True)   # D2D, 22 MB at HBM speed
         self.consumed[s].record(main)
         self.upload(i + 1)
 
@@ -768,10 +771,10 @@ def time_api_config(c, device, calls=100, warm=10):
     return entry
 
 
-def run_in_flight(reps, n):
+def run_in_flight(reps, n, before=None):
     """n steps over the replicas `reps` = [(Stepper, stream), ...], step i on replica i % len(reps): `InFlight.run` -- replay, copy the packed record to the replica's
     pinned slot, record; the host waits for (and checks) step i - 1's record after step i is enqueued.  -> the counts of the last step."""
-    return InFlight([st for st, _ in reps], [s for _, s in reps]).run(n)
+    return InFlight([st for st, _ in reps], [s for _, s in reps]).run(n, before=before)
 
 
 def main():
@@ -821,7 +824,7 @@ def main():
     # other step does that, and the forks only cost (same box, two in flight: 3.467 / 3.453 ms with them, 3.364 / 3.393 / 3.396 without the neck fork, 3.352 / 3.355 /
     # 3.385 / 3.391 without any; one in flight: 3.66 with, 3.74 - 3.76 without).  So: two in flight = every step a ONE-stream graph (VD3D_BENCH_SIDE_STREAMS=1
     # keeps the forks, for the A/B); one in flight = forks on (--no-overlap: off).
-    n_fl_wanted = 1 if (args.feed == 'host' or args.no_graph or args.no_overlap) else args.in_flight
+    n_fl_wanted = 1 if (args.no_graph or args.no_overlap) else args.in_flight
     no_forks = args.no_overlap or (n_fl_wanted == 2 and not os.environ.get('VD3D_BENCH_SIDE_STREAMS'))
 
     def apply_knobs(m, no_forks=no_forks):
@@ -835,30 +838,39 @@ def main():
     from visualdet3d_amd import hip_ops
 
     feed = None
+    inputs_r = [inputs, inputs]                 # per replica: resident feed -> the same (read-only) tensors
+    pre_r = [None, None]
     if args.feed == 'host':
-        feed = HostFeed(B, args.height, args.width, device, L, R, seed=rank)
+        feed = HostFeed(B, args.height, args.width, device, L, R, seed=rank, replicas=n_fl_wanted)
         mean_c = (C_float3)(*feed.mean)
         std_c = (C_float3)(*feed.std)
         Hr, Wr, _ = hip_ops.resized_shape(feed.HS, feed.WS, 0, feed.size)
+        inputs_r = [inputs, (L.clone(), R.clone(), P2)]      # the preprocessing WRITES the network inputs: each replica its own
 
-        def preprocess():           # 2 x B launches inside the captured step: frame b -> L[b] / R[b] (fp32 NCHW, the reference's input)
-            from visualdet3d_amd import _lib
-            for b in range(2 * B):
-                dst = L[b] if b < B else R[b - B]
-                _lib.check(_lib.lib().vd3d_preprocess_image(feed.frames[b].data_ptr(), feed.HS, feed.WS, 0, Hr, Wr, dst.data_ptr(), None,
-                                                            args.height, args.width, mean_c, std_c, hip_ops._stream()), 'vd3d_preprocess_image')
-        feed.preprocess = preprocess
+        def make_preprocess(r):
+            Lr, Rr = inputs_r[r][0], inputs_r[r][1]
+            src = feed.frames_all[min(r, len(feed.frames_all) - 1)]
+
+            def preprocess():       # 2 x B launches inside the captured step: frame b -> L[b] / R[b] (fp32 NCHW, the reference's input)
+                from visualdet3d_amd import _lib
+                for b in range(2 * B):
+                    dst = Lr[b] if b < B else Rr[b - B]
+                    _lib.check(_lib.lib().vd3d_preprocess_image(src[b].data_ptr(), feed.HS, feed.WS, 0, Hr, Wr, dst.data_ptr(), None,
+                                                                args.height, args.width, mean_c, std_c, hip_ops._stream()), 'vd3d_preprocess_image')
+            return preprocess
+        pre_r = [make_preprocess(0), make_preprocess(1)]
+        feed.preprocess = pre_r[0]
 
     stepper = Stepper(model, inputs, B, device, use_graph=not args.no_graph, pre=feed.preprocess if feed else None)
     graph, pack_static = stepper.graph, stepper.pack_static
     # Steps in flight: replica r = (its Stepper, the stream its steps are enqueued on).  One replica: the current stream, steps back to back.  Two: a second
     # detector object with the same weights (nothing is shared between the two but the read-only inputs), each on its own stream; step i runs on replica i & 1.
-    n_fl = 1 if (feed or args.no_graph or graph is None or args.no_overlap) else args.in_flight      # (--no-overlap: ONE stream, kernel durations additive)
+    n_fl = 1 if (args.no_graph or graph is None or args.no_overlap) else args.in_flight      # (--no-overlap: ONE stream, kernel durations additive)
     reps = [(stepper, torch.cuda.current_stream())]
     if n_fl == 2:
         model2 = build_model(args, device)[0]
         apply_knobs(model2)
-        reps = [(stepper, torch.cuda.Stream()), (Stepper(model2, inputs, B, device), torch.cuda.Stream())]
+        reps = [(stepper, torch.cuda.Stream()), (Stepper(model2, inputs_r[1], B, device, pre=pre_r[1]), torch.cuda.Stream())]
         torch.cuda.synchronize()
 
     # Results leave the device every step, inside the timed region: the packed record of the step (B x (KDET + 1) x 13 floats,
@@ -890,7 +902,7 @@ def main():
         if not dist:
             if n_fl == 1:
                 return stepper.run(n, before_step=feed.before_step if feed else None)
-            return run_in_flight(reps, n)
+            return run_in_flight(reps, n, before=feed.before_step if feed else None)
         counts = None
 
         def collect(i):
@@ -919,6 +931,8 @@ def main():
                 q = i % RD
                 st, main = reps[i % n_fl]
                 with torch.cuda.stream(main):
+                    if feed:
+                        feed.before_step(i, i % n_fl)
                     st.forward_step()
                     gatherers[q].pack.copy_(st.pack_static, non_blocking=True)
                     packed_ev[q].record(main)
@@ -940,7 +954,7 @@ def main():
                 if i >= n_fl:
                     main.wait_event(taken_ev[(i - n_fl) % RD])   # this replica's previous record (step i - n_fl) has been copied out of its static buffer
                 if feed:
-                    feed.before_step(i)
+                    feed.before_step(i, i % n_fl)
                 st.forward_step()
                 packed_ev[q].record(main)
             with torch.cuda.stream(comm_stream):
@@ -1002,8 +1016,9 @@ def main():
             host_block = stepper.pinned_ring[0 if stepper.sync_each_step else last & 1]
         else:
             host_block = reps[last % n_fl][0].pinned_ring[(last // n_fl) & 1]
-        torch.save(dict(host=host_block.clone(), direct=[t.cpu() for t in stepper.forward_step()],
-                        inputs=[L.cpu(), R.cpu()] if feed else None),
+        last_st = reps[last % n_fl][0]                  # (host feed: the replica whose static inputs hold the last step's frames)
+        torch.save(dict(host=host_block.clone(), direct=[t.cpu() for t in last_st.forward_step()],
+                        inputs=[last_st.inputs[0].cpu(), last_st.inputs[1].cpu()] if feed else None),
                    os.environ['VD3D_BENCH_DUMP'])
 
     if rank == 0:
@@ -1060,7 +1075,7 @@ def main():
         }
         if gather_us is not None:
             line['config']['all_gather_us_per_step_rank0'] = round(gather_us, 1)
-        if n_fl == 2:
+        if n_fl == 2 and not feed:
             # for the record: the same steps one at a time (this rank alone, no collective), with the intra-step side streams that suit a lone step: rounds
             # 1 - 5's loop.  A third detector object for it (the replicas' graphs were captured without forks)
             model1 = build_model(args, device)[0]

@@ -140,13 +140,16 @@ class InFlight:
         k = len(self.steps)
         return self.steps[i % k], self.streams[i % k], (i // k) & 1
 
-    def submit(self, *inputs):
-        """Enqueue one step (copy-in of `inputs` if given, replay, D2H of the record) on the next replica's stream; returns its ticket at once."""
+    def submit(self, *inputs, before=None):
+        """Enqueue one step (copy-in of `inputs` if given, replay, D2H of the record) on the next replica's stream; returns its ticket at once.
+        `before(i, r)`: launches of the caller that must precede step i on replica r's stream (e.g. a refresh of what the step's `pre` reads)."""
         i = self.submitted
         st, s, slot = self._slot(i)
         if inputs:
             s.wait_stream(torch.cuda.current_stream())        # the caller's tensors were produced on the current stream
         with torch.cuda.stream(s):
+            if before is not None:
+                before(i, i % len(self.steps))
             if inputs:
                 st.set_inputs(*inputs)
             st.forward_step()
@@ -173,12 +176,12 @@ class InFlight:
         count = torch.clamp(rec[:, st.k, 0].round().to(torch.int32), max=st.k)
         return vdist.unpack_detections(rec[:, :st.k], count)
 
-    def run(self, n):
+    def run(self, n, before=None):
         """n steps on the static inputs, the host reading (and checking) step i - 1's record after enqueuing step i.  -> the counts of the last step."""
         counts = None
         first = self.submitted
         for j in range(n):
-            t = self.submit()
+            t = self.submit(before=before)
             if j >= 1:
                 counts = self.counts(t - 1)
         if n >= 1:
