@@ -868,10 +868,15 @@ def main():
     n_fl = 1 if (args.no_graph or graph is None or args.no_overlap) else args.in_flight      # (--no-overlap: ONE stream, kernel durations additive)
     reps = [(stepper, torch.cuda.current_stream())]
     if n_fl == 2:
-        model2 = build_model(args, device)[0]
-        apply_knobs(model2)
-        reps = [(stepper, torch.cuda.Stream()), (Stepper(model2, inputs_r[1], B, device, pre=pre_r[1]), torch.cuda.Stream())]
-        torch.cuda.synchronize()
+        try:
+            model2 = build_model(args, device)[0]
+            apply_knobs(model2)
+            reps = [(stepper, torch.cuda.Stream()), (Stepper(model2, inputs_r[1], B, device, pre=pre_r[1]), torch.cuda.Stream())]
+            torch.cuda.synchronize()
+        except torch.cuda.OutOfMemoryError as e:      # (not on a 288 GB part; the line says what ran: config.in_flight)
+            print('[bench] second replica does not fit (%s): ONE step in flight' % str(e).splitlines()[0], file=sys.stderr, flush=True)
+            n_fl, model2 = 1, None
+            torch.cuda.empty_cache()
 
     # Results leave the device every step, inside the timed region: the packed record of the step (B x (KDET + 1) x 13 floats,
     # ~53 KB) is copied to pinned host memory and its counts are checked on the host.
